@@ -1,0 +1,60 @@
+/*
+ * oracle/bwtc_oracle.h -- CPU restatement of the bwtc BWTManager/BWTransform hot path
+ * and of the 'H' (Huffman) entropy coder + stream framing around it.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bwtc_amd/ links, imports or executes this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
+ * only as the checker.  Pinned against: the reference's own libdivsufsort compiled from
+ * /root/reference (oracle/_ref, see oracle/Makefile), the golden vectors recorded from the
+ * reference in SURVEY.md 8c (tests/golden/), and the known-answer asserts of the
+ * reference's test/UtilsTest.cpp.
+ */
+#ifndef BWTC_ORACLE_H
+#define BWTC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BWT ---------------------------------------- */
+uint32_t orc_n_lf(uint32_t size, uint32_t starting_points);
+int  orc_suffix_array(const uint8_t *T, uint32_t n, uint32_t *SA);
+int  orc_bwt_raw(uint8_t *T, uint32_t n, uint32_t *lf, uint32_t n_lf, uint32_t *freqs);
+int  orc_bwt_block(uint8_t *block, uint32_t size, uint32_t starting_points,
+                   uint32_t *lf, uint32_t *n_lf_out, uint32_t *freqs);
+int  orc_inverse_bwt_block(uint8_t *block, uint32_t size, const uint32_t *lf, uint32_t n_lf);
+
+/* ---- utils (Utils.cpp / Utils.hpp) ----------------------------------------- */
+uint64_t orc_pack_integer(uint64_t v, int *bytes_needed);
+uint64_t orc_run_frequencies(uint64_t *run_freqs, const uint8_t *src, size_t len);
+uint64_t orc_run_frequencies_store(uint64_t *run_freqs, uint8_t *runseq, uint32_t *runlen,
+                                   const uint8_t *src, size_t len);
+int  orc_huffman_lengths(const uint64_t freqs[256], uint32_t clen[256]);
+void orc_huffman_codes(const uint32_t clen[256], uint32_t code[256]);
+/* bit strings are returned one bit per byte (0/1) for easy comparison with the
+ * reference's vector<bool> known answers; return value = number of bits */
+size_t orc_binary_code(size_t n, size_t lo, size_t hi, uint8_t *bits);
+size_t orc_binary_interpolative_code(const uint32_t *list, size_t count, size_t max_value,
+                                     uint8_t *bits);
+size_t orc_serialize_shape(const uint32_t clen[256], uint8_t *bits);
+uint32_t orc_sections(const uint32_t freqs[256], uint32_t section_len[256]);
+
+/* ---- 'H' coder + framing (HuffmanCoders.cpp, BWTBlock.cpp, Compressor.cpp) -- */
+size_t orc_write_bwtblock_header(const uint32_t *lf, uint32_t n_lf, uint8_t *out);
+/* encodes an already-transformed block; returns bytes written incl. the 6 length bytes */
+size_t orc_huffman_encode_block(const uint8_t *bwt, uint32_t size, const uint32_t *lf,
+                                uint32_t n_lf, const uint32_t freqs[256], uint8_t *out,
+                                size_t out_cap);
+/* full stream: 'H' + pblocks + 0x00.  block_size = bwt block size (Compressor.cpp:77-79) */
+size_t orc_compress_H(const uint8_t *in, size_t size, size_t block_size,
+                      uint32_t starting_points, uint8_t *out, size_t out_cap);
+/* returns decoded size, or (size_t)-1 on malformed input */
+size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_cap);
+size_t orc_compress_bound(size_t size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""ctypes bindings for the parity checker (oracle/liboracle.so and, when present,
+oracle/_ref/libbwtc_ref.so = the reference's own libdivsufsort).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under bwtc_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_sz = ctypes.c_size_t
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(p):
+            build()
+        L = ctypes.CDLL(p)
+        L.orc_n_lf.restype = _u32
+        L.orc_n_lf.argtypes = [_u32, _u32]
+        L.orc_suffix_array.argtypes = [_vp, _u32, _vp]
+        L.orc_bwt_raw.argtypes = [_vp, _u32, _vp, _u32, _vp]
+        L.orc_bwt_block.argtypes = [_vp, _u32, _u32, _vp, _vp, _vp]
+        L.orc_inverse_bwt_block.argtypes = [_vp, _u32, _vp, _u32]
+        L.orc_pack_integer.restype = ctypes.c_uint64
+        L.orc_pack_integer.argtypes = [ctypes.c_uint64, _vp]
+        L.orc_run_frequencies.restype = ctypes.c_uint64
+        L.orc_run_frequencies.argtypes = [_vp, _vp, _sz]
+        L.orc_huffman_lengths.argtypes = [_vp, _vp]
+        L.orc_huffman_codes.argtypes = [_vp, _vp]
+        L.orc_binary_code.restype = _sz
+        L.orc_binary_code.argtypes = [_sz, _sz, _sz, _vp]
+        L.orc_binary_interpolative_code.restype = _sz
+        L.orc_binary_interpolative_code.argtypes = [_vp, _sz, _sz, _vp]
+        L.orc_serialize_shape.restype = _sz
+        L.orc_serialize_shape.argtypes = [_vp, _vp]
+        L.orc_sections.restype = _u32
+        L.orc_sections.argtypes = [_vp, _vp]
+        L.orc_write_bwtblock_header.restype = _sz
+        L.orc_write_bwtblock_header.argtypes = [_vp, _u32, _vp]
+        L.orc_huffman_encode_block.restype = _sz
+        L.orc_huffman_encode_block.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _sz]
+        L.orc_compress_H.restype = _sz
+        L.orc_compress_H.argtypes = [_vp, _sz, _sz, _u32, _vp, _sz]
+        L.orc_decompress_H.restype = _sz
+        L.orc_decompress_H.argtypes = [_vp, _sz, _vp, _sz]
+        L.orc_compress_bound.restype = _sz
+        L.orc_compress_bound.argtypes = [_sz]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's libdivsufsort (oracle/_ref), or None when it was not built."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libbwtc_ref.so")
+        if not os.path.exists(p):
+            return None
+        R = ctypes.CDLL(p)
+        R.ref_bwt_raw.argtypes = [_vp, _u32, _vp, _u32, _vp]
+        R.ref_bwt_block.argtypes = [_vp, _u32, _u32, _vp, _vp, _vp]
+        _ref = R
+    return _ref
+
+
+def _bwt_block(fn, data, sp, pad=0xA5):
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    size = data.size
+    buf = np.empty(size + 1, np.uint8)
+    buf[:size] = data
+    buf[size] = pad
+    lf = np.zeros(256, np.uint32)
+    nlf = _u32(0)
+    freqs = np.zeros(256, np.uint32)
+    fn(_ptr(buf), size, sp, _ptr(lf), ctypes.byref(nlf), _ptr(freqs))
+    assert buf[size] == pad, "byte after the block must be preserved"
+    return buf[:size].copy(), lf[:nlf.value].copy(), freqs
+
+
+def oracle_bwt_block(data, sp=8):
+    """(bwt bytes, LFpowers, freqs) per BWTManager::doTransform(block, freqs)."""
+    return _bwt_block(lib().orc_bwt_block, data, sp)
+
+
+def ref_bwt_block(data, sp=8):
+    return _bwt_block(ref().ref_bwt_block, data, sp)
+
+
+def oracle_inverse_bwt_block(bwt, lf):
+    b = np.array(bwt, dtype=np.uint8, copy=True)
+    lfa = np.array(lf, dtype=np.uint32)
+    rc = lib().orc_inverse_bwt_block(_ptr(b), b.size, _ptr(lfa), lfa.size)
+    return rc, b
+
+
+def oracle_suffix_array(T):
+    T = np.ascontiguousarray(T, dtype=np.uint8)
+    sa = np.zeros(T.size, np.uint32)
+    lib().orc_suffix_array(_ptr(T), T.size, _ptr(sa))
+    return sa
+
+
+def oracle_huffman_encode_block(bwt, lf, freqs):
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    lf = np.ascontiguousarray(lf, dtype=np.uint32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    cap = lib().orc_compress_bound(bwt.size)
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_huffman_encode_block(_ptr(bwt), bwt.size, _ptr(lf), lf.size, _ptr(freqs),
+                                       _ptr(out), cap)
+    return out[:n].copy()
+
+
+def oracle_compress_H(data, block_size, sp=8):
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    data = np.ascontiguousarray(data)
+    nblocks = (data.size + block_size - 1) // max(block_size, 1) + 1
+    cap = lib().orc_compress_bound(data.size) + nblocks * 8192
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_compress_H(_ptr(data), data.size, block_size, sp, _ptr(out), cap)
+    return out[:n].copy()
+
+
+def oracle_decompress_H(stream, max_size):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    out = np.zeros(max(max_size, 1), np.uint8)
+    n = lib().orc_decompress_H(_ptr(stream), stream.size, _ptr(out), out.size)
+    if n == ctypes.c_size_t(-1).value:
+        return None
+    return out[:n].copy()
