@@ -1,0 +1,483 @@
+// BwtEngine implementation: kernels + host orchestration.  See bwt_engine.hpp.
+#include "bwt_engine.hpp"
+#include "radix_sort.hpp"
+#include <cstring>
+
+namespace bwtc_hip {
+
+// ---------------------------------------------------------------------------------------
+// K1  load (+reverse) + 256-bin histogram.  T[j] = src[size-1-j] (reverse) or src[j], for
+//     j < size; T[size..] = 0 up to the padded end.  The histogram is over the `size`
+//     source bytes (BWTransform.cpp:53-55 + divsufsort.c:506-512: the sentinel is never
+//     counted).  4 bytes per thread, one dword store; LDS histogram, one global atomic per
+//     non-empty bin per workgroup.
+// ---------------------------------------------------------------------------------------
+constexpr int kLoadTPB = 256;
+
+__global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ src,
+                                                        u8* __restrict__ T, u32 size,
+                                                        u32 padded_words, int reverse,
+                                                        u32* __restrict__ freqs) {
+  __shared__ u32 hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 w = blockIdx.x * kLoadTPB + threadIdx.x;
+  if (w < padded_words) {
+    const u32 j0 = w * 4u;
+    u32 word = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 j = j0 + b;
+      if (j < size) {
+        const u32 c = src[reverse ? (size - 1u - j) : j];
+        word |= c << (8 * b);
+        atomicAdd(&hist[c], 1u);
+      }
+    }
+    reinterpret_cast<u32*>(T)[w] = word;
+  }
+  __syncthreads();
+  const u32 c = hist[threadIdx.x];
+  if (c) atomicAdd(&freqs[threadIdx.x], c);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2  initial keys.  Slot j holds suffix i = n-1-j (descending!) with the big-endian
+//     4-byte key T[i..i+3] (zero padded past the end).  Feeding the stable sort in
+//     descending suffix order puts, inside every group of equal keys, the suffixes that
+//     are shorter than 4 first and shortest-first -- exactly "proper prefix sorts first".
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
+                                                   u32* __restrict__ keys,
+                                                   u32* __restrict__ idx, u32 n) {
+  const u32 j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const u32 i = n - 1u - j;
+  const u32 key = ((u32)T[i] << 24) | ((u32)T[i + 1] << 16) | ((u32)T[i + 2] << 8) | (u32)T[i + 3];
+  keys[j] = key;
+  idx[j] = i;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4  re-ranking of a sorted list (INIT: the whole SA after the 4-byte sort, keys u32;
+//     rounds: the active list after sorting by (group, rank[s+h]), keys u64).
+//
+//     head[p]   = p starts a new group (key differs from p-1; INIT: or p-1 is shorter
+//                 than the key, which makes it a finished singleton)
+//     active[p] = p's group has >= 2 members
+//     new rank of p = global SA slot of its group head
+//     finished suffixes go to SA; active ones are compacted (order kept) into the next
+//     active list with their global slot and a dense group number.
+//     Three launches: tile reduce, one-workgroup scan of the tile aggregates, tile apply.
+// ---------------------------------------------------------------------------------------
+constexpr int kRrTPB = 256;
+constexpr int kRrE = 8;
+constexpr int kRrTile = kRrTPB * kRrE;
+
+template <typename K, bool INIT>
+struct RrFlags {
+  u32 head;   // bit e: element e is a group head
+  u32 act;    // bit e: element e stays active
+  u32 valid;  // bit e: element e exists
+};
+
+template <typename K, bool INIT>
+__device__ __forceinline__ RrFlags<K, INIT> rr_flags(const K* __restrict__ key,
+                                                     const u32* __restrict__ idx, u32 m, u32 n,
+                                                     u32 p0) {
+  RrFlags<K, INIT> f;
+  f.head = 0; f.act = 0; f.valid = 0;
+  if (p0 >= m) return f;
+  K k[kRrE + 2];
+  u32 s[kRrE + 1];   // s[e] = idx[p0 - 1 + e]  (INIT only)
+  k[0] = (p0 > 0) ? key[p0 - 1] : (K)0;
+  if (INIT) s[0] = (p0 > 0) ? idx[p0 - 1] : 0u;
+#pragma unroll
+  for (int e = 0; e < kRrE + 1; ++e) {
+    const u32 p = p0 + e;
+    k[e + 1] = (p < m) ? key[p] : (K)0;
+    if (INIT && e < kRrE) s[e + 1] = (p < m) ? idx[p] : 0u;
+  }
+  u32 head = 0;   // kRrE + 1 bits
+#pragma unroll
+  for (int e = 0; e < kRrE + 1; ++e) {
+    const u32 p = p0 + e;
+    bool h;
+    if (p >= m) h = true;
+    else if (p == 0) h = true;
+    else {
+      h = k[e + 1] != k[e];
+      if (INIT) h = h || ((u64)s[e] + 3u >= (u64)n);
+    }
+    head |= (h ? 1u : 0u) << e;
+  }
+#pragma unroll
+  for (int e = 0; e < kRrE; ++e) {
+    const u32 p = p0 + e;
+    if (p < m) {
+      f.valid |= 1u << e;
+      const bool h = (head >> e) & 1u, hn = (head >> (e + 1)) & 1u;
+      if (!h || !hn) f.act |= 1u << e;
+    }
+  }
+  f.head = head & f.valid;
+  return f;
+}
+
+template <typename K, bool INIT>
+__global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
+                                                          const u32* __restrict__ idx, u32 m,
+                                                          u32 n, u32* __restrict__ aggA,
+                                                          u32* __restrict__ aggB,
+                                                          u32* __restrict__ aggC) {
+  __shared__ u32 scr[kRrTPB / kWave + 1];
+  const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
+  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, p0);
+  const u32 nact = __popc(f.act);
+  const u32 nha = __popc(f.act & f.head);
+  const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
+  u32 ta, tb, tc;
+  block_scan_excl_add<kRrTPB>(nact, scr, &ta);
+  block_scan_excl_add<kRrTPB>(nha, scr, &tb);
+  block_scan_incl_max<kRrTPB>(last, scr, &tc);
+  if (threadIdx.x == 0) { aggA[blockIdx.x] = ta; aggB[blockIdx.x] = tb; aggC[blockIdx.x] = tc; }
+}
+
+// One workgroup: exclusive sum of aggA, aggB; exclusive max of aggC; totals -> counts[0..1].
+__global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ aggA,
+                                                            u32* __restrict__ aggB,
+                                                            u32* __restrict__ aggC, u32 ntiles,
+                                                            u32* __restrict__ counts) {
+  __shared__ u32 scr[1024 / kWave + 1];
+  __shared__ u32 s_prev[1024];
+  const u32 per = (ntiles + 1023u) / 1024u;
+  const u32 b = threadIdx.x * per;
+  const u32 e = min(b + per, ntiles);
+  u32 sa = 0, sb = 0, sc = 0;
+  for (u32 i = b; i < e; ++i) { sa += aggA[i]; sb += aggB[i]; sc = max(sc, aggC[i]); }
+  u32 ta, tb, tc;
+  u32 oa = block_scan_excl_add<1024>(sa, scr, &ta);
+  u32 ob = block_scan_excl_add<1024>(sb, scr, &tb);
+  u32 ic = block_scan_incl_max<1024>(sc, scr, &tc);
+  s_prev[threadIdx.x] = ic;
+  __syncthreads();
+  u32 oc = threadIdx.x ? s_prev[threadIdx.x - 1] : 0u;
+  for (u32 i = b; i < e; ++i) {
+    u32 va = aggA[i], vb = aggB[i], vc = aggC[i];
+    aggA[i] = oa; aggB[i] = ob; aggC[i] = oc;
+    oa += va; ob += vb; oc = max(oc, vc);
+  }
+  if (threadIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
+}
+
+template <typename K, bool INIT>
+__global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
+    const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
+    u32 n, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
+    const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
+    u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out) {
+  __shared__ u32 scr[kRrTPB / kWave + 1];
+  __shared__ u32 s_prev[kRrTPB];
+  const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
+  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, p0);
+  const u32 nact = __popc(f.act);
+  const u32 nha = __popc(f.act & f.head);
+  const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
+  u32 t;
+  u32 q = block_scan_excl_add<kRrTPB>(nact, scr, &t) + aggA[blockIdx.x];
+  u32 gcount = block_scan_excl_add<kRrTPB>(nha, scr, &t) + aggB[blockIdx.x];
+  const u32 incl = block_scan_incl_max<kRrTPB>(last, scr, &t);
+  s_prev[threadIdx.x] = incl;
+  __syncthreads();
+  u32 hp1 = max(threadIdx.x ? s_prev[threadIdx.x - 1] : 0u, aggC[blockIdx.x]);  // head pos + 1
+#pragma unroll
+  for (int e = 0; e < kRrE; ++e) {
+    if (!((f.valid >> e) & 1u)) break;
+    const u32 p = p0 + e;
+    const bool h = (f.head >> e) & 1u, a = (f.act >> e) & 1u;
+    if (h) hp1 = p + 1u;
+    if (h && a) ++gcount;
+    const u32 hp = hp1 - 1u;
+    const u32 s = idx[p];
+    const u32 g = INIT ? p : aglob[p];
+    const u32 nr = INIT ? hp : aglob[hp];
+    rank[s] = nr;
+    if (a) {
+      aidx_out[q] = s;
+      aglob_out[q] = g;
+      agrp_out[q] = gcount - 1u;
+      ++q;
+    } else {
+      SA[g] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5  second sort key of a doubling round:  (group << b2) | key2,  key2 = rank[s+h] + 1,
+//     or 0 for the one suffix whose h-successor is the empty suffix.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_key2(const u32* __restrict__ aidx,
+                                                     const u32* __restrict__ agrp,
+                                                     const u32* __restrict__ rank,
+                                                     u64* __restrict__ key, u32 m, u32 n, u32 h,
+                                                     int b2) {
+  const u32 p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= m) return;
+  const u64 t = (u64)aidx[p] + (u64)h;
+  const u64 key2 = (t < (u64)n) ? (u64)rank[t] + 1ull : 0ull;
+  key[p] = ((u64)agrp[p] << b2) | key2;
+}
+
+// ---------------------------------------------------------------------------------------
+// K9  BWT gather: out[j] = T[SA[j]-1]; the row of suffix 0 is the end-of-block row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwt_gather(const u32* __restrict__ SA,
+                                                    const u8* __restrict__ T,
+                                                    u8* __restrict__ out, u32 n,
+                                                    u32* __restrict__ pidx) {
+  const u32 w = blockIdx.x * 256u + threadIdx.x;
+  const u32 j0 = w * 4u;
+  if (j0 >= n) return;
+  u32 word = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const u32 j = j0 + b;
+    if (j < n) {
+      const u32 s = SA[j];
+      u32 c = 0;
+      if (s) c = T[s - 1];
+      else *pidx = j;
+      word |= c << (8 * b);
+    }
+  }
+  reinterpret_cast<u32*>(out)[w] = word;
+}
+
+// End-of-block patch + LF powers.  block mode: out[pidx] = out[n-1] (BWTransform.cpp:60);
+// raw mode: out[pidx] = the input byte at pidx (divsufsort.c:507-511 leaves it untouched).
+// LF[0] = pidx, LF[k] = ISA[n - k*(n/nLF)] (divsufsort.c:337-338,350,381,390).
+__global__ void k_finalize(u8* __restrict__ out, const u8* __restrict__ T,
+                           const u32* __restrict__ rank, u32* __restrict__ lf, u32 n_lf, u32 n,
+                           const u32* __restrict__ pidx, int raw) {
+  const u32 p = *pidx;
+  const u32 k = threadIdx.x;
+  if (k == 0) {
+    out[p] = raw ? T[p] : out[n - 1];
+    lf[0] = p;
+  } else if (k < n_lf) {
+    const u32 x = n / n_lf;
+    lf[k] = rank[n - k * x];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+
+struct ArenaPlan {
+  u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
+      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, total;
+};
+
+static ArenaPlan plan_arena(u64 cap) {
+  ArenaPlan a;
+  u64 o = 0;
+  auto take = [&](u64 bytes) { u64 r = o; o = align_up(o + bytes, 256); return r; };
+  a.off_T = take(cap + 32);
+  a.off_out = take(cap + 32);
+  a.off_in = take(cap + 32);
+  a.off_SA = take(cap * 4);
+  a.off_rank = take(cap * 4);
+  a.off_R1 = take(cap * 8);
+  a.off_R2 = take(cap * 8);
+  a.off_V0 = take(cap * 4);
+  a.off_V1 = take(cap * 4);
+  a.off_G0 = take(cap * 4);
+  a.off_G1 = take(cap * 4);
+  a.off_GRP = take(cap * 4);
+  a.off_table = take(radix_table_words(cap) * 4);
+  a.off_partial = take(radix_partial_words(cap) * 4);
+  const u64 rr_tiles = (cap + kRrTile - 1) / kRrTile + 1;
+  a.off_aggA = take(rr_tiles * 4);
+  a.off_aggB = take(rr_tiles * 4);
+  a.off_aggC = take(rr_tiles * 4);
+  a.off_small = take(1024 * 4);
+  a.total = o;
+  return a;
+}
+
+u64 BwtEngine::workspace_bytes(u32 max_block) { return plan_arena((u64)max_block + 1).total; }
+
+int BwtEngine::init(int dev, u32 max_block_size) {
+  device = dev;
+  max_block = max_block_size;
+  cap = (u64)max_block_size + 1;
+  std::memset(&stats, 0, sizeof stats);
+  BWTC_HIP_TRY(hipSetDevice(dev));
+  BWTC_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  const ArenaPlan a = plan_arena(cap);
+  arena_bytes = a.total;
+  BWTC_HIP_TRY(hipMalloc(&arena, arena_bytes));
+  u8* base = static_cast<u8*>(arena);
+  d_T = base + a.off_T;
+  d_out = base + a.off_out;
+  d_in = base + a.off_in;
+  d_SA = reinterpret_cast<u32*>(base + a.off_SA);
+  d_rank = reinterpret_cast<u32*>(base + a.off_rank);
+  d_R1 = base + a.off_R1;
+  d_R2 = base + a.off_R2;
+  d_V0 = reinterpret_cast<u32*>(base + a.off_V0);
+  d_V1 = reinterpret_cast<u32*>(base + a.off_V1);
+  d_G0 = reinterpret_cast<u32*>(base + a.off_G0);
+  d_G1 = reinterpret_cast<u32*>(base + a.off_G1);
+  d_GRP = reinterpret_cast<u32*>(base + a.off_GRP);
+  d_table = reinterpret_cast<u32*>(base + a.off_table);
+  d_partial = reinterpret_cast<u32*>(base + a.off_partial);
+  d_aggA = reinterpret_cast<u32*>(base + a.off_aggA);
+  d_aggB = reinterpret_cast<u32*>(base + a.off_aggB);
+  d_aggC = reinterpret_cast<u32*>(base + a.off_aggC);
+  d_small = reinterpret_cast<u32*>(base + a.off_small);
+  BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
+  BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
+  BWTC_HIP_TRY(hipEventCreate(&ev_begin));
+  BWTC_HIP_TRY(hipEventCreate(&ev_end));
+  for (int i = 0; i < kMaxSortEvents; ++i) BWTC_HIP_TRY(hipEventCreate(&ev_sort[i]));
+  return 0;
+}
+
+void BwtEngine::release() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  if (arena) (void)hipFree(arena);
+  if (h_small) (void)hipHostFree(h_small);
+  if (h_stage) (void)hipHostFree(h_stage);
+  if (ev_begin) (void)hipEventDestroy(ev_begin);
+  if (ev_end) (void)hipEventDestroy(ev_end);
+  for (int i = 0; i < kMaxSortEvents; ++i) if (ev_sort[i]) (void)hipEventDestroy(ev_sort[i]);
+  if (stream) (void)hipStreamDestroy(stream);
+  arena = nullptr; h_small = nullptr; h_stage = nullptr; stream = nullptr;
+}
+
+static constexpr int kSmallFreqs = 0, kSmallLf = 256, kSmallPidx = 512, kSmallCounts = 520;
+
+int BwtEngine::suffix_sort(u32 n) {
+  hipStream_t st = stream;
+  n_sort_events = 0;
+  stats.rounds = 0;
+  stats.active_sum = 0;
+  stats.sort_pass_items = 0;
+  if (n == 0) return 0;
+
+  u32* K32a = static_cast<u32*>(d_R1);
+  u32* K32b = K32a + cap;
+  hipLaunchKernelGGL(k_make_keys, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, K32a, d_V0, n);
+
+  u32 *ks = nullptr, *vs = nullptr;
+  BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  radix_sort_pairs<u32>(K32a, K32b, d_V0, d_V1, n, 32, d_table, d_partial, st, &ks, &vs);
+  BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  stats.sort_pass_items += (u64)n * 4;
+
+  // initial ranking.  Sorted suffixes are in vs; the other V buffer receives the active list.
+  u32* aidx = (vs == d_V0) ? d_V1 : d_V0;
+  u32* aidx_other = vs;             // free once the ranking has consumed it
+  u32* aglob = d_G0;
+  u32* aglob_other = d_G1;
+  u32* counts = d_small + kSmallCounts;
+  {
+    const u32 tiles = ceil_div(n, kRrTile);
+    hipLaunchKernelGGL((k_rerank_reduce<u32, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, n,
+                       n, d_aggA, d_aggB, d_aggC);
+    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
+                       tiles, counts);
+    hipLaunchKernelGGL((k_rerank_apply<u32, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
+                       (const u32*)nullptr, n, n, d_aggA, d_aggB, d_aggC, d_rank, d_SA, aidx,
+                       aglob, d_GRP);
+  }
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  u32 m = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
+
+  u64* K64a = static_cast<u64*>(d_R1);
+  u64* K64b = static_cast<u64*>(d_R2);
+  const int b2 = bit_width_u64(n);    // key2 <= n
+  u64 h = 4;
+  while (m > 0) {
+    if (h >= (u64)n * 2 + 8) return -3;   // cannot happen: every group splits by then
+    ++stats.rounds;
+    stats.active_sum += m;
+    const int b1 = bit_width_u64(groups ? groups - 1 : 0);
+    hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m, 256)), dim3(256), 0, st, aidx, d_GRP,
+                       d_rank, K64a, m, n, (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFu : h), b2);
+    u64* k64s = nullptr;
+    u32* v64s = nullptr;
+    const int nbits = b1 + b2;
+    const bool timed = n_sort_events + 2 <= kMaxSortEvents;
+    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    radix_sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, d_table, d_partial, st, &k64s,
+                          &v64s);
+    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    stats.sort_pass_items += (u64)m * (u64)((nbits + kRadixBits - 1) / kRadixBits);
+    u32* next_aidx = (v64s == aidx) ? aidx_other : aidx;
+    const u32 tiles = ceil_div(m, kRrTile);
+    hipLaunchKernelGGL((k_rerank_reduce<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
+                       v64s, m, n, d_aggA, d_aggB, d_aggC);
+    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
+                       tiles, counts);
+    hipLaunchKernelGGL((k_rerank_apply<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s, v64s,
+                       aglob, m, n, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx, aglob_other,
+                       d_GRP);
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipStreamSynchronize(st));
+    m = h_small[kSmallCounts];
+    groups = h_small[kSmallCounts + 1];
+    aidx_other = v64s;
+    aidx = next_aidx;
+    { u32* t = aglob; aglob = aglob_other; aglob_other = t; }
+    h *= 2;
+  }
+  return 0;
+}
+
+int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf, u32 n_lf,
+                         u32* freqs) {
+  hipStream_t st = stream;
+  // block mode: size source bytes, n = size + 1 suffixes.  raw mode: `size` is the length
+  // of T including the caller's sentinel, so the source bytes that count are size - 1.
+  const u32 n = raw ? size : size + 1u;
+  const u32 nsrc = n - 1u;
+  if (n_lf == 0 || n_lf > 256 || !lf) return -1;
+  if ((u64)n > cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(device));
+  BWTC_HIP_TRY(hipEventRecord(ev_begin, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_small, 0, 1024 * 4, st));
+  const u32 padded_words = (u32)(((u64)n + 8 + 3) / 4);
+  hipLaunchKernelGGL(k_load_hist, dim3(ceil_div(padded_words, kLoadTPB)), dim3(kLoadTPB), 0, st,
+                     d_src, d_T, nsrc, padded_words, raw ? 0 : 1, d_small + kSmallFreqs);
+  int rc = suffix_sort(n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bwt_gather, dim3(ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, st, d_SA,
+                     d_T, d_out, n, d_small + kSmallPidx);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d_out, d_T, d_rank,
+                     d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0);
+  if (raw ? n : size)
+    BWTC_HIP_TRY(hipMemcpyAsync(d_dst, d_out, raw ? n : size, hipMemcpyDeviceToDevice, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small, d_small, 520 * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipEventRecord(ev_end, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(hipGetLastError());
+  for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
+  if (freqs) for (int c = 0; c < 256; ++c) freqs[c] += h_small[kSmallFreqs + c];
+  stats.n = n;
+  (void)hipEventElapsedTime(&stats.ms_total, ev_begin, ev_end);
+  stats.ms_sort = 0.f;
+  for (int i = 0; i + 1 < n_sort_events; i += 2) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev_sort[i], ev_sort[i + 1]);
+    stats.ms_sort += ms;
+  }
+  return 0;
+}
+
+}  // namespace bwtc_hip

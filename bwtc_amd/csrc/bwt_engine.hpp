@@ -1,0 +1,73 @@
+// BwtEngine: device-resident Burrows-Wheeler transform of one block on one MI355X.
+//
+// Replaces the work of Divsufsorter / SAISBWTransform behind
+// BWTransform::doTransform (bwtransforms/BWTransform.hpp:53-58, BWTransform.cpp:52-64):
+// suffix sort of T = reverse(block) + '\0' under "proper prefix sorts first", BWT
+// emission with the reference's end-of-block and LFpowers conventions
+// (bwtransforms/divsufsort.c:328-404,480-522) and the 256-bin histogram.
+//
+// Algorithm (integer / index work, HBM-bound, no MFMA):
+//   1. load+reverse+histogram, 4-byte big-endian keys            (streaming)
+//   2. LSD radix sort of (key32, suffix) pairs                   (radix_sort.hpp)
+//   3. ranking: group heads -> rank[], singleton suffixes are final, the rest is
+//      compacted into the active list (suffix, global slot, dense group id)
+//   4. prefix doubling with discarding: per round gather rank[s+h], radix sort the active
+//      list by (group, rank[s+h]), re-rank, compact; stop when nothing is active
+//   5. BWT gather T[SA-1], end-of-block patch, LF powers from the final rank[] (= ISA)
+#pragma once
+#include "common.hpp"
+#include "bwtc_hip.h"
+
+namespace bwtc_hip {
+
+struct BwtEngine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  u32 max_block = 0;     // largest block size in bytes
+  u64 cap = 0;           // suffix capacity = max_block + 1
+
+  // device workspace
+  void* arena = nullptr;
+  u64 arena_bytes = 0;
+  u8* d_T = nullptr;       // cap + 32
+  u8* d_out = nullptr;     // cap + 32
+  u8* d_in = nullptr;      // staging for host blocks: cap + 32
+  u32* d_SA = nullptr;     // cap
+  u32* d_rank = nullptr;   // cap
+  void* d_R1 = nullptr;    // 8*cap : K32a|K32b, later K64a
+  void* d_R2 = nullptr;    // 8*cap : K64b
+  u32* d_V0 = nullptr;     // cap
+  u32* d_V1 = nullptr;     // cap
+  u32* d_G0 = nullptr;     // cap
+  u32* d_G1 = nullptr;     // cap
+  u32* d_GRP = nullptr;    // cap
+  u32* d_table = nullptr;  // radix tables
+  u32* d_partial = nullptr;
+  u32* d_aggA = nullptr;   // rerank tile aggregates
+  u32* d_aggB = nullptr;
+  u32* d_aggC = nullptr;
+  u32* d_small = nullptr;  // [0..255] freqs, [256..511] lf, [512] pidx, [520..521] counts
+  u32* h_small = nullptr;  // pinned mirror of d_small
+  u8* h_stage = nullptr;   // pinned staging, cap + 32
+
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  static constexpr int kMaxSortEvents = 160;
+  hipEvent_t ev_sort[kMaxSortEvents];
+  int n_sort_events = 0;
+
+  bwtc_hip_stats stats;
+
+  static u64 workspace_bytes(u32 max_block);
+  int init(int dev, u32 max_block_size);
+  void release();
+
+  // Sorts the suffixes of d_T[0..n-1]; on return d_SA holds the suffix array and d_rank
+  // its inverse.  d_T must be followed by >= 8 zero bytes.
+  int suffix_sort(u32 n);
+  // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).
+  // raw=false: block semantics (reverse, sentinel, EOB patch).  raw=true: d_src already is
+  // T (size = length), position pidx keeps its input byte.
+  int transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf, u32 n_lf, u32* freqs);
+};
+
+}  // namespace bwtc_hip

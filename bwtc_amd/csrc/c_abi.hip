@@ -1,0 +1,167 @@
+// extern "C" surface of libbwtc_hip.so (include/bwtc_hip.h).
+#include "bwt_engine.hpp"
+#include "radix_sort.hpp"
+#include "bwtc_hip.h"
+#include <cstring>
+#include <new>
+
+using namespace bwtc_hip;
+
+struct bwtc_hip_ctx {
+  BwtEngine eng;
+};
+
+template <typename K>
+static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int nbits) {
+  if (!ctx || !keys || !vals) return -1;
+  BwtEngine& e = ctx->eng;
+  if (n > e.cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  K* k0 = static_cast<K*>(e.d_R1);
+  K* k1 = static_cast<K*>(e.d_R2);
+  BWTC_HIP_TRY(hipMemcpyAsync(k0, keys, n * sizeof(K), hipMemcpyHostToDevice, e.stream));
+  BWTC_HIP_TRY(hipMemcpyAsync(e.d_V0, vals, n * 4, hipMemcpyHostToDevice, e.stream));
+  K* ks; u32* vs;
+  radix_sort_pairs<K>(k0, k1, e.d_V0, e.d_V1, n, nbits, e.d_table, e.d_partial, e.stream, &ks, &vs);
+  BWTC_HIP_TRY(hipMemcpyAsync(keys, ks, n * sizeof(K), hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipMemcpyAsync(vals, vs, n * 4, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+int bwtc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* bwtc_hip_version(void) { return "bwtc_hip 0.1 (gfx950)"; }
+
+uint64_t bwtc_hip_workspace_bytes(uint32_t max_block_size) {
+  return BwtEngine::workspace_bytes(max_block_size);
+}
+
+int bwtc_hip_create(int device, uint32_t max_block_size, bwtc_hip_ctx** ctx_out) {
+  if (!ctx_out) return -1;
+  *ctx_out = nullptr;
+  if (max_block_size >= 0x7FFFFFFEu) return -1;   // PrecompressorBlock.cpp:126
+  bwtc_hip_ctx* c = new (std::nothrow) bwtc_hip_ctx();
+  if (!c) return -2;
+  for (int i = 0; i < BwtEngine::kMaxSortEvents; ++i) c->eng.ev_sort[i] = nullptr;
+  int rc = c->eng.init(device, max_block_size);
+  if (rc != 0) { c->eng.release(); delete c; return rc; }
+  *ctx_out = c;
+  return 0;
+}
+
+void bwtc_hip_destroy(bwtc_hip_ctx* ctx) {
+  if (!ctx) return;
+  ctx->eng.release();
+  delete ctx;
+}
+
+void* bwtc_hip_stream(bwtc_hip_ctx* ctx) { return ctx ? (void*)ctx->eng.stream : nullptr; }
+
+int bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out) {
+  if (!ctx || !out) return -1;
+  *out = ctx->eng.stats;
+  return 0;
+}
+
+uint32_t bwtc_hip_n_lf(uint32_t size, uint32_t starting_points) {
+  if (starting_points < 1) starting_points = 1;          // BWTManager.cpp:60-64
+  else if (starting_points > 256) starting_points = 256;
+  if (size <= 256) return 1;                             // BWTBlock.cpp:104-108
+  return starting_points;
+}
+
+static int stage_in(BwtEngine& e, const uint8_t* host, uint32_t bytes) {
+  if (!bytes) return 0;
+  std::memcpy(e.h_stage, host, bytes);
+  BWTC_HIP_TRY(hipMemcpyAsync(e.d_in, e.h_stage, bytes, hipMemcpyHostToDevice, e.stream));
+  return 0;
+}
+static int stage_out(BwtEngine& e, uint8_t* host, uint32_t bytes) {
+  if (!bytes) return 0;
+  BWTC_HIP_TRY(hipMemcpyAsync(e.h_stage, e.d_in, bytes, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  std::memcpy(host, e.h_stage, bytes);
+  return 0;
+}
+
+int bwtc_hip_bwt(bwtc_hip_ctx* ctx, uint8_t* T, uint32_t length, uint32_t* lf, uint32_t n_lf,
+                 uint32_t* freqs) {
+  if (!ctx || !T || !lf || n_lf == 0) return -1;
+  if (length <= 1) return 0;                             // divsufsort.c:489
+  BwtEngine& e = ctx->eng;
+  if ((u64)length > e.cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, T, length);
+  if (rc) return rc;
+  rc = e.transform(e.d_in, e.d_in, length, true, lf, n_lf, freqs);
+  if (rc) return rc;
+  return stage_out(e, T, length);
+}
+
+int bwtc_hip_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size, uint32_t* lf,
+                       uint32_t n_lf, uint32_t* freqs) {
+  if (!ctx || (!block && size) || !lf || n_lf == 0) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, block, size);
+  if (rc) return rc;
+  rc = e.transform(e.d_in, e.d_in, size, false, lf, n_lf, freqs);
+  if (rc) return rc;
+  return stage_out(e, block, size);
+}
+
+int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d_out,
+                              uint32_t size, uint32_t* lf, uint32_t n_lf, uint32_t* freqs) {
+  if (!ctx || ((!d_in || !d_out) && size) || !lf || n_lf == 0) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  return e.transform(d_in, d_out, size, false, lf, n_lf, freqs);
+}
+
+int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, uint32_t* sa) {
+  if (!ctx || !T || !sa) return -1;
+  if (length == 0) return 0;
+  BwtEngine& e = ctx->eng;
+  if ((u64)length > e.cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  BWTC_HIP_TRY(hipMemsetAsync(e.d_T, 0, (u64)length + 16, e.stream));
+  BWTC_HIP_TRY(hipMemcpyAsync(e.d_T, T, length, hipMemcpyHostToDevice, e.stream));
+  int rc = e.suffix_sort(length);
+  if (rc) return rc;
+  BWTC_HIP_TRY(hipMemcpyAsync(sa, e.d_SA, (u64)length * 4, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  return 0;
+}
+
+int bwtc_hip_test_sort_u32(bwtc_hip_ctx* ctx, uint32_t* keys, uint32_t* vals, uint64_t n, int nbits) {
+  return test_sort<u32>(ctx, keys, vals, n, nbits);
+}
+int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int nbits) {
+  return test_sort<u64>(ctx, keys, vals, n, nbits);
+}
+
+int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n) {
+  if (!ctx || !data) return -1;
+  BwtEngine& e = ctx->eng;
+  // the scan borrows R1 for the data and R2 for the tile partials
+  if (n * 4 > e.cap * 8) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  u32* d = static_cast<u32*>(e.d_R1);
+  BWTC_HIP_TRY(hipMemcpyAsync(d, data, n * 4, hipMemcpyHostToDevice, e.stream));
+  exclusive_scan_u32(d, n, static_cast<u32*>(e.d_R2), e.stream);
+  BWTC_HIP_TRY(hipMemcpyAsync(data, d, n * 4, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

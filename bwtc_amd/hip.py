@@ -1,0 +1,172 @@
+"""ctypes binding of libbwtc_hip.so (include/bwtc_hip.h).
+
+This is the only way Python code in this repository reaches the GPU path.  There is no CPU
+fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbwtc_hip.so")
+
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+
+
+class BwtcHipError(RuntimeError):
+    pass
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("n", _u32), ("rounds", _u32), ("active_sum", _u64), ("sort_pass_items", _u64),
+                ("ms_total", ctypes.c_float), ("ms_sort", ctypes.c_float)]
+
+
+EXPORTS = [
+    "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
+    "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_suffix_array",
+    "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
+]
+
+_lib = None
+
+
+def load():
+    """Load libbwtc_hip.so; raises BwtcHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BwtcHipError(
+            "%s not found: build it with `make -C bwtc_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.bwtc_hip_device_count.restype = ctypes.c_int
+    L.bwtc_hip_version.restype = ctypes.c_char_p
+    L.bwtc_hip_workspace_bytes.restype = _u64
+    L.bwtc_hip_workspace_bytes.argtypes = [_u32]
+    L.bwtc_hip_create.argtypes = [ctypes.c_int, _u32, ctypes.POINTER(_vp)]
+    L.bwtc_hip_destroy.argtypes = [_vp]
+    L.bwtc_hip_destroy.restype = None
+    L.bwtc_hip_stream.restype = _vp
+    L.bwtc_hip_stream.argtypes = [_vp]
+    L.bwtc_hip_get_stats.argtypes = [_vp, ctypes.POINTER(Stats)]
+    L.bwtc_hip_n_lf.restype = _u32
+    L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
+    L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
+    L.bwtc_hip_bwt_block.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
+    L.bwtc_hip_bwt_block_device.argtypes = [_vp, _vp, _vp, _u32, _vp, _u32, _vp]
+    L.bwtc_hip_suffix_array.argtypes = [_vp, _vp, _u32, _vp]
+    L.bwtc_hip_test_sort_u32.argtypes = [_vp, _vp, _vp, _u64, ctypes.c_int]
+    L.bwtc_hip_test_sort_u64.argtypes = [_vp, _vp, _vp, _u64, ctypes.c_int]
+    L.bwtc_hip_test_scan_u32.argtypes = [_vp, _vp, _u64]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise BwtcHipError("%s failed with code %d" % (what, rc))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class Context:
+    """One GPU, one stream, one persistent workspace (bwtc_hip_ctx)."""
+
+    def __init__(self, device=0, max_block_size=1 << 20):
+        self.lib = load()
+        if self.lib.bwtc_hip_device_count() <= 0:
+            raise BwtcHipError("no HIP device visible")
+        h = _vp()
+        _check(self.lib.bwtc_hip_create(device, max_block_size, ctypes.byref(h)), "bwtc_hip_create")
+        self.handle = h
+        self.max_block_size = max_block_size
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bwtc_hip_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def n_lf(self, size, starting_points):
+        return int(self.lib.bwtc_hip_n_lf(size, starting_points))
+
+    def stats(self):
+        s = Stats()
+        _check(self.lib.bwtc_hip_get_stats(self.handle, ctypes.byref(s)), "bwtc_hip_get_stats")
+        return s
+
+    def bwt_block(self, data, starting_points=8):
+        """BWTManager::doTransform(block, freqs): returns (bwt bytes, LFpowers, freqs).
+
+        The buffer handed to the library carries one extra byte after the block, as the
+        reference's PrecompressorBlock does, and that byte is checked to be untouched."""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)
+                                    if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        size = data.size
+        buf = np.empty(size + 1, np.uint8)
+        buf[:size] = data
+        buf[size] = 0xA5
+        n_lf = self.n_lf(size, starting_points)
+        lf = np.zeros(n_lf, np.uint32)
+        freqs = np.zeros(256, np.uint32)
+        _check(self.lib.bwtc_hip_bwt_block(self.handle, _ptr(buf), size, _ptr(lf), n_lf,
+                                           _ptr(freqs)), "bwtc_hip_bwt_block")
+        if buf[size] != 0xA5:
+            raise BwtcHipError("byte after the block was modified")
+        return buf[:size].copy(), lf, freqs
+
+    def bwt_raw(self, T, n_lf=1, freqs=None):
+        """BWTransform::doTransform(begin, length, LF, freqs) on T (sentinel included)."""
+        T = np.array(T, dtype=np.uint8, copy=True)
+        lf = np.zeros(n_lf, np.uint32)
+        fr = np.zeros(256, np.uint32) if freqs is None else freqs
+        _check(self.lib.bwtc_hip_bwt(self.handle, _ptr(T), T.size, _ptr(lf), n_lf, _ptr(fr)),
+               "bwtc_hip_bwt")
+        return T, lf, fr
+
+    def bwt_block_device(self, d_in_ptr, d_out_ptr, size, starting_points=8):
+        n_lf = self.n_lf(size, starting_points)
+        lf = np.zeros(n_lf, np.uint32)
+        freqs = np.zeros(256, np.uint32)
+        _check(self.lib.bwtc_hip_bwt_block_device(self.handle, _vp(d_in_ptr), _vp(d_out_ptr), size,
+                                                  _ptr(lf), n_lf, _ptr(freqs)),
+               "bwtc_hip_bwt_block_device")
+        return lf, freqs
+
+    def suffix_array(self, T):
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        sa = np.zeros(T.size, np.uint32)
+        _check(self.lib.bwtc_hip_suffix_array(self.handle, _ptr(T), T.size, _ptr(sa)),
+               "bwtc_hip_suffix_array")
+        return sa
+
+    def test_sort(self, keys, vals, nbits):
+        keys = np.array(keys, copy=True)
+        vals = np.array(vals, dtype=np.uint32, copy=True)
+        fn = self.lib.bwtc_hip_test_sort_u64 if keys.dtype == np.uint64 else self.lib.bwtc_hip_test_sort_u32
+        _check(fn(self.handle, _ptr(keys), _ptr(vals), keys.size, nbits), "bwtc_hip_test_sort")
+        return keys, vals
+
+    def test_scan(self, data):
+        data = np.array(data, dtype=np.uint32, copy=True)
+        _check(self.lib.bwtc_hip_test_scan_u32(self.handle, _ptr(data), data.size), "bwtc_hip_test_scan")
+        return data

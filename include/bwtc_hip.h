@@ -1,0 +1,89 @@
+/*
+ * bwtc_hip.h -- C ABI of libbwtc_hip.so, the MI355X (gfx950) back-end for the
+ * BWTManager -> BWTransform hot path of pjmikkol/bwtc and for the data-parallel half of
+ * its 'H' entropy coder.  Plain pointers and sizes only; no exceptions cross this
+ * boundary.  Citations are file:line relative to the reference tree.
+ *
+ * Return convention (mirrors divbwtf, bwtransforms/divsufsort.c:448,513-515):
+ *   0 success, -1 bad arguments, -2 out of (device) memory, -3 HIP runtime error.
+ *
+ * A context owns one device, one stream and a persistent HBM workspace sized for
+ * max_block_size, the way the reference back-ends own their per-call workspace
+ * (bwtransforms/divsufsort.c:491-493) -- but allocated once, not per block.
+ * A context is not thread-safe; use one per worker (= one per GPU in the block farm).
+ */
+#ifndef BWTC_HIP_H
+#define BWTC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bwtc_hip_ctx bwtc_hip_ctx;
+
+/* Statistics of the last transform on a context (all device work, HIP events on the
+ * context's stream). */
+typedef struct bwtc_hip_stats {
+  uint32_t n;                 /* suffixes sorted = block size + 1                          */
+  uint32_t rounds;            /* prefix-doubling rounds after the initial 4-byte sort      */
+  uint64_t active_sum;        /* sum over rounds of suffixes still in non-singleton groups */
+  uint64_t sort_pass_items;   /* sum over all radix passes of items moved                  */
+  float    ms_total;          /* whole transform, device time                              */
+  float    ms_sort;           /* radix sort passes only                                    */
+} bwtc_hip_stats;
+
+int  bwtc_hip_device_count(void);
+const char* bwtc_hip_version(void);
+
+/* Workspace bytes a context for blocks up to max_block_size bytes will allocate. */
+uint64_t bwtc_hip_workspace_bytes(uint32_t max_block_size);
+
+/* Create / destroy.  *ctx_out is NULL on failure. */
+int  bwtc_hip_create(int device, uint32_t max_block_size, bwtc_hip_ctx** ctx_out);
+void bwtc_hip_destroy(bwtc_hip_ctx* ctx);
+void* bwtc_hip_stream(bwtc_hip_ctx* ctx);          /* hipStream_t of the context */
+int  bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out);
+
+/* LF powers a block of `size` bytes gets for `starting_points`
+ * (BWTManager::setStartingPoints clamp, bwtransforms/BWTManager.cpp:60-64, then
+ * BWTBlock::prepareLFpowers, BWTBlock.cpp:104-108). */
+uint32_t bwtc_hip_n_lf(uint32_t size, uint32_t starting_points);
+
+/* Raw transform.  Replaces BWTransform::doTransform(byte* begin, uint32 length,
+ * std::vector<uint32>& LF, uint32 freqs[256]) (bwtransforms/BWTransform.hpp:53-58) as
+ * implemented by Divsufsorter (bwtransforms/Divsufsorter.hpp:60-65) and SAISBWTransform
+ * (bwtransforms/SA-IS-bwt.cpp:48-54): T[0..length-1] (host memory, caller already planted
+ * the 0 sentinel at T[length-1]) is transformed in place; every position except LF[0] is
+ * written; lf[0..n_lf-1] receives the LF powers; freqs (may be NULL) is INCREMENTED. */
+int bwtc_hip_bwt(bwtc_hip_ctx* ctx, uint8_t* T, uint32_t length, uint32_t* lf, uint32_t n_lf,
+                 uint32_t* freqs);
+
+/* Block-level transform.  Replaces BWTransform::doTransform(BWTBlock&, uint32 freqs[256])
+ * (bwtransforms/BWTransform.cpp:52-64): block[0..size-1] (host) is reversed, terminated,
+ * transformed and the end-of-block hole filled, all on the device; block[size] is never
+ * touched (the reference borrows and restores it).  n_lf as from bwtc_hip_n_lf(). */
+int bwtc_hip_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size, uint32_t* lf,
+                       uint32_t n_lf, uint32_t* freqs);
+
+/* Same, device-resident: d_in/d_out are device pointers to `size` bytes (may alias);
+ * lf (n_lf words) and freqs (256 words, incremented; may be NULL) are HOST pointers.
+ * Work is issued on the context's stream and has completed on return. */
+int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d_out,
+                              uint32_t size, uint32_t* lf, uint32_t n_lf, uint32_t* freqs);
+
+/* Suffix array of T[0..length-1] under "proper prefix sorts first"
+ * (test/SaisTest.cpp:45-53); sa is a host buffer of `length` words.  Test hook for the
+ * property the reference checks in test/SaisTest.cpp:55-70. */
+int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, uint32_t* sa);
+
+/* Unit-test hooks for the sort/scan primitives (host buffers, in place). */
+int bwtc_hip_test_sort_u32(bwtc_hip_ctx* ctx, uint32_t* keys, uint32_t* vals, uint64_t n, int nbits);
+int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int nbits);
+int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

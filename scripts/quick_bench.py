@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Ad-hoc timing of the block transform through the host-pointer ABI (device time from the
+context's HIP events).  Usage: quick_bench.py [size_MiB ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bwtc_amd import hip, synth  # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:]] or [16, 64]
+ctx = hip.Context(0, (max(sizes) << 20) + 64)
+for kind, gen, seed in [("text", synth.gen_text, 3), ("dna", synth.gen_dna, 2), ("random", synth.gen_random_bytes, 1)]:
+    for mib in sizes:
+        d = gen(mib << 20, seed)
+        best = None
+        for rep in range(3):
+            t0 = time.time()
+            bwt, lf, fr = ctx.bwt_block(d, 8)
+            wall = time.time() - t0
+            st = ctx.stats()
+            if best is None or st.ms_total < best[0]:
+                best = (st.ms_total, st.ms_sort, st.rounds, st.active_sum / st.n, wall, st.sort_pass_items / st.n)
+        print("%-6s %4d MiB: device %8.2f ms (sort %8.2f) rounds %2d R_eff %.2f passes/N %.1f  -> %8.1f MB/s (wall %.2fs)"
+              % (kind, mib, best[0], best[1], best[2], best[3], best[5], (mib << 20) / 1e6 / (best[0] / 1e3), best[4]), flush=True)

@@ -1,0 +1,156 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
+(bwtc_amd/hip.py -> libbwtc_hip.so); the oracle and the golden fixtures are the checkers."""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bwtc_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+# ---- primitives --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100000, (1 << 20) + 3])
+def test_scan(hip_ctx, n):
+    rng = np.random.default_rng(n)
+    d = rng.integers(0, 1000, n).astype(np.uint32)
+    got = hip_ctx.test_scan(d)
+    want = np.concatenate([[0], np.cumsum(d[:-1], dtype=np.uint64)]).astype(np.uint32)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 8191, 8192, 8193, 300001])
+@pytest.mark.parametrize("mode", ["random", "few", "equal"])
+def test_sort_u32(hip_ctx, n, mode):
+    rng = np.random.default_rng(n)
+    if mode == "random":
+        k = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    elif mode == "few":
+        k = (rng.integers(0, 3, n).astype(np.uint32) * np.uint32(0x01010101))
+    else:
+        k = np.full(n, 0xDEADBEEF, np.uint32)
+    v = np.arange(n, dtype=np.uint32)
+    gk, gv = hip_ctx.test_sort(k, v, 32)
+    order = np.argsort(k, kind="stable")
+    assert (gk == k[order]).all()
+    assert (gv == v[order]).all()          # stability
+
+
+@pytest.mark.parametrize("n,nbits", [(1, 64), (5, 64), (4096, 64), (4097, 40), (250001, 57), (250001, 13)])
+def test_sort_u64(hip_ctx, n, nbits):
+    rng = np.random.default_rng(n + nbits)
+    k = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    if nbits < 64:
+        k &= np.uint64((1 << nbits) - 1)
+    k[::7] = k[0]
+    v = np.arange(n, dtype=np.uint32)
+    gk, gv = hip_ctx.test_sort(k, v, nbits)
+    order = np.argsort(k, kind="stable")
+    assert (gk == k[order]).all()
+    assert (gv == v[order]).all()
+
+
+# ---- suffix array (the property test/SaisTest.cpp:55-70 checks) ----------------------------
+
+def test_suffix_array_small(hip_ctx, oracle):
+    rng = np.random.default_rng(5)
+    for it in range(40):
+        n = int(rng.integers(1, 3000))
+        sigma = int(rng.choice([1, 2, 4, 256]))
+        t = np.concatenate([rng.integers(0, sigma, n).astype(np.uint8), [0]]).astype(np.uint8)
+        sa = hip_ctx.suffix_array(t)
+        assert sa[0] == n
+        assert (sa == oracle.oracle_suffix_array(t)).all(), (it, n, sigma)
+
+
+# ---- block transform against the reference-generated goldens ------------------------------
+
+def test_bwt_block_small_goldens(hip_ctx):
+    for c in _load("bwt_small.json")["cases"]:
+        data = np.frombuffer(base64.b64decode(c["input"]), np.uint8)
+        bwt, lf, freqs = hip_ctx.bwt_block(data, c["sp"])
+        assert bwt.tobytes() == base64.b64decode(c["bwt"]), c["name"]
+        assert [int(x) for x in lf] == c["lf"], c["name"]
+        want = np.zeros(256, np.uint32)
+        for k, v in c["freqs_nonzero"].items():
+            want[int(k)] = v
+        assert (freqs == want).all(), c["name"]
+
+
+def test_bwt_block_large_goldens(hip_ctx):
+    for c in _load("bwt_large.json")["cases"]:
+        d = getattr(synth, c["gen"])(c["size"], c["seed"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == c["input_sha256"]
+        bwt, lf, freqs = hip_ctx.bwt_block(d, c["sp"])
+        assert hashlib.sha256(bwt.tobytes()).hexdigest() == c["bwt_sha256"], c["name"]
+        assert [int(x) for x in lf] == c["lf"], c["name"]
+        assert (freqs == np.bincount(d, minlength=256)).all()
+
+
+def test_bwt_block_random_vs_oracle(hip_ctx, oracle):
+    # test/InverseBwtTest.cpp:51-114 and test/LFpowersTest.cpp:49-181 in spirit: random
+    # blocks, every alphabet size incl. 0 bytes, random starting points; plus the inverse.
+    rng = np.random.default_rng(99)
+    for it in range(120):
+        n = int(rng.integers(1, 20000))
+        sigma = int(rng.choice([1, 2, 3, 26, 256]))
+        d = rng.integers(0, sigma, n).astype(np.uint8)
+        if it % 4 == 0:
+            d = np.tile(d[:max(1, n // 11)], 12)[:n]
+        sp = int(rng.integers(1, 301))
+        a = hip_ctx.bwt_block(d, sp)
+        b = oracle.oracle_bwt_block(d, sp)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (it, n, sigma, sp)
+        rc, inv = oracle.oracle_inverse_bwt_block(a[0], a[1])
+        assert rc == 0 and (inv == d).all()
+
+
+def test_bwt_raw_leaves_pidx_slot_untouched(hip_ctx, oracle):
+    # raw virtual: BWTransform::doTransform(begin, length, LF, freqs), divsufsort.c:506-512
+    rng = np.random.default_rng(17)
+    for n in [2, 3, 10, 1000, 70000]:
+        t = np.concatenate([rng.integers(0, 5, n - 1).astype(np.uint8), [0]]).astype(np.uint8)
+        n_lf = 5 if n > 300 else 1
+        got, lf, fr = hip_ctx.bwt_raw(t, n_lf)
+        want = t.copy()
+        wlf = np.zeros(n_lf, np.uint32)
+        wfr = np.zeros(256, np.uint32)
+        oracle.lib().orc_bwt_raw(oracle._ptr(want), n, oracle._ptr(wlf), n_lf, oracle._ptr(wfr))
+        assert (got == want).all() and (lf == wlf).all() and (fr == wfr).all()
+        assert got[lf[0]] == t[lf[0]]
+
+
+def test_degenerate_blocks(hip_ctx, oracle):
+    for d in [np.zeros(1, np.uint8), np.zeros(70000, np.uint8), np.full(50000, 255, np.uint8),
+              np.tile(np.array([1, 0], np.uint8), 40000),
+              np.tile(np.frombuffer(b"abcabcabd", np.uint8), 9000)]:
+        a = hip_ctx.bwt_block(d, 8)
+        b = oracle.oracle_bwt_block(d, 8)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+
+
+def test_full_size_text_roundtrip(hip_ctx, oracle):
+    # 64 MiB text block: too big for the oracle's sorter, so check the size-independent
+    # properties: the inverse transform reproduces the input (and every LF power lies on the
+    # LF walk), and freqs is the byte histogram.
+    size = 64 << 20
+    d = synth.gen_text(size, 3)
+    bwt, lf, freqs = hip_ctx.bwt_block(d, 8)
+    assert (freqs == np.bincount(d, minlength=256)).all()
+    rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
+    assert rc == 0
+    assert hashlib.sha256(inv.tobytes()).digest() == hashlib.sha256(d.tobytes()).digest()
+    st = hip_ctx.stats()
+    print("64MiB text: %.1f ms total, %.1f ms sort, rounds %d, R_eff %.2f" %
+          (st.ms_total, st.ms_sort, st.rounds, st.active_sum / st.n))
