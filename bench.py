@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MB/s compressed (BWT + encode) on a 256 MiB block, one block per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (BWTManager::doTransform + the entropy front-end that is
+built, see config.stages) over one synthetic block that is already resident in HBM.  Blocks
+are independent (PrecompressorBlock::sliceIntoBlocks), so rank r works on its own block
+(C4: generator seed 30 + r) and no data-path collective exists; torch.distributed is used
+only for the barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(size_mib_sample, seed, coder):
+    """Times the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
+    BWT = the reference's own divbwtf when oracle/_ref was built ("reference"), else the
+    oracle's restatement ("port"); the entropy stage is the oracle's port either way."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from bwtc_amd import synth
+    d = synth.gen_text(size_mib_sample << 20, seed)
+    use_ref = oracle_lib.ref() is not None
+    t0 = time.perf_counter()
+    bwt, lf, fr = (oracle_lib.ref_bwt_block if use_ref else oracle_lib.oracle_bwt_block)(d, 8)
+    t_bwt = time.perf_counter() - t0
+    t_enc = 0.0
+    if coder == "H":
+        t1 = time.perf_counter()
+        oracle_lib.oracle_huffman_encode_block(bwt, lf, fr)
+        t_enc = time.perf_counter() - t1
+    mb = d.size / 1e6
+    return {
+        "value": round(mb / (t_bwt + t_enc), 3), "unit": "MB/s", "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "bwt_only_MBps": round(mb / t_bwt, 3),
+        "sample": "%d MiB of the same text generator (seed %d), 8 starting points: BWT by %s, "
+                  "1 thread%s" % (size_mib_sample, seed,
+                                  "the reference's divbwtf (oracle/_ref)" if use_ref
+                                  else "oracle/bwtc_oracle.c",
+                                  "; 'H' encode by the oracle port" if coder == "H" else ""),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-mib", type=int, default=256)
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from bwtc_amd import hip, synth
+    size = args.size_mib << 20
+    seed = 3 if world == 1 else 30 + rank          # C3 at N=1, C4 blocks otherwise
+    host = synth.gen_text(size, seed)
+    d_in = torch.from_numpy(host).to(dev)
+    d_out = torch.empty_like(d_in)
+    ctx = hip.Context(local_rank, size)
+    have_encode = hasattr(ctx, "huffman_encode_device")
+    d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev) if have_encode else None
+    torch.cuda.synchronize()
+
+    def step():
+        lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
+        if have_encode:
+            return ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
+        return 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_kernel_timers()
+    barrier()
+    t0 = time.perf_counter()
+    comp_bytes = 0
+    for _ in range(args.steps):
+        comp_bytes = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kt = ctx.kernel_timers()
+        st = ctx.stats()
+        total_mb = world * args.steps * size / 1e6
+        roof = None
+        if kt["scatter_launches"]:
+            achieved = kt["scatter_bytes"] / (kt["scatter_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_radix_scatter<u64> (+<u32> initial passes)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": kt["scatter_launches"],
+                    "avg_launch_us": round(1e3 * kt["scatter_ms"] / kt["scatter_launches"], 1),
+                    "algorithmic_bytes_per_launch": int(kt["scatter_bytes"] / kt["scatter_launches"])}
+        out = {
+            "metric": "MB/s compressed (BWT+encode) on 256 MiB block",
+            "value": round(total_mb / elapsed, 2), "unit": "MB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
+            "config": {"workload": "C3: %d MiB enwik8-style synthetic text block per GPU "
+                                   "(splitmix64 token generator, seed %s), 8 starting points"
+                                   % (args.size_mib, "3" if world == 1 else "30+rank"),
+                       "stages": "BWT (suffix sort + BWT + LFpowers + freqs)" +
+                                 (" + 'H' run-length/Huffman encode" if have_encode else
+                                  " only; entropy front-end not built yet"),
+                       "blocks_per_gpu": 1, "parallelism": "block farm, no collective"},
+            "device_ms_bwt": round(st.ms_total, 3), "rounds": st.rounds,
+            "R_eff": round(st.active_sum / max(st.n, 1), 3),
+            "compressed_bytes": int(comp_bytes),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_mib, seed, "H" if have_encode else "")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -355,6 +355,7 @@ void BwtEngine::release() {
   if (ev_begin) (void)hipEventDestroy(ev_begin);
   if (ev_end) (void)hipEventDestroy(ev_end);
   for (int i = 0; i < kMaxSortEvents; ++i) if (ev_sort[i]) (void)hipEventDestroy(ev_sort[i]);
+  probe.destroy();
   if (stream) (void)hipStreamDestroy(stream);
   arena = nullptr; h_small = nullptr; h_stage = nullptr; stream = nullptr;
 }
@@ -375,7 +376,7 @@ int BwtEngine::suffix_sort(u32 n) {
 
   u32 *ks = nullptr, *vs = nullptr;
   BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-  radix_sort_pairs<u32>(K32a, K32b, d_V0, d_V1, n, 32, d_table, d_partial, st, &ks, &vs);
+  radix_sort_pairs<u32>(K32a, K32b, d_V0, d_V1, n, 32, d_table, d_partial, st, &ks, &vs, &probe);
   BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
   stats.sort_pass_items += (u64)n * 4;
 
@@ -416,7 +417,7 @@ int BwtEngine::suffix_sort(u32 n) {
     const bool timed = n_sort_events + 2 <= kMaxSortEvents;
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     radix_sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, d_table, d_partial, st, &k64s,
-                          &v64s);
+                          &v64s, &probe);
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     stats.sort_pass_items += (u64)m * (u64)((nbits + kRadixBits - 1) / kRadixBits);
     u32* next_aidx = (v64s == aidx) ? aidx_other : aidx;
@@ -469,6 +470,7 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   BWTC_HIP_TRY(hipGetLastError());
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
   if (freqs) for (int c = 0; c < 256; ++c) freqs[c] += h_small[kSmallFreqs + c];
+  probe.harvest();
   stats.n = n;
   (void)hipEventElapsedTime(&stats.ms_total, ev_begin, ev_end);
   stats.ms_sort = 0.f;

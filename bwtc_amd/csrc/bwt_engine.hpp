@@ -17,6 +17,7 @@
 #pragma once
 #include "common.hpp"
 #include "bwtc_hip.h"
+#include "radix_sort.hpp"
 
 namespace bwtc_hip {
 
@@ -56,6 +57,7 @@ struct BwtEngine {
   int n_sort_events = 0;
 
   bwtc_hip_stats stats;
+  ScatterProbe probe;
 
   static u64 workspace_bytes(u32 max_block);
   int init(int dev, u32 max_block_size);

@@ -71,6 +71,20 @@ int bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out) {
   return 0;
 }
 
+int bwtc_hip_set_profiling(bwtc_hip_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->eng.probe.enabled = on != 0;
+  return 0;
+}
+
+int bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, int reset) {
+  if (!ctx) return -1;
+  ScatterProbe& p = ctx->eng.probe;
+  if (out) { out->scatter_launches = p.total_launches; out->scatter_bytes = p.total_bytes; out->scatter_ms = p.total_ms; }
+  if (reset) { p.total_launches = 0; p.total_bytes = 0; p.total_ms = 0.0; }
+  return 0;
+}
+
 uint32_t bwtc_hip_n_lf(uint32_t size, uint32_t starting_points) {
   if (starting_points < 1) starting_points = 1;          // BWTManager.cpp:60-64
   else if (starting_points > 256) starting_points = 256;

@@ -157,12 +157,42 @@ static inline u64 radix_partial_words(u64 max_n) {
   return (radix_table_words(max_n) + kScanTile - 1) / kScanTile + 1;
 }
 
+// Optional HIP-event probe around every scatter launch (bench.py's roofline figure).
+struct ScatterProbe {
+  static constexpr int kMax = 1024;
+  bool enabled = false;
+  hipEvent_t ev[2 * kMax];
+  u64 bytes[kMax];
+  int used = 0;
+  bool created = false;
+  u64 total_launches = 0, total_bytes = 0;
+  double total_ms = 0.0;
+  bool begin(hipStream_t st) {
+    if (!enabled || used >= kMax) return false;
+    if (!created) { for (int i = 0; i < 2 * kMax; ++i) (void)hipEventCreate(&ev[i]); created = true; }
+    (void)hipEventRecord(ev[2 * used], st);
+    return true;
+  }
+  void end(hipStream_t st, u64 nbytes) { (void)hipEventRecord(ev[2 * used + 1], st); bytes[used++] = nbytes; }
+  // call after the stream has been synchronised
+  void harvest() {
+    for (int i = 0; i < used; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) {
+        total_ms += ms; total_bytes += bytes[i]; ++total_launches;
+      }
+    }
+    used = 0;
+  }
+  void destroy() { if (created) for (int i = 0; i < 2 * kMax; ++i) (void)hipEventDestroy(ev[i]); created = false; }
+};
+
 // Sorts n pairs by key bits [0, nbits).  Buffers ping-pong; on return *k_sorted/*v_sorted
 // point at whichever of (k0,v0)/(k1,v1) holds the result.
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
-                                    K** k_sorted, u32** v_sorted) {
+                                    K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1) {
@@ -171,8 +201,10 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n,
                          shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
+      const bool timed = probe && probe->begin(st);
       hipLaunchKernelGGL(k_radix_scatter<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, kin, vin,
                          kout, vout, table, n, shift, ntiles);
+      if (timed) probe->end(st, n * 2 * (sizeof(K) + sizeof(u32)));
       K* tk = kin; kin = kout; kout = tk;
       u32* tv = vin; vin = vout; vout = tv;
     }

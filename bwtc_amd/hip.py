@@ -25,9 +25,14 @@ class Stats(ctypes.Structure):
                 ("ms_total", ctypes.c_float), ("ms_sort", ctypes.c_float)]
 
 
+class KernelTimers(ctypes.Structure):
+    _fields_ = [("scatter_launches", _u64), ("scatter_bytes", _u64), ("scatter_ms", ctypes.c_double)]
+
+
 EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
-    "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
+    "bwtc_hip_get_kernel_timers", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -55,6 +60,8 @@ def load():
     L.bwtc_hip_stream.restype = _vp
     L.bwtc_hip_stream.argtypes = [_vp]
     L.bwtc_hip_get_stats.argtypes = [_vp, ctypes.POINTER(Stats)]
+    L.bwtc_hip_set_profiling.argtypes = [_vp, ctypes.c_int]
+    L.bwtc_hip_get_kernel_timers.argtypes = [_vp, ctypes.POINTER(KernelTimers), ctypes.c_int]
     L.bwtc_hip_n_lf.restype = _u32
     L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
     L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
@@ -113,6 +120,18 @@ class Context:
         s = Stats()
         _check(self.lib.bwtc_hip_get_stats(self.handle, ctypes.byref(s)), "bwtc_hip_get_stats")
         return s
+
+    def reset_kernel_timers(self):
+        """Turns per-kernel event timing on and clears the accumulators."""
+        _check(self.lib.bwtc_hip_set_profiling(self.handle, 1), "bwtc_hip_set_profiling")
+        _check(self.lib.bwtc_hip_get_kernel_timers(self.handle, None, 1), "bwtc_hip_get_kernel_timers")
+
+    def kernel_timers(self):
+        k = KernelTimers()
+        _check(self.lib.bwtc_hip_get_kernel_timers(self.handle, ctypes.byref(k), 0),
+               "bwtc_hip_get_kernel_timers")
+        return {"scatter_launches": int(k.scatter_launches), "scatter_bytes": int(k.scatter_bytes),
+                "scatter_ms": float(k.scatter_ms)}
 
     def bwt_block(self, data, starting_points=8):
         """BWTManager::doTransform(block, freqs): returns (bwt bytes, LFpowers, freqs).

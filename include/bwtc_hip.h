@@ -34,6 +34,15 @@ typedef struct bwtc_hip_stats {
   float    ms_sort;           /* radix sort passes only                                    */
 } bwtc_hip_stats;
 
+/* Per-kernel device timing of the dominant kernel (the radix scatter pass), gathered with
+ * HIP events on the context's stream while profiling is on.  bytes = ALGORITHMIC bytes:
+ * items * (key + value) read once and written once. */
+typedef struct bwtc_hip_kernel_timers {
+  uint64_t scatter_launches;
+  uint64_t scatter_bytes;
+  double   scatter_ms;
+} bwtc_hip_kernel_timers;
+
 int  bwtc_hip_device_count(void);
 const char* bwtc_hip_version(void);
 
@@ -45,6 +54,8 @@ int  bwtc_hip_create(int device, uint32_t max_block_size, bwtc_hip_ctx** ctx_out
 void bwtc_hip_destroy(bwtc_hip_ctx* ctx);
 void* bwtc_hip_stream(bwtc_hip_ctx* ctx);          /* hipStream_t of the context */
 int  bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out);
+int  bwtc_hip_set_profiling(bwtc_hip_ctx* ctx, int on);
+int  bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, int reset);
 
 /* LF powers a block of `size` bytes gets for `starting_points`
  * (BWTManager::setStartingPoints clamp, bwtransforms/BWTManager.cpp:60-64, then
