@@ -278,7 +278,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, total;
+      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -304,6 +304,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_aggB = take(rr_tiles * 4);
   a.off_aggC = take(rr_tiles * 4);
   a.off_small = take(1024 * 4);
+  a.off_ent = take(2u << 20);
+  a.off_comp = take(huffman_compress_bound(cap));
   a.total = o;
   return a;
 }
@@ -339,6 +341,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_aggB = reinterpret_cast<u32*>(base + a.off_aggB);
   d_aggC = reinterpret_cast<u32*>(base + a.off_aggC);
   d_small = reinterpret_cast<u32*>(base + a.off_small);
+  d_ent = base + a.off_ent;
+  d_comp = base + a.off_comp;
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
   BWTC_HIP_TRY(hipEventCreate(&ev_begin));

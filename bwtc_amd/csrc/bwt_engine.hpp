@@ -47,6 +47,8 @@ struct BwtEngine {
   u32* d_aggA = nullptr;   // rerank tile aggregates
   u32* d_aggB = nullptr;
   u32* d_aggC = nullptr;
+  u8* d_comp = nullptr;    // compressed-block staging, huffman_compress_bound(max_block)
+  u8* d_ent = nullptr;     // 2 MiB of small tables for the entropy front-end
   u32* d_small = nullptr;  // [0..255] freqs, [256..511] lf, [512] pidx, [520..521] counts
   u32* h_small = nullptr;  // pinned mirror of d_small
   u8* h_stage = nullptr;   // pinned staging, cap + 32
@@ -71,5 +73,11 @@ struct BwtEngine {
   // T (size = length), position pidx keeps its input byte.
   int transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf, u32 n_lf, u32* freqs);
 };
+
+u64 huffman_compress_bound(u64 size);
+// 'H' coder over an already transformed block that is resident on the device: writes the
+// complete BWT-block record (48-bit length, BWTBlock header, sections, payloads) to d_out.
+int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                          const u32* freqs, u8* d_out, u64 out_cap, u64* out_bytes);
 
 }  // namespace bwtc_hip

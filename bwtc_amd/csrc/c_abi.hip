@@ -2,8 +2,10 @@
 #include "bwt_engine.hpp"
 #include "radix_sort.hpp"
 #include "bwtc_hip.h"
+#include "entropy_host.hpp"
 #include <cstring>
 #include <new>
+#include <vector>
 
 using namespace bwtc_hip;
 
@@ -139,6 +141,92 @@ int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d
   BwtEngine& e = ctx->eng;
   if (size > e.max_block) return -1;
   return e.transform(d_in, d_out, size, false, lf, n_lf, freqs);
+}
+
+uint64_t bwtc_hip_compress_bound(uint32_t size) { return huffman_compress_bound(size); }
+
+int bwtc_hip_huffman_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                   const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                   uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes) {
+  if (!ctx || (!d_bwt && size) || !d_out || !lf || !freqs || !out_bytes) return -1;
+  if (size > ctx->eng.max_block) return -1;
+  return huffman_encode_device(ctx->eng, d_bwt, size, lf, n_lf, freqs, d_out, out_cap, out_bytes);
+}
+
+int bwtc_hip_huffman_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                            const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                            uint8_t* out, uint64_t out_cap, uint64_t* out_bytes) {
+  if (!ctx || (!bwt && size) || !out || !lf || !freqs || !out_bytes) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, bwt, size);
+  if (rc) return rc;
+  u64 n = 0;
+  rc = huffman_encode_device(e, e.d_in, size, lf, n_lf, freqs, e.d_comp,
+                             huffman_compress_bound(e.cap), &n);
+  if (rc) return rc;
+  if (n > out_cap) return -1;
+  BWTC_HIP_TRY(hipMemcpyAsync(out, e.d_comp, n, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  *out_bytes = n;
+  return 0;
+}
+
+int bwtc_hip_transform_and_encode(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                                  uint32_t starting_points, uint8_t* out, uint64_t out_cap,
+                                  uint64_t* out_bytes) {
+  if (!ctx || (!block && size) || !out || !out_bytes) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  uint32_t lf[256];
+  uint32_t freqs[256];
+  std::memset(freqs, 0, sizeof freqs);                    // HuffmanCoders.cpp:53
+  const uint32_t n_lf = bwtc_hip_n_lf(size, starting_points);
+  int rc = stage_in(e, block, size);
+  if (rc) return rc;
+  rc = e.transform(e.d_in, e.d_in, size, false, lf, n_lf, freqs);
+  if (rc) return rc;
+  u64 n = 0;
+  rc = huffman_encode_device(e, e.d_in, size, lf, n_lf, freqs, e.d_comp,
+                             huffman_compress_bound(e.cap), &n);
+  if (rc) return rc;
+  if (n > out_cap) return -1;
+  BWTC_HIP_TRY(hipMemcpyAsync(out, e.d_comp, n, hipMemcpyDeviceToHost, e.stream));
+  rc = stage_out(e, block, size);
+  if (rc) return rc;
+  *out_bytes = n;
+  return 0;
+}
+
+void bwtc_hip_host_huffman_lengths(const uint64_t* freqs, uint8_t* clen) {
+  bwtc::utils::calculateHuffmanLengths(freqs, clen);
+}
+void bwtc_hip_host_huffman_codes(const uint8_t* clen, uint32_t* code) {
+  bwtc::utils::computeHuffmanCodes(clen, code);
+}
+uint32_t bwtc_hip_host_serialize_shape(const uint8_t* clen, uint8_t* out, uint32_t cap) {
+  bool any = false;
+  for (int c = 0; c < 256; ++c) any = any || clen[c];
+  if (!any) return 0;
+  std::vector<uint8_t> v;
+  bwtc::serializeShape(clen, v);
+  if (v.size() > cap) return 0;
+  std::memcpy(out, v.data(), v.size());
+  return (uint32_t)v.size();
+}
+uint32_t bwtc_hip_host_sections(const uint32_t* freqs, uint32_t* section_len) {
+  const std::vector<uint32_t> s = bwtc::deduceSections(freqs);
+  for (size_t i = 0; i < s.size(); ++i) section_len[i] = s[i];
+  return (uint32_t)s.size();
+}
+uint32_t bwtc_hip_host_bwtblock_header(const uint32_t* lf, uint32_t n_lf, uint8_t* out, uint32_t cap) {
+  std::vector<uint8_t> v;
+  bwtc::writeBWTBlockHeader(lf, n_lf, v);
+  if (v.size() > cap) return 0;
+  std::memcpy(out, v.data(), v.size());
+  return (uint32_t)v.size();
 }
 
 int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, uint32_t* sa) {

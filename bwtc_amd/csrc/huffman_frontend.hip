@@ -1,0 +1,453 @@
+// Device half of the 'H' coder (HuffmanEncoder::encodeData, HuffmanCoders.cpp:119-257):
+// everything that is a pass over the transformed block.
+//
+//   runs      run heads of every section (utils::calculateRunFrequenciesAndStoreRuns,
+//             Utils.cpp:150-170; a run never crosses a section start) -> run_start[], run_sym[]
+//   stats     per section: runs per symbol (the Huffman weights) and total gamma bits
+//   pack      for each of the two bit streams of a section (Huffman codes of the run symbols,
+//             HuffmanCoders.cpp:200-226; gamma codes of the run lengths, :229-251): prefix sum
+//             of the code lengths -> absolute bit position -> MSB-first bits OR-ed into the
+//             output
+// The small-table work in between (code lengths, canonical codes, shape, headers) is host
+// code in entropy_host.cpp.
+#include "bwt_engine.hpp"
+#include "entropy_host.hpp"
+#include "scan.hpp"
+#include <cstring>
+#include <vector>
+
+namespace bwtc_hip {
+
+constexpr int kRunTPB = 256;
+constexpr int kRunE = 16;
+constexpr int kRunTile = kRunTPB * kRunE;      // bytes per workgroup
+
+// head bits of the 16 bytes starting at p0 (bit e = byte p0+e starts a run)
+__device__ __forceinline__ u32 run_head_bits(const u8* __restrict__ bwt, u32 size, u32 p0,
+                                             const u32* __restrict__ s_sec, u32 nsec,
+                                             u32* first_sec, u8 (&b)[kRunE], bool aligned) {
+  u32 heads = 0;
+  *first_sec = nsec;
+  if (p0 >= size) return 0;
+  u8 prev = p0 ? bwt[p0 - 1] : 0;
+  if (aligned && p0 + kRunE <= size) {
+    const uint4 v = *reinterpret_cast<const uint4*>(bwt + p0);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < kRunE; ++e) b[e] = (u8)(w[e >> 2] >> (8 * (e & 3)));
+  } else {
+#pragma unroll
+    for (int e = 0; e < kRunE; ++e) b[e] = (p0 + e < size) ? bwt[p0 + e] : 0;
+  }
+#pragma unroll
+  for (int e = 0; e < kRunE; ++e) {
+    const u32 p = p0 + e;
+    if (p < size && (p == 0 || b[e] != prev)) heads |= 1u << e;
+    prev = b[e];
+  }
+  // section starts inside [p0, p0 + 16): binary search for the first one >= p0
+  u32 lo = 0, hi = nsec;
+  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_sec[mid] < p0) lo = mid + 1; else hi = mid; }
+  *first_sec = lo;
+  for (u32 j = lo; j < nsec && s_sec[j] < p0 + kRunE && s_sec[j] < size; ++j)
+    heads |= 1u << (s_sec[j] - p0);
+  return heads;
+}
+
+__global__ __launch_bounds__(kRunTPB) void k_runs_count(const u8* __restrict__ bwt, u32 size,
+                                                        const u32* __restrict__ sec_start,
+                                                        u32 nsec, u32* __restrict__ tile_cnt, int aligned) {
+  __shared__ u32 s_sec[256];
+  __shared__ u32 scr[kRunTPB / kWave + 1];
+  if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
+  __syncthreads();
+  const u32 p0 = blockIdx.x * kRunTile + threadIdx.x * kRunE;
+  u8 b[kRunE];
+  u32 fs;
+  const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &fs, b, aligned != 0);
+  u32 total;
+  block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kRunTPB) void k_runs_emit(const u8* __restrict__ bwt, u32 size,
+                                                       const u32* __restrict__ sec_start,
+                                                       u32 nsec, const u32* __restrict__ tile_off,
+                                                       u32* __restrict__ run_start,
+                                                       u8* __restrict__ run_sym,
+                                                       u32* __restrict__ first_run,
+                                                       u32* __restrict__ n_runs, int aligned) {
+  __shared__ u32 s_sec[256];
+  __shared__ u32 scr[kRunTPB / kWave + 1];
+  if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
+  __syncthreads();
+  const u32 p0 = blockIdx.x * kRunTile + threadIdx.x * kRunE;
+  u8 b[kRunE];
+  u32 sec;
+  const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
+  u32 total;
+  u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < kRunE; ++e) {
+    const u32 p = p0 + e;
+    if (p >= size) break;
+    if ((heads >> e) & 1u) {
+      run_start[r] = p;
+      run_sym[r] = b[e];
+      if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; ++sec; }
+      ++r;
+    }
+    if (p == size - 1) { *n_runs = r; run_start[r] = size; first_run[nsec] = r; }
+  }
+}
+
+// section of run r: last s with first_run[s] <= r
+__device__ __forceinline__ u32 section_of(const u32* s_first, u32 nsec, u32 r) {
+  u32 lo = 0, hi = nsec;           // invariant: first_run[lo] <= r < first_run[hi]
+  while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (s_first[mid] <= r) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__device__ __forceinline__ u32 gamma_bits(u32 len) { return 2u * (31u - (u32)__clz(len)) + 1u; }
+
+constexpr int kStatTPB = 256;
+constexpr int kStatE = 8;
+constexpr int kStatTile = kStatTPB * kStatE;
+
+__global__ __launch_bounds__(kStatTPB) void k_run_stats(const u32* __restrict__ run_start,
+                                                        const u8* __restrict__ run_sym,
+                                                        u32 n_runs, const u32* __restrict__ first_run,
+                                                        u32 nsec, u32* __restrict__ run_freqs,
+                                                        unsigned long long* __restrict__ gbits) {
+  __shared__ u32 s_first[257];
+  __shared__ u32 hist[256];
+  __shared__ u32 s_g0;
+  for (u32 i = threadIdx.x; i <= nsec; i += kStatTPB) s_first[i] = first_run[i];
+  hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_g0 = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * kStatTile;
+  const u32 s0 = section_of(s_first, nsec, base);
+  for (int e = 0; e < kStatE; ++e) {
+    const u32 r = base + e * kStatTPB + threadIdx.x;
+    if (r >= n_runs) break;
+    const u32 len = run_start[r + 1] - run_start[r];
+    const u32 sym = run_sym[r];
+    const u32 g = gamma_bits(len);
+    if (r < s_first[s0 + 1]) {
+      atomicAdd(&hist[sym], 1u);
+      atomicAdd(&s_g0, g);
+    } else {
+      const u32 s = section_of(s_first, nsec, r);
+      atomicAdd(&run_freqs[s * 256u + sym], 1u);
+      atomicAdd(&gbits[s], (unsigned long long)g);
+    }
+  }
+  __syncthreads();
+  const u32 c = hist[threadIdx.x];
+  if (c) atomicAdd(&run_freqs[s0 * 256u + threadIdx.x], c);
+  if (threadIdx.x == 0 && s_g0) atomicAdd(&gbits[s0], (unsigned long long)s_g0);
+}
+
+// ---- bit packing ---------------------------------------------------------------------
+// STREAM 0: Huffman code of the run symbol (clen/code tables per section)
+// STREAM 1: gamma code of the run length (2*floor(log2 len)+1 bits, value = len)
+template <int STREAM>
+__device__ __forceinline__ u32 item_bits(u32 r, u32 s, const u32* __restrict__ run_start,
+                                         const u8* __restrict__ run_sym,
+                                         const u8* __restrict__ clen_tab) {
+  if (STREAM == 0) return clen_tab[s * 256u + run_sym[r]];
+  return gamma_bits(run_start[r + 1] - run_start[r]);
+}
+
+constexpr int kPackTPB = 256;
+constexpr int kPackE = 8;
+constexpr int kPackTile = kPackTPB * kPackE;
+
+template <int STREAM>
+__global__ __launch_bounds__(kPackTPB) void k_pack_count(const u32* __restrict__ run_start,
+                                                         const u8* __restrict__ run_sym,
+                                                         u32 n_runs,
+                                                         const u32* __restrict__ first_run,
+                                                         u32 nsec, const u8* __restrict__ clen_tab,
+                                                         u32* __restrict__ tile_bits) {
+  __shared__ u32 s_first[257];
+  __shared__ u32 scr[kPackTPB / kWave + 1];
+  for (u32 i = threadIdx.x; i <= nsec; i += kPackTPB) s_first[i] = first_run[i];
+  __syncthreads();
+  const u32 r0 = blockIdx.x * kPackTile + threadIdx.x * kPackE;
+  u32 sum = 0;
+  if (r0 < n_runs) {
+    u32 s = section_of(s_first, nsec, r0);
+    for (int e = 0; e < kPackE; ++e) {
+      const u32 r = r0 + e;
+      if (r >= n_runs) break;
+      while (r >= s_first[s + 1]) ++s;
+      sum += item_bits<STREAM>(r, s, run_start, run_sym, clen_tab);
+    }
+  }
+  u32 total;
+  block_scan_excl_add<kPackTPB>(sum, scr, &total);
+  if (threadIdx.x == 0) tile_bits[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive u64 prefix of the per-tile bit counts
+__global__ __launch_bounds__(1024) void k_scan_tiles_u64(const u32* __restrict__ tile_bits,
+                                                         unsigned long long* __restrict__ tile_base,
+                                                         u32 ntiles) {
+  __shared__ unsigned long long s_part[1024];
+  const u32 per = (ntiles + 1023u) / 1024u;
+  const u32 b = threadIdx.x * per;
+  const u32 e = min(b + per, ntiles);
+  unsigned long long s = 0;
+  for (u32 i = b; i < e; ++i) s += tile_bits[i];
+  s_part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+  }
+  __syncthreads();
+  unsigned long long off = s_part[threadIdx.x];
+  for (u32 i = b; i < e; ++i) { tile_base[i] = off; off += tile_bits[i]; }
+}
+
+// per section: adj[s] = base_bit[s] - P[first_run[s]], P = global exclusive bit prefix
+template <int STREAM>
+__global__ __launch_bounds__(256) void k_section_adjust(
+    const u32* __restrict__ run_start, const u8* __restrict__ run_sym,
+    const u32* __restrict__ first_run, u32 nsec, const u8* __restrict__ clen_tab,
+    const unsigned long long* __restrict__ tile_base,
+    const unsigned long long* __restrict__ base_bit, unsigned long long* __restrict__ adj) {
+  const u32 s = threadIdx.x;
+  if (s >= nsec) return;
+  const u32 r0 = first_run[s];
+  const u32 t = r0 / kPackTile;
+  unsigned long long P = tile_base[t];
+  // runs [t*tile, r0) may belong to section s-1 (or earlier): walk sections backwards lazily
+  u32 sec = s;
+  for (u32 r = r0; r-- > t * kPackTile;) {
+    while (r < first_run[sec]) --sec;
+    P += item_bits<STREAM>(r, sec, run_start, run_sym, clen_tab);
+  }
+  adj[s] = base_bit[s] - P;
+}
+
+__device__ __forceinline__ void or_bits(u32* __restrict__ out32, unsigned long long pos,
+                                        unsigned long long value, u32 nbits) {
+  // MSB-first stream: bit `pos` is bit (7 - pos%8) of byte pos/8.  Work on big-endian
+  // 32-bit words and byte-swap each contribution into the little-endian store.
+  while (nbits) {
+    const u32 o = (u32)(pos & 31ull);
+    const u32 take = min(nbits, 32u - o);
+    const u32 chunk = (u32)((value >> (nbits - take)) & ((take == 32u) ? 0xFFFFFFFFull : ((1ull << take) - 1ull)));
+    const u32 be = chunk << (32u - o - take);
+    if (be) atomicOr(&out32[pos >> 5], __builtin_bswap32(be));
+    pos += take;
+    nbits -= take;
+  }
+}
+
+template <int STREAM>
+__global__ __launch_bounds__(kPackTPB) void k_pack_emit(
+    const u32* __restrict__ run_start, const u8* __restrict__ run_sym, u32 n_runs,
+    const u32* __restrict__ first_run, u32 nsec, const u8* __restrict__ clen_tab,
+    const u32* __restrict__ code_tab, const unsigned long long* __restrict__ tile_base,
+    const unsigned long long* __restrict__ adj, u32* __restrict__ out32) {
+  __shared__ u32 s_first[257];
+  __shared__ u32 scr[kPackTPB / kWave + 1];
+  for (u32 i = threadIdx.x; i <= nsec; i += kPackTPB) s_first[i] = first_run[i];
+  __syncthreads();
+  const u32 r0 = blockIdx.x * kPackTile + threadIdx.x * kPackE;
+  u32 nb[kPackE];
+  u32 sum = 0, s_begin = 0;
+  if (r0 < n_runs) {
+    u32 s = section_of(s_first, nsec, r0);
+    s_begin = s;
+#pragma unroll
+    for (int e = 0; e < kPackE; ++e) {
+      const u32 r = r0 + e;
+      nb[e] = 0;
+      if (r < n_runs) {
+        while (r >= s_first[s + 1]) ++s;
+        nb[e] = item_bits<STREAM>(r, s, run_start, run_sym, clen_tab);
+      }
+      sum += nb[e];
+    }
+  }
+  u32 total;
+  const u32 off = block_scan_excl_add<kPackTPB>(sum, scr, &total);
+  if (r0 >= n_runs) return;
+  unsigned long long P = tile_base[blockIdx.x] + off;
+  u32 s = s_begin;
+#pragma unroll
+  for (int e = 0; e < kPackE; ++e) {
+    const u32 r = r0 + e;
+    if (r >= n_runs) break;
+    while (r >= s_first[s + 1]) ++s;
+    unsigned long long value;
+    if (STREAM == 0) value = code_tab[s * 256u + run_sym[r]];
+    else value = run_start[r + 1] - run_start[r];
+    or_bits(out32, adj[s] + P, value, nb[e]);
+    P += nb[e];
+  }
+}
+
+// scatter of the host-built header pieces: piece i = bytes[src_off[i] .. +len[i]) -> out + dst_off[i]
+__global__ __launch_bounds__(256) void k_place_pieces(const u8* __restrict__ bytes,
+                                                      const unsigned long long* __restrict__ desc,
+                                                      u8* __restrict__ out) {
+  const unsigned long long dst = desc[3 * blockIdx.x], src = desc[3 * blockIdx.x + 1],
+                           len = desc[3 * blockIdx.x + 2];
+  for (unsigned long long i = threadIdx.x; i < len; i += 256) out[dst + i] = bytes[src + i];
+}
+
+// ---------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------
+u64 huffman_compress_bound(u64 size) {
+  // worst case per run: 47-bit code + 63-bit gamma is never reached; sections cost < 1 KiB
+  // of headers each.  2x the block + headers is a safe and simple bound.
+  return size * 2 + 256 * 1024 + 4096;
+}
+
+int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                          const u32* freqs, u8* d_out, u64 out_cap, u64* out_bytes) {
+  hipStream_t st = e.stream;
+  if (!freqs || !lf || !out_bytes || n_lf == 0 || n_lf > 256) return -1;
+  if ((u64)size > e.cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  if (reinterpret_cast<uintptr_t>(d_out) & 3u) return -1;
+
+  // ---- host: block header + sections (HuffmanEncoder::writeBlockHeader, :271-313)
+  std::vector<uint8_t> head(6, 0);
+  bwtc::writeBWTBlockHeader(lf, n_lf, head);
+  const std::vector<uint32_t> sections = bwtc::deduceSections(freqs);
+  const u32 nsec = (u32)sections.size();
+  head.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
+  for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(sections[s], head);
+  if (size == 0 || nsec == 0) {
+    const u64 len = head.size() - 6;
+    for (int i = 0; i < 6; ++i) head[i] = (uint8_t)(len >> (8 * (5 - i)));
+    if (head.size() > out_cap) return -1;
+    BWTC_HIP_TRY(hipMemcpyAsync(d_out, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    BWTC_HIP_TRY(hipStreamSynchronize(st));
+    *out_bytes = head.size();
+    return 0;
+  }
+
+  // ---- workspace carving (the BWT arrays are dead once the block has been emitted)
+  u32* d_run_start = static_cast<u32*>(e.d_R1);                 // size + 1 words
+  u8* d_run_sym = static_cast<u8*>(e.d_R2);                     // size bytes
+  u32* d_tile = e.d_V0;                                         // per-tile counters / bases
+  unsigned long long* d_tile_base = reinterpret_cast<unsigned long long*>(e.d_G0);
+  u32* d_sec = reinterpret_cast<u32*>(e.d_ent);                 // small tables (2 MiB region)
+  u32* d_sec_start = d_sec;                                     // 256
+  u32* d_first_run = d_sec + 512;                               // 257
+  u32* d_nruns = d_sec + 1024;                                  // 1
+  u32* d_run_freqs = d_sec + 2048;                              // 256*256
+  unsigned long long* d_gbits = reinterpret_cast<unsigned long long*>(d_sec + 2048 + 65536);  // 256
+  unsigned long long* d_base_bit = d_gbits + 256;               // 256
+  unsigned long long* d_adj = d_base_bit + 256;                 // 256
+  u8* d_clen = reinterpret_cast<u8*>(d_adj + 256);              // 65536
+  u32* d_code = reinterpret_cast<u32*>(d_clen + 65536);         // 65536 words
+  unsigned long long* d_desc = reinterpret_cast<unsigned long long*>(d_code + 65536);  // 3*260
+  u8* d_pieces = reinterpret_cast<u8*>(d_desc + 3 * 260);       // header bytes
+  const u64 pieces_cap = (2u << 20) - (u64)(d_pieces - e.d_ent);
+
+  std::vector<u32> sec_start(nsec);
+  { u64 acc = 0; for (u32 s = 0; s < nsec; ++s) { sec_start[s] = (u32)acc; acc += sections[s]; } }
+  BWTC_HIP_TRY(hipMemcpyAsync(d_sec_start, sec_start.data(), nsec * 4, hipMemcpyHostToDevice, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_run_freqs, 0, (65536 + 512) * 4, st));   // run_freqs + gbits
+
+  // ---- runs
+  const u32 rtiles = ceil_div(size, kRunTile);
+  const int aligned = (reinterpret_cast<uintptr_t>(d_bwt) & 15u) == 0;
+  hipLaunchKernelGGL(k_runs_count, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, aligned);
+  exclusive_scan_u32(d_tile, rtiles, e.d_partial, st);
+  hipLaunchKernelGGL(k_runs_emit, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
+  u32 n_runs = 0;
+  BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  n_runs = e.h_small[0];
+  if (n_runs == 0 || n_runs > size) return -3;
+
+  // ---- stats
+  hipLaunchKernelGGL(k_run_stats, dim3(ceil_div(n_runs, kStatTile)), dim3(kStatTPB), 0, st,
+                     d_run_start, d_run_sym, n_runs, d_first_run, nsec, d_run_freqs, d_gbits);
+  std::vector<u32> h_run_freqs((size_t)nsec * 256);
+  std::vector<unsigned long long> h_gbits(nsec);
+  std::vector<u32> h_first(nsec + 1);
+  BWTC_HIP_TRY(hipMemcpyAsync(h_run_freqs.data(), d_run_freqs, (size_t)nsec * 1024, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_gbits.data(), d_gbits, (size_t)nsec * 8, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- host: per-section tables and layout (encodeData, :133-198)
+  std::vector<uint8_t> clen_tab((size_t)nsec * 256);
+  std::vector<u32> code_tab((size_t)nsec * 256);
+  std::vector<unsigned long long> base_code(nsec), base_gamma(nsec);
+  std::vector<uint8_t> pieces;                  // all header bytes, concatenated
+  std::vector<unsigned long long> desc;         // (dst, src, len) per piece
+  desc.push_back(0); desc.push_back(0); desc.push_back(head.size());
+  pieces.insert(pieces.end(), head.begin(), head.end());
+  u64 pos = head.size();
+  for (u32 s = 0; s < nsec; ++s) {
+    uint64_t f64[256];
+    for (int c = 0; c < 256; ++c) f64[c] = h_run_freqs[(size_t)s * 256 + c];
+    uint8_t* cl = &clen_tab[(size_t)s * 256];
+    bwtc::utils::calculateHuffmanLengths(f64, cl);
+    bwtc::utils::computeHuffmanCodes(cl, &code_tab[(size_t)s * 256]);
+    std::vector<uint8_t> sh;
+    bwtc::utils::packInteger(h_first[s + 1] - h_first[s], sh);      // number of runs
+    bwtc::serializeShape(cl, sh);
+    desc.push_back(pos); desc.push_back(pieces.size()); desc.push_back(sh.size());
+    pieces.insert(pieces.end(), sh.begin(), sh.end());
+    pos += sh.size();
+    u64 code_bits = 0;
+    for (int c = 0; c < 256; ++c) code_bits += f64[c] * cl[c];
+    base_code[s] = pos * 8;
+    pos += (code_bits + 7) / 8;
+    base_gamma[s] = pos * 8;
+    pos += (h_gbits[s] + 7) / 8;
+  }
+  const u64 total = pos;
+  if (total > out_cap || pieces.size() > pieces_cap) return -1;
+  { const u64 len = total - 6; for (int i = 0; i < 6; ++i) pieces[i] = (uint8_t)(len >> (8 * (5 - i))); }
+
+  BWTC_HIP_TRY(hipMemsetAsync(d_out, 0, (total + 3) / 4 * 4 <= out_cap ? (total + 3) / 4 * 4 : total, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(d_clen, clen_tab.data(), clen_tab.size(), hipMemcpyHostToDevice, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(d_code, code_tab.data(), code_tab.size() * 4, hipMemcpyHostToDevice, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(d_pieces, pieces.data(), pieces.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_place_pieces, dim3((u32)(desc.size() / 3)), dim3(256), 0, st, d_pieces, d_desc, d_out);
+
+  // ---- the two bit streams
+  const u32 ptiles = ceil_div(n_runs, kPackTile);
+  u32* out32 = reinterpret_cast<u32*>(d_out);
+  BWTC_HIP_TRY(hipMemcpyAsync(d_base_bit, base_code.data(), nsec * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_pack_count<0>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
+                     n_runs, d_first_run, nsec, d_clen, d_tile);
+  hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, st, d_tile, d_tile_base, ptiles);
+  hipLaunchKernelGGL(k_section_adjust<0>, dim3(1), dim3(256), 0, st, d_run_start, d_run_sym,
+                     d_first_run, nsec, d_clen, d_tile_base, d_base_bit, d_adj);
+  hipLaunchKernelGGL(k_pack_emit<0>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
+                     n_runs, d_first_run, nsec, d_clen, d_code, d_tile_base, d_adj, out32);
+  // gamma stream (stream order keeps d_base_bit/d_adj/d_tile reuse safe)
+  BWTC_HIP_TRY(hipMemcpyAsync(d_base_bit, base_gamma.data(), nsec * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_pack_count<1>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
+                     n_runs, d_first_run, nsec, d_clen, d_tile);
+  hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, st, d_tile, d_tile_base, ptiles);
+  hipLaunchKernelGGL(k_section_adjust<1>, dim3(1), dim3(256), 0, st, d_run_start, d_run_sym,
+                     d_first_run, nsec, d_clen, d_tile_base, d_base_bit, d_adj);
+  hipLaunchKernelGGL(k_pack_emit<1>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
+                     n_runs, d_first_run, nsec, d_clen, d_code, d_tile_base, d_adj, out32);
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(hipGetLastError());
+  *out_bytes = total;
+  return 0;
+}
+
+}  // namespace bwtc_hip

@@ -33,7 +33,10 @@ EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_n_lf", "bwtc_hip_bwt",
-    "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_suffix_array",
+    "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_compress_bound",
+    "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
+    "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
 
@@ -67,6 +70,23 @@ def load():
     L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
     L.bwtc_hip_bwt_block.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
     L.bwtc_hip_bwt_block_device.argtypes = [_vp, _vp, _vp, _u32, _vp, _u32, _vp]
+    L.bwtc_hip_compress_bound.restype = _u64
+    L.bwtc_hip_compress_bound.argtypes = [_u32]
+    L.bwtc_hip_huffman_encode_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u64,
+                                                 ctypes.POINTER(_u64)]
+    L.bwtc_hip_huffman_encode.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u64,
+                                          ctypes.POINTER(_u64)]
+    L.bwtc_hip_transform_and_encode.argtypes = [_vp, _vp, _u32, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_host_huffman_lengths.restype = None
+    L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
+    L.bwtc_hip_host_huffman_codes.restype = None
+    L.bwtc_hip_host_huffman_codes.argtypes = [_vp, _vp]
+    L.bwtc_hip_host_serialize_shape.restype = _u32
+    L.bwtc_hip_host_serialize_shape.argtypes = [_vp, _vp, _u32]
+    L.bwtc_hip_host_sections.restype = _u32
+    L.bwtc_hip_host_sections.argtypes = [_vp, _vp]
+    L.bwtc_hip_host_bwtblock_header.restype = _u32
+    L.bwtc_hip_host_bwtblock_header.argtypes = [_vp, _u32, _vp, _u32]
     L.bwtc_hip_suffix_array.argtypes = [_vp, _vp, _u32, _vp]
     L.bwtc_hip_test_sort_u32.argtypes = [_vp, _vp, _vp, _u64, ctypes.c_int]
     L.bwtc_hip_test_sort_u64.argtypes = [_vp, _vp, _vp, _u64, ctypes.c_int]
@@ -170,6 +190,51 @@ class Context:
                                                   _ptr(lf), n_lf, _ptr(freqs)),
                "bwtc_hip_bwt_block_device")
         return lf, freqs
+
+    def compress_bound(self, size):
+        return int(self.lib.bwtc_hip_compress_bound(size))
+
+    def huffman_encode_device(self, d_bwt_ptr, size, lf, freqs, d_out_ptr, out_cap=None):
+        """HuffmanEncoder: writeBlockHeader + encodeData + finishBlock on a device-resident
+        transformed block; returns the number of bytes written at d_out_ptr."""
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        n = _u64(0)
+        cap = self.compress_bound(size) if out_cap is None else out_cap
+        _check(self.lib.bwtc_hip_huffman_encode_device(self.handle, _vp(d_bwt_ptr), size, _ptr(lf),
+                                                       lf.size, _ptr(freqs), _vp(d_out_ptr), cap,
+                                                       ctypes.byref(n)),
+               "bwtc_hip_huffman_encode_device")
+        return int(n.value)
+
+    def huffman_encode(self, bwt, lf, freqs):
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        cap = self.compress_bound(bwt.size)
+        out = np.zeros(cap, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_huffman_encode(self.handle, _ptr(bwt), bwt.size, _ptr(lf), lf.size,
+                                                _ptr(freqs), _ptr(out), cap, ctypes.byref(n)),
+               "bwtc_hip_huffman_encode")
+        return out[:n.value].copy()
+
+    def transform_and_encode(self, data, starting_points=8):
+        """HuffmanEncoder::transformAndEncode: returns (encoded BWT-block record, bwt bytes)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        buf = np.empty(data.size + 1, np.uint8)
+        buf[:data.size] = data
+        buf[data.size] = 0x5A
+        cap = self.compress_bound(data.size)
+        out = np.zeros(cap, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_transform_and_encode(self.handle, _ptr(buf), data.size,
+                                                      starting_points, _ptr(out), cap,
+                                                      ctypes.byref(n)),
+               "bwtc_hip_transform_and_encode")
+        if buf[data.size] != 0x5A:
+            raise BwtcHipError("byte after the block was modified")
+        return out[:n.value].copy(), buf[:data.size].copy()
 
     def suffix_array(self, T):
         T = np.ascontiguousarray(T, dtype=np.uint8)

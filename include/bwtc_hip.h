@@ -84,6 +84,51 @@ int bwtc_hip_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size, uint32_
 int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d_out,
                               uint32_t size, uint32_t* lf, uint32_t n_lf, uint32_t* freqs);
 
+/* ---- 'H' entropy coder (HuffmanCoders.cpp) ------------------------------------------- */
+
+/* Upper bound of the bytes one encoded BWT block of `size` input bytes can take. */
+uint64_t bwtc_hip_compress_bound(uint32_t size);
+
+/* Encodes an already transformed block.  Replaces the part of
+ * HuffmanEncoder::transformAndEncode (HuffmanCoders.cpp:51-61) after the transform:
+ * writeBlockHeader (:271-313), encodeData (:119-257) and finishBlock (:259-261).  Output =
+ * the complete BWT-block record: 48-bit big-endian length of the rest, BWTBlock header
+ * (BWTBlock.cpp:61-86), section count and packed section lengths, then per section packed
+ * run count, serialised code shape, Huffman-coded run symbols and gamma-coded run lengths.
+ * d_bwt/d_out are device pointers (d_out 4-byte aligned, out_cap bytes); lf/freqs are the
+ * HOST arrays the transform returned (freqs is not modified).  *out_bytes = record size. */
+int bwtc_hip_huffman_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                   const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                   uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes);
+
+/* Same with host buffers (staged through the context's workspace). */
+int bwtc_hip_huffman_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                            const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                            uint8_t* out, uint64_t out_cap, uint64_t* out_bytes);
+
+/* HuffmanEncoder::transformAndEncode(block, bwtm, out) (HuffmanCoders.cpp:51-61) in one
+ * call: block (host, `size` bytes, left transformed like the reference leaves it) ->
+ * encoded BWT-block record in `out` (host).  starting_points as given to
+ * BWTManager::setStartingPoints. */
+int bwtc_hip_transform_and_encode(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                                  uint32_t starting_points, uint8_t* out, uint64_t out_cap,
+                                  uint64_t* out_bytes);
+
+/* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the
+ * small-table steps the encoder runs between its device passes, exported so the host logic
+ * can be checked on its own:
+ *   lengths : utils::calculateHuffmanLengths (Utils.cpp:408-473), freqs[256] -> clen[256]
+ *   codes   : utils::computeHuffmanCodes (Utils.cpp:180-202)
+ *   shape   : HuffmanEncoder::serializeShape, byte padded (HuffmanCoders.cpp:63-86,181-192);
+ *             returns bytes written (<= cap) or 0
+ *   sections: section heuristic of writeBlockHeader (HuffmanCoders.cpp:282-296); returns count
+ *   header  : BWTBlock::writeHeader (BWTBlock.cpp:61-86); returns bytes written */
+void     bwtc_hip_host_huffman_lengths(const uint64_t* freqs, uint8_t* clen);
+void     bwtc_hip_host_huffman_codes(const uint8_t* clen, uint32_t* code);
+uint32_t bwtc_hip_host_serialize_shape(const uint8_t* clen, uint8_t* out, uint32_t cap);
+uint32_t bwtc_hip_host_sections(const uint32_t* freqs, uint32_t* section_len);
+uint32_t bwtc_hip_host_bwtblock_header(const uint32_t* lf, uint32_t n_lf, uint8_t* out, uint32_t cap);
+
 /* Suffix array of T[0..length-1] under "proper prefix sorts first"
  * (test/SaisTest.cpp:45-53); sa is a host buffer of `length` words.  Test hook for the
  * property the reference checks in test/SaisTest.cpp:55-70. */
