@@ -1,59 +1,100 @@
 // BwtEngine implementation: kernels + host orchestration.  See bwt_engine.hpp.
 #include "bwt_engine.hpp"
 #include "radix_sort.hpp"
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace bwtc_hip {
 
 // ---------------------------------------------------------------------------------------
-// K1  load (+reverse) + 256-bin histogram.  T[j] = src[size-1-j] (reverse) or src[j], for
-//     j < size; T[size..] = 0 up to the padded end.  The histogram is over the `size`
-//     source bytes (BWTransform.cpp:53-55 + divsufsort.c:506-512: the sentinel is never
-//     counted).  4 bytes per thread, one dword store; LDS histogram, one global atomic per
-//     non-empty bin per workgroup.
+// K1  load (+reverse) + 256-bin histogram.  T[j] = src[ncopy-1-j] (reverse) or src[j] for
+//     j < ncopy; T[ncopy..padded) = 0.  The histogram is over the ncopy source bytes
+//     (BWTransform.cpp:53-55 + divsufsort.c:506-512: the sentinel is never counted).
+//     One workgroup = 4096 destination bytes: the source window is staged in LDS with
+//     16-byte loads, every thread assembles one aligned 16-byte store.  Histogram in LDS,
+//     16 interleaved copies per bin (copy = lane & 15) so that skewed inputs (text, DNA,
+//     all-equal blocks) do not serialise on one address; one global atomic per non-empty
+//     bin per workgroup.
 // ---------------------------------------------------------------------------------------
 constexpr int kLoadTPB = 256;
+constexpr int kLoadTile = kLoadTPB * 16;
+constexpr u32 kTextPad = 64;   // zero bytes guaranteed after T[n-1]
 
 __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ src,
-                                                        u8* __restrict__ T, u32 size,
-                                                        u32 padded_words, int reverse,
+                                                        u8* __restrict__ T, u32 ncopy,
+                                                        u32 padded, int reverse, int aligned,
                                                         u32* __restrict__ freqs) {
-  __shared__ u32 hist[256];
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  const u32 w = blockIdx.x * kLoadTPB + threadIdx.x;
-  if (w < padded_words) {
-    const u32 j0 = w * 4u;
-    u32 word = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const u32 j = j0 + b;
-      if (j < size) {
-        const u32 c = src[reverse ? (size - 1u - j) : j];
-        word |= c << (8 * b);
-        atomicAdd(&hist[c], 1u);
+  __shared__ __attribute__((aligned(16))) u8 s_src[kLoadTile + 32];
+  __shared__ u32 s_hist[256 * 16];
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < 256 * 16; i += kLoadTPB) s_hist[i] = 0;
+  const u32 d0 = blockIdx.x * kLoadTile;                 // first destination byte
+  const u32 dend = min(d0 + (u32)kLoadTile, padded);     // one past the last one
+  // source bytes this tile needs: [a_lo, a_hi)
+  u32 a_lo = 0, a_hi = 0;
+  if (d0 < ncopy) {
+    const u32 last = min(dend, ncopy);                   // destinations [d0, last) have a source
+    if (reverse) { a_lo = ncopy - last; a_hi = ncopy - d0; }
+    else { a_lo = d0; a_hi = last; }
+  }
+  const u32 w_lo = a_lo & ~15u;
+  if (a_hi > a_lo) {
+    const u32 nchunks = (a_hi - w_lo + 15u) / 16u;
+    for (u32 c = tid; c < nchunks; c += kLoadTPB) {
+      const u32 a = w_lo + 16u * c;
+      if (aligned && a + 16u <= ncopy) {
+        *reinterpret_cast<uint4*>(&s_src[16u * c]) = *reinterpret_cast<const uint4*>(src + a);
+      } else {
+        for (u32 b = 0; b < 16u; ++b) s_src[16u * c + b] = (a + b < ncopy) ? src[a + b] : (u8)0;
       }
     }
-    reinterpret_cast<u32*>(T)[w] = word;
   }
   __syncthreads();
-  const u32 c = hist[threadIdx.x];
-  if (c) atomicAdd(&freqs[threadIdx.x], c);
+  const u32 j0 = d0 + tid * 16u;
+  if (j0 < dend) {
+    u32 wds[4] = {0, 0, 0, 0};
+    const u32 copy = tid & 15u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const u32 j = j0 + e;
+      if (j < ncopy) {
+        const u32 a = reverse ? (ncopy - 1u - j) : j;
+        const u32 c = s_src[a - w_lo];
+        wds[e >> 2] |= c << (8 * (e & 3));
+        atomicAdd(&s_hist[c * 16u + copy], 1u);
+      }
+    }
+    *reinterpret_cast<uint4*>(T + j0) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  }
+  __syncthreads();
+  u32 c = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c += s_hist[tid * 16u + r];
+  if (c) atomicAdd(&freqs[tid], c);
 }
 
 // ---------------------------------------------------------------------------------------
-// K2  initial keys.  Slot j holds suffix i = n-1-j (descending!) with the big-endian
-//     4-byte key T[i..i+3] (zero padded past the end).  Feeding the stable sort in
-//     descending suffix order puts, inside every group of equal keys, the suffixes that
-//     are shorter than 4 first and shortest-first -- exactly "proper prefix sorts first".
+// K2  initial keys.  The alphabet is remapped to dense codes of w bits (order preserving,
+//     byte 0 -> code 0) and the key of suffix i is its first k characters packed MSB-first,
+//     k*w <= bits of K; characters past the end read the zero padding.  Slot j holds suffix
+//     i = n-1-j (descending!).  Feeding the stable sort in descending suffix order puts,
+//     inside every group of equal keys, the suffixes shorter than k first and
+//     shortest-first -- exactly "proper prefix sorts first" -- without spending key bits.
 // ---------------------------------------------------------------------------------------
+template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
-                                                   u32* __restrict__ keys,
-                                                   u32* __restrict__ idx, u32 n) {
+                                                   const u8* __restrict__ lut,
+                                                   K* __restrict__ keys, u32* __restrict__ idx,
+                                                   u32 n, int k, int w) {
+  __shared__ u8 s_lut[256];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
   const u32 j = blockIdx.x * 256u + threadIdx.x;
   if (j >= n) return;
   const u32 i = n - 1u - j;
-  const u32 key = ((u32)T[i] << 24) | ((u32)T[i + 1] << 16) | ((u32)T[i + 2] << 8) | (u32)T[i + 3];
+  K key = 0;
+  for (int t = 0; t < k; ++t) key = (K)(key << w) | (K)s_lut[T[i + t]];
   keys[j] = key;
   idx[j] = i;
 }
@@ -84,7 +125,7 @@ struct RrFlags {
 template <typename K, bool INIT>
 __device__ __forceinline__ RrFlags<K, INIT> rr_flags(const K* __restrict__ key,
                                                      const u32* __restrict__ idx, u32 m, u32 n,
-                                                     u32 p0) {
+                                                     u32 short_len, u32 p0) {
   RrFlags<K, INIT> f;
   f.head = 0; f.act = 0; f.valid = 0;
   if (p0 >= m) return f;
@@ -107,7 +148,7 @@ __device__ __forceinline__ RrFlags<K, INIT> rr_flags(const K* __restrict__ key,
     else if (p == 0) h = true;
     else {
       h = k[e + 1] != k[e];
-      if (INIT) h = h || ((u64)s[e] + 3u >= (u64)n);
+      if (INIT) h = h || ((u64)s[e] + short_len >= (u64)n);
     }
     head |= (h ? 1u : 0u) << e;
   }
@@ -127,12 +168,13 @@ __device__ __forceinline__ RrFlags<K, INIT> rr_flags(const K* __restrict__ key,
 template <typename K, bool INIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
                                                           const u32* __restrict__ idx, u32 m,
-                                                          u32 n, u32* __restrict__ aggA,
+                                                          u32 n, u32 short_len,
+                                                          u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
                                                           u32* __restrict__ aggC) {
   __shared__ u32 scr[kRrTPB / kWave + 1];
   const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
-  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, p0);
+  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, short_len, p0);
   const u32 nact = __popc(f.act);
   const u32 nha = __popc(f.act & f.head);
   const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
@@ -143,29 +185,43 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
   if (threadIdx.x == 0) { aggA[blockIdx.x] = ta; aggB[blockIdx.x] = tb; aggC[blockIdx.x] = tc; }
 }
 
-// One workgroup: exclusive sum of aggA, aggB; exclusive max of aggC; totals -> counts[0..1].
+// One workgroup of 16 waves: exclusive sum of aggA, aggB; exclusive max of aggC; totals ->
+// counts[0..1].  Every wave owns a contiguous chunk and walks it 64 entries at a time
+// (coalesced), first to get the chunk totals, then again with the carried prefix.
 __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ aggA,
                                                             u32* __restrict__ aggB,
                                                             u32* __restrict__ aggC, u32 ntiles,
                                                             u32* __restrict__ counts) {
-  __shared__ u32 scr[1024 / kWave + 1];
-  __shared__ u32 s_prev[1024];
-  const u32 per = (ntiles + 1023u) / 1024u;
-  const u32 b = threadIdx.x * per;
+  __shared__ u32 s_tot[3][16];
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x / kWave;
+  const u32 per = ((ntiles + 15u) / 16u + 63u) / 64u * 64u;   // chunk length, multiple of 64
+  const u32 b = wave * per;
   const u32 e = min(b + per, ntiles);
   u32 sa = 0, sb = 0, sc = 0;
-  for (u32 i = b; i < e; ++i) { sa += aggA[i]; sb += aggB[i]; sc = max(sc, aggC[i]); }
-  u32 ta, tb, tc;
-  u32 oa = block_scan_excl_add<1024>(sa, scr, &ta);
-  u32 ob = block_scan_excl_add<1024>(sb, scr, &tb);
-  u32 ic = block_scan_incl_max<1024>(sc, scr, &tc);
-  s_prev[threadIdx.x] = ic;
+  for (u32 i = b + lane; i < e; i += kWave) { sa += aggA[i]; sb += aggB[i]; sc = max(sc, aggC[i]); }
+  sa = wave_scan_add(sa, lane); sb = wave_scan_add(sb, lane); sc = wave_scan_max(sc, lane);
+  if (lane == kWave - 1) { s_tot[0][wave] = sa; s_tot[1][wave] = sb; s_tot[2][wave] = sc; }
   __syncthreads();
-  u32 oc = threadIdx.x ? s_prev[threadIdx.x - 1] : 0u;
-  for (u32 i = b; i < e; ++i) {
-    u32 va = aggA[i], vb = aggB[i], vc = aggC[i];
-    aggA[i] = oa; aggB[i] = ob; aggC[i] = oc;
-    oa += va; ob += vb; oc = max(oc, vc);
+  u32 ca = 0, cb = 0, cc = 0, ta = 0, tb = 0;
+  for (u32 w = 0; w < 16; ++w) {
+    if (w < wave) { ca += s_tot[0][w]; cb += s_tot[1][w]; cc = max(cc, s_tot[2][w]); }
+    ta += s_tot[0][w]; tb += s_tot[1][w];
+  }
+  for (u32 i0 = b; i0 < e; i0 += kWave) {
+    const u32 i = i0 + lane;
+    const bool ok = i < e;
+    const u32 va = ok ? aggA[i] : 0u, vb = ok ? aggB[i] : 0u, vc = ok ? aggC[i] : 0u;
+    const u32 ia = wave_scan_add(va, lane), ib = wave_scan_add(vb, lane), ic = wave_scan_max(vc, lane);
+    const u32 pc = __shfl_up(ic, 1, kWave);
+    if (ok) {
+      aggA[i] = ca + ia - va;
+      aggB[i] = cb + ib - vb;
+      aggC[i] = max(cc, lane ? pc : 0u);
+    }
+    ca += __shfl(ia, kWave - 1, kWave);
+    cb += __shfl(ib, kWave - 1, kWave);
+    cc = max(cc, __shfl(ic, kWave - 1, kWave));
   }
   if (threadIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
 }
@@ -173,13 +229,13 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
 template <typename K, bool INIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
-    u32 n, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
+    u32 n, u32 short_len, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
     u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out) {
   __shared__ u32 scr[kRrTPB / kWave + 1];
   __shared__ u32 s_prev[kRrTPB];
   const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
-  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, p0);
+  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, short_len, p0);
   const u32 nact = __popc(f.act);
   const u32 nha = __popc(f.act & f.head);
   const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
@@ -285,9 +341,9 @@ static ArenaPlan plan_arena(u64 cap) {
   ArenaPlan a;
   u64 o = 0;
   auto take = [&](u64 bytes) { u64 r = o; o = align_up(o + bytes, 256); return r; };
-  a.off_T = take(cap + 32);
-  a.off_out = take(cap + 32);
-  a.off_in = take(cap + 32);
+  a.off_T = take(cap + kTextPad + kLoadTile);
+  a.off_out = take(cap + 64);
+  a.off_in = take(cap + 64);
   a.off_SA = take(cap * 4);
   a.off_rank = take(cap * 4);
   a.off_R1 = take(cap * 8);
@@ -364,9 +420,41 @@ void BwtEngine::release() {
   arena = nullptr; h_small = nullptr; h_stage = nullptr; stream = nullptr;
 }
 
-static constexpr int kSmallFreqs = 0, kSmallLf = 256, kSmallPidx = 512, kSmallCounts = 520;
+static constexpr int kSmallFreqs = 0, kSmallLf = 256, kSmallPidx = 512, kSmallCounts = 520,
+                     kSmallLut = 600;   // 64 words = 256-byte alphabet remap table
 
-int BwtEngine::suffix_sort(u32 n) {
+// Width of the initial sort key.  The alphabet of T is remapped to dense w-bit codes and as
+// many characters as fit are packed into a 32- or 64-bit key: 16 characters of DNA or 4 raw
+// bytes in 32 bits, 9 characters of text in 64 bits.  32 bits are used when the order-0
+// entropy says the 32-bit key already separates almost all suffixes; the choice only
+// changes speed, never the result.
+struct KeyPlan { int w, k; bool wide; u8 lut[256]; };
+
+// lone_sentinel: the only zero byte of T is the terminator planted at T[n-1].  It then
+// shares code 0 with the smallest real symbol instead of costing a code of its own (DNA
+// stays at 2 bits per character): a suffix whose key window reaches the terminator has
+// length <= k, and all of those are split off as singletons in true order by the
+// "shorter first" rule of the initial ranking, so the merged code is never compared.
+static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
+  KeyPlan p;
+  int sigma = 0;
+  double total = 0.0, h0 = 0.0;
+  for (int c = 0; c < 256; ++c) {
+    p.lut[c] = (u8)(sigma > 255 ? 255 : sigma);
+    const bool present = hist[c] != 0 && !(c == 0 && lone_sentinel);
+    if (present) { ++sigma; total += hist[c]; }
+  }
+  for (int c = lone_sentinel ? 1 : 0; c < 256; ++c)
+    if (hist[c]) { const double q = hist[c] / total; h0 -= q * std::log2(q); }
+  p.w = sigma <= 1 ? 1 : bit_width_u64((u64)sigma - 1);
+  const int k32 = std::min(32 / p.w, 32), k64 = std::min(64 / p.w, 32);
+  const double need = std::log2((double)n + 1.0) + 2.0;
+  p.wide = (k64 > k32) && (k32 * h0 < need);
+  p.k = p.wide ? k64 : k32;
+  return p;
+}
+
+int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   hipStream_t st = stream;
   n_sort_events = 0;
   stats.rounds = 0;
@@ -374,32 +462,60 @@ int BwtEngine::suffix_sort(u32 n) {
   stats.sort_pass_items = 0;
   if (n == 0) return 0;
 
-  u32* K32a = static_cast<u32*>(d_R1);
-  u32* K32b = K32a + cap;
-  hipLaunchKernelGGL(k_make_keys, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, K32a, d_V0, n);
+  const KeyPlan plan = plan_keys(hist, n, lone_sentinel);
+  std::memcpy(h_small + kSmallLut, plan.lut, 256);
+  BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallLut, h_small + kSmallLut, 256, hipMemcpyHostToDevice, st));
+  const u8* d_lut = reinterpret_cast<const u8*>(d_small + kSmallLut);
+  const int key_bits = plan.k * plan.w;
+  // suffixes of length <= k are finished by the initial ranking (a suffix of length exactly
+  // k is a proper prefix of every other suffix with the same key)
+  const u32 short_len = (u32)plan.k;
 
-  u32 *ks = nullptr, *vs = nullptr;
-  BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-  radix_sort_pairs<u32>(K32a, K32b, d_V0, d_V1, n, 32, d_table, d_partial, st, &ks, &vs, &probe);
-  BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-  stats.sort_pass_items += (u64)n * 4;
-
-  // initial ranking.  Sorted suffixes are in vs; the other V buffer receives the active list.
-  u32* aidx = (vs == d_V0) ? d_V1 : d_V0;
-  u32* aidx_other = vs;             // free once the ranking has consumed it
+  // initial sort + ranking.  The sorted suffixes end in one V buffer; the other one
+  // receives the active list.
+  u32* aidx = nullptr;
+  u32* aidx_other = nullptr;
   u32* aglob = d_G0;
   u32* aglob_other = d_G1;
   u32* counts = d_small + kSmallCounts;
-  {
-    const u32 tiles = ceil_div(n, kRrTile);
-    hipLaunchKernelGGL((k_rerank_reduce<u32, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, n,
-                       n, d_aggA, d_aggB, d_aggC);
+  const u32 tiles0 = ceil_div(n, kRrTile);
+  BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  if (plan.wide) {
+    u64* ka = static_cast<u64*>(d_R1);
+    u64* kb = static_cast<u64*>(d_R2);
+    hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
+                       d_V0, n, plan.k, plan.w);
+    u64* ks = nullptr; u32* vs = nullptr;
+    radix_sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, d_table, d_partial, st, &ks, &vs, &probe);
+    BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    aidx = (vs == d_V0) ? d_V1 : d_V0;
+    aidx_other = vs;
+    hipLaunchKernelGGL((k_rerank_reduce<u64, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs, n,
+                       n, short_len, d_aggA, d_aggB, d_aggC);
     hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
-                       tiles, counts);
-    hipLaunchKernelGGL((k_rerank_apply<u32, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
-                       (const u32*)nullptr, n, n, d_aggA, d_aggB, d_aggC, d_rank, d_SA, aidx,
-                       aglob, d_GRP);
+                       tiles0, counts);
+    hipLaunchKernelGGL((k_rerank_apply<u64, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
+                       (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
+                       aidx, aglob, d_GRP);
+  } else {
+    u32* ka = static_cast<u32*>(d_R1);
+    u32* kb = ka + cap;
+    hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
+                       d_V0, n, plan.k, plan.w);
+    u32* ks = nullptr; u32* vs = nullptr;
+    radix_sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, d_table, d_partial, st, &ks, &vs, &probe);
+    BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    aidx = (vs == d_V0) ? d_V1 : d_V0;
+    aidx_other = vs;
+    hipLaunchKernelGGL((k_rerank_reduce<u32, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs, n,
+                       n, short_len, d_aggA, d_aggB, d_aggC);
+    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
+                       tiles0, counts);
+    hipLaunchKernelGGL((k_rerank_apply<u32, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
+                       (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
+                       aidx, aglob, d_GRP);
   }
+  stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipStreamSynchronize(st));
   u32 m = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
@@ -407,9 +523,9 @@ int BwtEngine::suffix_sort(u32 n) {
   u64* K64a = static_cast<u64*>(d_R1);
   u64* K64b = static_cast<u64*>(d_R2);
   const int b2 = bit_width_u64(n);    // key2 <= n
-  u64 h = 4;
+  u64 h = (u64)plan.k;
   while (m > 0) {
-    if (h >= (u64)n * 2 + 8) return -3;   // cannot happen: every group splits by then
+    if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
     ++stats.rounds;
     stats.active_sum += m;
     const int b1 = bit_width_u64(groups ? groups - 1 : 0);
@@ -427,11 +543,11 @@ int BwtEngine::suffix_sort(u32 n) {
     u32* next_aidx = (v64s == aidx) ? aidx_other : aidx;
     const u32 tiles = ceil_div(m, kRrTile);
     hipLaunchKernelGGL((k_rerank_reduce<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
-                       v64s, m, n, d_aggA, d_aggB, d_aggC);
+                       v64s, m, n, 0u, d_aggA, d_aggB, d_aggC);
     hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
                        tiles, counts);
     hipLaunchKernelGGL((k_rerank_apply<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s, v64s,
-                       aglob, m, n, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx, aglob_other,
+                       aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx, aglob_other,
                        d_GRP);
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipStreamSynchronize(st));
@@ -442,6 +558,23 @@ int BwtEngine::suffix_sort(u32 n) {
     { u32* t = aglob; aglob = aglob_other; aglob_other = t; }
     h *= 2;
   }
+  return 0;
+}
+
+// Loads `ncopy` bytes of d_src into d_T (reversed or not), zero-fills up to n + padding and
+// returns the histogram of T[0..n-1] (the implicit zeros included) in hist_T.
+int BwtEngine::load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T) {
+  hipStream_t st = stream;
+  BWTC_HIP_TRY(hipMemsetAsync(d_small, 0, 1024 * 4, st));
+  const u32 padded = (u32)((((u64)n + kTextPad + 15) / 16) * 16);
+  const int aligned = (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0;
+  hipLaunchKernelGGL(k_load_hist, dim3(ceil_div(padded, kLoadTile)), dim3(kLoadTPB), 0, st, d_src,
+                     d_T, ncopy, padded, reverse ? 1 : 0, aligned, d_small + kSmallFreqs);
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFreqs, d_small + kSmallFreqs, 256 * 4,
+                              hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  for (int c = 0; c < 256; ++c) hist_T[c] = h_small[kSmallFreqs + c];
+  hist_T[0] += n - ncopy;
   return 0;
 }
 
@@ -456,11 +589,11 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   if ((u64)n > cap) return -1;
   BWTC_HIP_TRY(hipSetDevice(device));
   BWTC_HIP_TRY(hipEventRecord(ev_begin, st));
-  BWTC_HIP_TRY(hipMemsetAsync(d_small, 0, 1024 * 4, st));
-  const u32 padded_words = (u32)(((u64)n + 8 + 3) / 4);
-  hipLaunchKernelGGL(k_load_hist, dim3(ceil_div(padded_words, kLoadTPB)), dim3(kLoadTPB), 0, st,
-                     d_src, d_T, nsrc, padded_words, raw ? 0 : 1, d_small + kSmallFreqs);
-  int rc = suffix_sort(n);
+  u32 hist_T[256];
+  int rc = load_text(d_src, nsrc, n, !raw, hist_T);
+  if (rc) return rc;
+  if (freqs) for (int c = 0; c < 256; ++c) freqs[c] += h_small[kSmallFreqs + c];
+  rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0);
   if (rc) return rc;
   hipLaunchKernelGGL(k_bwt_gather, dim3(ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, st, d_SA,
                      d_T, d_out, n, d_small + kSmallPidx);
@@ -468,12 +601,11 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
                      d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0);
   if (raw ? n : size)
     BWTC_HIP_TRY(hipMemcpyAsync(d_dst, d_out, raw ? n : size, hipMemcpyDeviceToDevice, st));
-  BWTC_HIP_TRY(hipMemcpyAsync(h_small, d_small, 520 * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallLf, d_small + kSmallLf, 264 * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipEventRecord(ev_end, st));
   BWTC_HIP_TRY(hipStreamSynchronize(st));
   BWTC_HIP_TRY(hipGetLastError());
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
-  if (freqs) for (int c = 0; c < 256; ++c) freqs[c] += h_small[kSmallFreqs + c];
   probe.harvest();
   stats.n = n;
   (void)hipEventElapsedTime(&stats.ms_total, ev_begin, ev_end);

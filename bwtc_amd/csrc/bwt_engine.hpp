@@ -67,7 +67,9 @@ struct BwtEngine {
 
   // Sorts the suffixes of d_T[0..n-1]; on return d_SA holds the suffix array and d_rank
   // its inverse.  d_T must be followed by >= 8 zero bytes.
-  int suffix_sort(u32 n);
+  // hist = byte histogram of d_T[0..n-1] (drives the width of the initial sort key).
+  int suffix_sort(u32 n, const u32* hist, bool lone_sentinel);
+  int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
   // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).
   // raw=false: block semantics (reverse, sentinel, EOB patch).  raw=true: d_src already is
   // T (size = length), position pidx keeps its input byte.

@@ -235,9 +235,11 @@ int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, 
   BwtEngine& e = ctx->eng;
   if ((u64)length > e.cap) return -1;
   BWTC_HIP_TRY(hipSetDevice(e.device));
-  BWTC_HIP_TRY(hipMemsetAsync(e.d_T, 0, (u64)length + 16, e.stream));
-  BWTC_HIP_TRY(hipMemcpyAsync(e.d_T, T, length, hipMemcpyHostToDevice, e.stream));
-  int rc = e.suffix_sort(length);
+  BWTC_HIP_TRY(hipMemcpyAsync(e.d_in, T, length, hipMemcpyHostToDevice, e.stream));
+  u32 hist[256];
+  int rc = e.load_text(e.d_in, length, length, false, hist);
+  if (rc) return rc;
+  rc = e.suffix_sort(length, hist, false);
   if (rc) return rc;
   BWTC_HIP_TRY(hipMemcpyAsync(sa, e.d_SA, (u64)length * 4, hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
