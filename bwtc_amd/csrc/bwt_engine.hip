@@ -100,70 +100,71 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
 }
 
 // ---------------------------------------------------------------------------------------
-// K4  re-ranking of a sorted list (INIT: the whole SA after the 4-byte sort, keys u32;
-//     rounds: the active list after sorting by (group, rank[s+h]), keys u64).
+// K4  re-ranking of a sorted list (INIT: the whole SA after the initial sort; rounds: the
+//     active list after sorting by (group, rank[s+h]), keys u64).
 //
-//     head[p]   = p starts a new group (key differs from p-1; INIT: or p-1 is shorter
+//     head[p]   = p starts a new group (key differs from p-1; INIT: or p-1 is no longer
 //                 than the key, which makes it a finished singleton)
 //     active[p] = p's group has >= 2 members
 //     new rank of p = global SA slot of its group head
 //     finished suffixes go to SA; active ones are compacted (order kept) into the next
 //     active list with their global slot and a dense group number.
 //     Three launches: tile reduce, one-workgroup scan of the tile aggregates, tile apply.
+//
+//     Every wave owns 512 consecutive list slots and walks them 64 at a time (coalesced).
+//     Flags become 64-bit ballots, so every prefix inside the wave is a popcount of a
+//     masked ballot and the running sums live in scalar registers; only the four wave
+//     totals of a tile cross LDS.
 // ---------------------------------------------------------------------------------------
 constexpr int kRrTPB = 256;
+constexpr int kRrWaves = kRrTPB / kWave;
 constexpr int kRrE = 8;
-constexpr int kRrTile = kRrTPB * kRrE;
+constexpr int kRrChunk = kWave * kRrE;        // slots per wave
+constexpr int kRrTile = kRrTPB * kRrE;        // slots per workgroup
+
+__device__ __forceinline__ u64 shfl_up1(u64 v) {
+  return (u64)__shfl_up((unsigned long long)v, 1, kWave);
+}
+__device__ __forceinline__ u32 shfl_up1(u32 v) { return __shfl_up(v, 1, kWave); }
+__device__ __forceinline__ u64 shfl_down1(u64 v) {
+  return (u64)__shfl_down((unsigned long long)v, 1, kWave);
+}
+__device__ __forceinline__ u32 shfl_down1(u32 v) { return __shfl_down(v, 1, kWave); }
 
 template <typename K, bool INIT>
-struct RrFlags {
-  u32 head;   // bit e: element e is a group head
-  u32 act;    // bit e: element e stays active
-  u32 valid;  // bit e: element e exists
+struct RrMasks {
+  u64 head[kRrE], act[kRrE], valid[kRrE];
+  u32 sfx[kRrE];       // idx[p] of this lane's slot in iteration e
 };
 
+// Masks of one wave chunk starting at list slot wbase.
 template <typename K, bool INIT>
-__device__ __forceinline__ RrFlags<K, INIT> rr_flags(const K* __restrict__ key,
-                                                     const u32* __restrict__ idx, u32 m, u32 n,
-                                                     u32 short_len, u32 p0) {
-  RrFlags<K, INIT> f;
-  f.head = 0; f.act = 0; f.valid = 0;
-  if (p0 >= m) return f;
-  K k[kRrE + 2];
-  u32 s[kRrE + 1];   // s[e] = idx[p0 - 1 + e]  (INIT only)
-  k[0] = (p0 > 0) ? key[p0 - 1] : (K)0;
-  if (INIT) s[0] = (p0 > 0) ? idx[p0 - 1] : 0u;
-#pragma unroll
-  for (int e = 0; e < kRrE + 1; ++e) {
-    const u32 p = p0 + e;
-    k[e + 1] = (p < m) ? key[p] : (K)0;
-    if (INIT && e < kRrE) s[e + 1] = (p < m) ? idx[p] : 0u;
-  }
-  u32 head = 0;   // kRrE + 1 bits
-#pragma unroll
-  for (int e = 0; e < kRrE + 1; ++e) {
-    const u32 p = p0 + e;
-    bool h;
-    if (p >= m) h = true;
-    else if (p == 0) h = true;
-    else {
-      h = k[e + 1] != k[e];
-      if (INIT) h = h || ((u64)s[e] + short_len >= (u64)n);
-    }
-    head |= (h ? 1u : 0u) << e;
-  }
+__device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
+                                         u32 m, u32 n, u32 short_len, u32 wbase, u32 lane,
+                                         RrMasks<K, INIT>& f) {
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
-    const u32 p = p0 + e;
-    if (p < m) {
-      f.valid |= 1u << e;
-      const bool h = (head >> e) & 1u, hn = (head >> (e + 1)) & 1u;
-      if (!h || !hn) f.act |= 1u << e;
-    }
+    const u32 p = wbase + e * kWave + lane;
+    const bool ok = p < m;
+    const K kc = ok ? key[p] : (K)0;
+    const u32 ic = ok ? idx[p] : 0u;
+    K kp = shfl_up1(kc);
+    K kn = shfl_down1(kc);
+    u32 ip = shfl_up1(ic);
+    if (lane == 0) { kp = (ok && p > 0) ? key[p - 1] : (K)0; if (INIT) ip = (ok && p > 0) ? idx[p - 1] : 0u; }
+    if (lane == kWave - 1) kn = (p + 1 < m) ? key[p + 1] : (K)0;
+    bool h = ok && (p == 0 || kc != kp);
+    if (INIT) h = h || (ok && p > 0 && (u64)ip + short_len >= (u64)n);
+    bool hn = (p + 1 >= m) || kn != kc;           // is p+1 a head (or past the end)?
+    if (INIT) hn = hn || ((u64)ic + short_len >= (u64)n);
+    f.head[e] = __ballot(h);
+    f.valid[e] = __ballot(ok);
+    f.act[e] = __ballot(ok && (!h || !hn));
+    f.sfx[e] = ic;
   }
-  f.head = head & f.valid;
-  return f;
 }
+
+__device__ __forceinline__ u32 top_bit(u64 v) { return 63u - (u32)__clzll((unsigned long long)v); }
 
 template <typename K, bool INIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
@@ -172,17 +173,26 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
                                                           u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
                                                           u32* __restrict__ aggC) {
-  __shared__ u32 scr[kRrTPB / kWave + 1];
-  const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
-  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, short_len, p0);
-  const u32 nact = __popc(f.act);
-  const u32 nha = __popc(f.act & f.head);
-  const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
-  u32 ta, tb, tc;
-  block_scan_excl_add<kRrTPB>(nact, scr, &ta);
-  block_scan_excl_add<kRrTPB>(nha, scr, &tb);
-  block_scan_incl_max<kRrTPB>(last, scr, &tc);
-  if (threadIdx.x == 0) { aggA[blockIdx.x] = ta; aggB[blockIdx.x] = tb; aggC[blockIdx.x] = tc; }
+  __shared__ u32 s_tot[3][kRrWaves];
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x / kWave;
+  const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
+  RrMasks<K, INIT> f;
+  rr_masks<K, INIT>(key, idx, m, n, short_len, wbase, lane, f);
+  u32 nact = 0, nha = 0, last = 0;
+#pragma unroll
+  for (int e = 0; e < kRrE; ++e) {
+    nact += (u32)__popcll(f.act[e]);
+    nha += (u32)__popcll(f.act[e] & f.head[e]);
+    if (f.head[e]) last = wbase + e * kWave + top_bit(f.head[e]) + 1u;
+  }
+  if (lane == 0) { s_tot[0][wave] = nact; s_tot[1][wave] = nha; s_tot[2][wave] = last; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 a = 0, b = 0, c = 0;
+    for (int w = 0; w < kRrWaves; ++w) { a += s_tot[0][w]; b += s_tot[1][w]; c = max(c, s_tot[2][w]); }
+    aggA[blockIdx.x] = a; aggB[blockIdx.x] = b; aggC[blockIdx.x] = c;
+  }
 }
 
 // One workgroup of 16 waves: exclusive sum of aggA, aggB; exclusive max of aggC; totals ->
@@ -226,47 +236,91 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
   if (threadIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
 }
 
-template <typename K, bool INIT>
+// PAIRS: instead of scattering rank[s] = nr from here (one random 4-byte write per element,
+// each costing a whole HBM sector), emit (s, nr) in list order; the caller partitions the
+// pairs by the high bits of s and k_scatter_pairs then writes into one small window of
+// rank[] at a time.
+template <typename K, bool INIT, bool PAIRS>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
     u32 n, u32 short_len, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
-    u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out) {
-  __shared__ u32 scr[kRrTPB / kWave + 1];
-  __shared__ u32 s_prev[kRrTPB];
-  const u32 p0 = blockIdx.x * kRrTile + threadIdx.x * kRrE;
-  const RrFlags<K, INIT> f = rr_flags<K, INIT>(key, idx, m, n, short_len, p0);
-  const u32 nact = __popc(f.act);
-  const u32 nha = __popc(f.act & f.head);
-  const u32 last = f.head ? (p0 + (31u - __clz(f.head)) + 1u) : 0u;
-  u32 t;
-  u32 q = block_scan_excl_add<kRrTPB>(nact, scr, &t) + aggA[blockIdx.x];
-  u32 gcount = block_scan_excl_add<kRrTPB>(nha, scr, &t) + aggB[blockIdx.x];
-  const u32 incl = block_scan_incl_max<kRrTPB>(last, scr, &t);
-  s_prev[threadIdx.x] = incl;
+    u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out,
+    u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+  __shared__ u32 s_tot[3][kRrWaves];
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x / kWave;
+  const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
+  RrMasks<K, INIT> f;
+  rr_masks<K, INIT>(key, idx, m, n, short_len, wbase, lane, f);
+  {
+    u32 nact = 0, nha = 0, last = 0;
+#pragma unroll
+    for (int e = 0; e < kRrE; ++e) {
+      nact += (u32)__popcll(f.act[e]);
+      nha += (u32)__popcll(f.act[e] & f.head[e]);
+      if (f.head[e]) last = wbase + e * kWave + top_bit(f.head[e]) + 1u;
+    }
+    if (lane == 0) { s_tot[0][wave] = nact; s_tot[1][wave] = nha; s_tot[2][wave] = last; }
+  }
   __syncthreads();
-  u32 hp1 = max(threadIdx.x ? s_prev[threadIdx.x - 1] : 0u, aggC[blockIdx.x]);  // head pos + 1
+  u32 q_run = aggA[blockIdx.x], g_run = aggB[blockIdx.x], hp_run = aggC[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) {
+    q_run += s_tot[0][w]; g_run += s_tot[1][w]; hp_run = max(hp_run, s_tot[2][w]);
+  }
+  const u64 lt = (1ull << lane) - 1ull;
+  const u64 le = lt | (1ull << lane);
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
-    if (!((f.valid >> e) & 1u)) break;
-    const u32 p = p0 + e;
-    const bool h = (f.head >> e) & 1u, a = (f.act >> e) & 1u;
-    if (h) hp1 = p + 1u;
-    if (h && a) ++gcount;
-    const u32 hp = hp1 - 1u;
-    const u32 s = idx[p];
-    const u32 g = INIT ? p : aglob[p];
-    const u32 nr = INIT ? hp : aglob[hp];
-    rank[s] = nr;
-    if (a) {
-      aidx_out[q] = s;
-      aglob_out[q] = g;
-      agrp_out[q] = gcount - 1u;
-      ++q;
-    } else {
-      SA[g] = s;
+    const u32 base = wbase + e * kWave;
+    const u32 p = base + lane;
+    const u64 hd = f.head[e], ac = f.act[e];
+    if ((f.valid[e] >> lane) & 1ull) {
+      const bool a = (ac >> lane) & 1ull;
+      const u64 hm = hd & le;
+      const u32 hp1 = hm ? base + top_bit(hm) + 1u : hp_run;   // head slot + 1
+      const u32 s = f.sfx[e];
+      const u32 g = INIT ? p : aglob[p];
+      const u32 nr = INIT ? hp1 - 1u : aglob[hp1 - 1u];
+      if (PAIRS) { pair_s[p] = s; pair_r[p] = nr; }
+      else rank[s] = nr;
+      if (a) {
+        const u32 q = q_run + (u32)__popcll(ac & lt);
+        aidx_out[q] = s;
+        aglob_out[q] = g;
+        agrp_out[q] = g_run + (u32)__popcll(ac & hd & le) - 1u;
+      } else {
+        SA[g] = s;
+      }
     }
+    q_run += (u32)__popcll(ac);
+    g_run += (u32)__popcll(ac & hd);
+    if (hd) hp_run = base + top_bit(hd) + 1u;
   }
+}
+
+constexpr int kSimpleE = 4;   // independent items per thread in the latency-bound kernels
+
+__global__ __launch_bounds__(256) void k_scatter_pairs(u32* __restrict__ dst,
+                                                       const u32* __restrict__ where,
+                                                       const u32* __restrict__ what, u32 m) {
+  // XCD-contiguous chunking (speed only): the pairs are partitioned by destination window,
+  // so giving each XCD one contiguous eighth of the list keeps every window in ONE L2.
+  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
+  const u32 per_xcd = (nblk + 7u) / 8u;
+  const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (blk >= nblk) return;
+  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
+  u32 w[kSimpleE], v[kSimpleE];
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u32 p = p0 + e * 256u;
+    w[e] = p < m ? where[p] : 0u;
+    v[e] = p < m ? what[p] : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e)
+    if (p0 + e * 256u < m) dst[w[e]] = v[e];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -278,11 +332,22 @@ __global__ __launch_bounds__(256) void k_gather_key2(const u32* __restrict__ aid
                                                      const u32* __restrict__ rank,
                                                      u64* __restrict__ key, u32 m, u32 n, u32 h,
                                                      int b2) {
-  const u32 p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= m) return;
-  const u64 t = (u64)aidx[p] + (u64)h;
-  const u64 key2 = (t < (u64)n) ? (u64)rank[t] + 1ull : 0ull;
-  key[p] = ((u64)agrp[p] << b2) | key2;
+  const u32 p0 = blockIdx.x * (256u * kSimpleE) + threadIdx.x;
+  u64 t[kSimpleE];
+  u32 r[kSimpleE], g[kSimpleE];
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u32 p = p0 + e * 256u;
+    t[e] = p < m ? (u64)aidx[p] + (u64)h : ~0ull;
+    g[e] = p < m ? agrp[p] : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) r[e] = (t[e] < (u64)n) ? rank[t[e]] + 1u : 0u;
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u32 p = p0 + e * 256u;
+    if (p < m) key[p] = ((u64)g[e] << b2) | (u64)r[e];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -454,6 +519,24 @@ static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
   return p;
 }
 
+// rank[pairs_s[i]] = pairs_r[i] for i < m, made cache-friendly: the pairs (two arrays of
+// `cap` words inside one 8*cap-byte region) are first partitioned by the top 16 bits of the
+// destination with two stable radix passes (tmp = another 8*cap-byte region), after which
+// consecutive pairs write into the same 4096-word window of rank[].
+constexpr u32 kPairsMin = 1u << 21;
+
+void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
+  hipStream_t st = stream;
+  const int bits = bit_width_u64(n ? n - 1 : 0);
+  const int lo = bits > 16 ? bits - 16 : 0;
+  u32 *ws = pairs, *wr = pairs + cap;
+  if (m >= kPairsMin && bits > 12)
+    radix_sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, d_table, d_partial, st, &ws,
+                          &wr, nullptr, lo);
+  hipLaunchKernelGGL(k_scatter_pairs, dim3((ceil_div(m, 256 * kSimpleE) + 7u) / 8u * 8u), dim3(256), 0, st,
+                     d_rank, ws, wr, m);
+}
+
 int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   hipStream_t st = stream;
   n_sort_events = 0;
@@ -494,9 +577,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
                        n, short_len, d_aggA, d_aggB, d_aggC);
     hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
                        tiles0, counts);
-    hipLaunchKernelGGL((k_rerank_apply<u64, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
+    u32* pairs = reinterpret_cast<u32*>(ks == ka ? kb : ka);
+    hipLaunchKernelGGL((k_rerank_apply<u64, true, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
                        (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
-                       aidx, aglob, d_GRP);
+                       aidx, aglob, d_GRP, pairs, pairs + cap);
+    scatter_rank_pairs(pairs, reinterpret_cast<u32*>(ks), n, n);
   } else {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
@@ -511,9 +596,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
                        n, short_len, d_aggA, d_aggB, d_aggC);
     hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
                        tiles0, counts);
-    hipLaunchKernelGGL((k_rerank_apply<u32, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
+    u32* pairs = static_cast<u32*>(d_R2);
+    hipLaunchKernelGGL((k_rerank_apply<u32, true, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
                        (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
-                       aidx, aglob, d_GRP);
+                       aidx, aglob, d_GRP, pairs, pairs + cap);
+    scatter_rank_pairs(pairs, static_cast<u32*>(d_R1), n, n);
   }
   stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
@@ -529,7 +616,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     ++stats.rounds;
     stats.active_sum += m;
     const int b1 = bit_width_u64(groups ? groups - 1 : 0);
-    hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m, 256)), dim3(256), 0, st, aidx, d_GRP,
+    hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m, 256 * kSimpleE)), dim3(256), 0, st, aidx, d_GRP,
                        d_rank, K64a, m, n, (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFu : h), b2);
     u64* k64s = nullptr;
     u32* v64s = nullptr;
@@ -546,9 +633,17 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
                        v64s, m, n, 0u, d_aggA, d_aggB, d_aggC);
     hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
                        tiles, counts);
-    hipLaunchKernelGGL((k_rerank_apply<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s, v64s,
-                       aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx, aglob_other,
-                       d_GRP);
+    if (m >= kPairsMin) {
+      u32* pairs = reinterpret_cast<u32*>(k64s == K64a ? K64b : K64a);
+      hipLaunchKernelGGL((k_rerank_apply<u64, false, true>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
+                         v64s, aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx,
+                         aglob_other, d_GRP, pairs, pairs + cap);
+      scatter_rank_pairs(pairs, reinterpret_cast<u32*>(k64s), m, n);
+    } else {
+      hipLaunchKernelGGL((k_rerank_apply<u64, false, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
+                         v64s, aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx,
+                         aglob_other, d_GRP, (u32*)nullptr, (u32*)nullptr);
+    }
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipStreamSynchronize(st));
     m = h_small[kSmallCounts];

@@ -69,6 +69,7 @@ struct BwtEngine {
   // its inverse.  d_T must be followed by >= 8 zero bytes.
   // hist = byte histogram of d_T[0..n-1] (drives the width of the initial sort key).
   int suffix_sort(u32 n, const u32* hist, bool lone_sentinel);
+  void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
   // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).
   // raw=false: block semantics (reverse, sentinel, EOB patch).  raw=true: d_src already is

@@ -74,7 +74,13 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 
   const u32 tid = threadIdx.x;
   const u32 wave = tid / kWave, lane = tid % kWave;
-  const u64 tile_base = (u64)blockIdx.x * TILE;
+  // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness): give
+  // every XCD a contiguous range of tiles so that the partial cache lines at the seams of
+  // neighbouring tiles' output runs meet in ONE L2 instead of being written back twice.
+  const u32 per_xcd = (ntiles + 7u) / 8u;
+  const u32 tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const u64 tile_base = (u64)tile * TILE;
   const u64 left = n - tile_base;
   const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
 
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   u32 dig_base = block_scan_excl_add<kRadixTPB>(tid < kRadixBins ? dig_total : 0u, s_scr, &unused);
   if (tid < kRadixBins) {
     s_base[tid] = dig_base;
-    s_gofs[tid] = table[(u64)tid * ntiles + blockIdx.x] - dig_base;
+    s_gofs[tid] = table[(u64)tid * ntiles + tile] - dig_base;
   }
   __syncthreads();
 
@@ -187,23 +193,24 @@ struct ScatterProbe {
   void destroy() { if (created) for (int i = 0; i < 2 * kMax; ++i) (void)hipEventDestroy(ev[i]); created = false; }
 };
 
-// Sorts n pairs by key bits [0, nbits).  Buffers ping-pong; on return *k_sorted/*v_sorted
+// Sorts n pairs by key bits [bit_lo, nbits) (stable, so lower bits keep their order).  Buffers ping-pong; on return *k_sorted/*v_sorted
 // point at whichever of (k0,v0)/(k1,v1) holds the result.
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
-                                    K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr) {
+                                    K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
+                                    int bit_lo = 0) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1) {
     const u32 ntiles = ceil_div(n, radix_tile<K>());
-    for (int shift = 0; shift < nbits; shift += kRadixBits) {
+    for (int shift = bit_lo; shift < nbits; shift += kRadixBits) {
       hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n,
                          shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-      hipLaunchKernelGGL(k_radix_scatter<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, kin, vin,
-                         kout, vout, table, n, shift, ntiles);
+      hipLaunchKernelGGL(k_radix_scatter<K>, dim3(((ntiles + 7u) / 8u) * 8u), dim3(kRadixTPB), 0,
+                         st, kin, vin, kout, vout, table, n, shift, ntiles);
       if (timed) probe->end(st, n * 2 * (sizeof(K) + sizeof(u32)));
       K* tk = kin; kin = kout; kout = tk;
       u32* tv = vin; vin = vout; vout = tv;

@@ -10,9 +10,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bwtc_amd import hip, synth  # noqa: E402
 
-sizes = [int(a) for a in sys.argv[1:]] or [16, 64]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+kinds = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or ["text", "dna", "random"]
+sizes = [int(a) for a in args] or [16, 64]
 ctx = hip.Context(0, (max(sizes) << 20) + 64)
 for kind, gen, seed in [("text", synth.gen_text, 3), ("dna", synth.gen_dna, 2), ("random", synth.gen_random_bytes, 1)]:
+    if kind not in kinds:
+        continue
     for mib in sizes:
         d = gen(mib << 20, seed)
         best = None
