@@ -65,9 +65,15 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles) {
   constexpr int E = RadixCfg<K>::E;
   constexpr int TILE = kRadixTPB * E;
-  __shared__ K s_key[TILE];
-  __shared__ u32 s_val[TILE];
-  __shared__ u32 s_cnt[kRadixWaves][kRadixBins];   // per-wave digit counts -> wave offsets
+  // LDS: the per-wave digit counters are dead once every thread has turned them into its
+  // tile slots, so the reorder staging (keys, then values) reuses their bytes; that keeps
+  // the (u64,u32) kernel at 50 KiB = three workgroups per CU.
+  constexpr int kStageBytes = TILE * (int)(sizeof(K) + sizeof(u32));
+  constexpr int kCntBytes = kRadixWaves * kRadixBins * (int)sizeof(u32);
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStageBytes > kCntBytes ? kStageBytes : kCntBytes];
+  K* s_key = reinterpret_cast<K*>(s_raw);
+  u32* s_val = reinterpret_cast<u32*>(s_raw + TILE * sizeof(K));
+  u32 (*s_cnt)[kRadixBins] = reinterpret_cast<u32 (*)[kRadixBins]>(s_raw);
   __shared__ u32 s_base[kRadixBins];               // first tile slot of each digit
   __shared__ u32 s_gofs[kRadixBins];               // global base minus tile slot
   __shared__ u32 s_scr[kRadixTPB / kWave + 1];
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   }
   __syncthreads();
 
-  volatile u32* my_cnt = s_cnt[wave];
+  volatile u32* my_cnt = &s_cnt[wave][0];
   const u64 lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -139,9 +145,15 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (int e = 0; e < E; ++e) {
     if ((wslot + e * kWave) < tile_n) {
       const u32 d = radix_digit(k[e], shift);
-      const u32 pos = s_base[d] + s_cnt[wave][d] + r[e];
-      s_key[pos] = k[e];
-      s_val[pos] = v[e];
+      r[e] += s_base[d] + s_cnt[wave][d];          // final tile slot
+    }
+  }
+  __syncthreads();                                  // counters are dead from here on
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((wslot + e * kWave) < tile_n) {
+      s_key[r[e]] = k[e];
+      s_val[r[e]] = v[e];
     }
   }
   __syncthreads();
