@@ -119,11 +119,21 @@ def main():
         st = ctx.stats()
         total_mb = world * args.steps * size / 1e6
         roof = None
+        # HBM bytes per launch of the same kernel on the same workload, from the committed PMC
+        # passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 runs, gfx950 correction applied
+        # by scripts/pmc_summary.py).  Only quoted for the workload it was measured on.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_text256.json")
+        if args.size_mib == 256 and os.path.exists(pmc):
+            for name, v in json.load(open(pmc))["kernels"].items():
+                if "k_radix_scatter<unsigned long>" in name:
+                    traffic = int(v["hbm_bytes_per_launch_avg"])
         if kt["scatter_launches"]:
             achieved = kt["scatter_bytes"] / (kt["scatter_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_radix_scatter<u64> (+<u32> initial passes)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_traffic_text256.json" if traffic else None,
                     "launches": kt["scatter_launches"],
                     "avg_launch_us": round(1e3 * kt["scatter_ms"] / kt["scatter_launches"], 1),
                     "algorithmic_bytes_per_launch": int(kt["scatter_bytes"] / kt["scatter_launches"])}
