@@ -65,21 +65,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
-    import torch.distributed as dist
+    from bwtc_amd import hip, synth
+    from bwtc_amd.farm import Farm
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    farm = Farm(backend="nccl", device=dev)          # "nccl" is RCCL on ROCm
+    rank, world = farm.rank, farm.world
 
-    from bwtc_amd import hip, synth
     size = args.size_mib << 20
-    seed = 3 if world == 1 else 30 + rank          # C3 at N=1, C4 blocks otherwise
+    # one block per GPU: rank r owns block r of the job (C3 at N=1, C4 seeds 30.. otherwise)
+    assert farm.my_blocks(world) == [rank]
+    seed = 3 if world == 1 else 30 + rank
     host = synth.gen_text(size, seed)
     d_in = torch.from_numpy(host).to(dev)
     d_out = torch.empty_like(d_in)
@@ -87,32 +85,18 @@ def main():
     have_encode = hasattr(ctx, "huffman_encode_device")
     d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev) if have_encode else None
     torch.cuda.synchronize()
+    comp = [0]
 
     def step():
         lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
         if have_encode:
-            return ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
-        return 0
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            comp[0] = ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
 
     for _ in range(args.warmup):
         step()
     ctx.reset_kernel_timers()
-    barrier()
-    t0 = time.perf_counter()
-    comp_bytes = 0
-    for _ in range(args.steps):
-        comp_bytes = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = farm.timed(step, args.steps, 0)
+    comp_bytes = comp[0]
 
     if rank == 0:
         kt = ctx.kernel_timers()
@@ -158,9 +142,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_mib, seed, "H" if have_encode else "")
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    farm.close()
 
 
 if __name__ == "__main__":
