@@ -154,3 +154,41 @@ def test_full_size_text_roundtrip(hip_ctx, oracle):
     st = hip_ctx.stats()
     print("64MiB text: %.1f ms total, %.1f ms sort, rounds %d, R_eff %.2f" %
           (st.ms_total, st.ms_sort, st.rounds, st.active_sum / st.n))
+
+
+def test_baseline_full_size_256MiB_text(oracle):
+    """BASELINE.json config 3 at full size (256 MiB text block, 8 starting points): the
+    size-independent properties -- inverse transform reproduces the input with every LF power
+    on the LF walk, freqs is the byte histogram -- plus, when the reference build is present,
+    bit-equality with the reference's divbwtf."""
+    from bwtc_amd import hip
+    size = 256 << 20
+    d = synth.gen_text(size, 3)
+    with hip.Context(0, size) as ctx:
+        bwt, lf, freqs = ctx.bwt_block(d, 8)
+        st = ctx.stats()
+    assert lf.size == 8
+    assert (freqs == np.bincount(d, minlength=256)).all()
+    rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
+    assert rc == 0
+    assert hashlib.sha256(inv.tobytes()).digest() == hashlib.sha256(d.tobytes()).digest()
+    del inv
+    if oracle.ref() is not None:
+        rb, rlf, rfr = oracle.ref_bwt_block(d, 8)
+        assert hashlib.sha256(rb.tobytes()).digest() == hashlib.sha256(bwt.tobytes()).digest()
+        assert (rlf == lf).all() and (rfr == freqs).all()
+    print("256MiB text: %.1f ms device, rounds %d, R_eff %.2f" % (st.ms_total, st.rounds, st.active_sum / st.n))
+
+
+@pytest.mark.skipif(os.environ.get("BWTC_TEST_1GIB") != "1", reason="set BWTC_TEST_1GIB=1 (takes minutes)")
+def test_baseline_1GiB_single_block(oracle):
+    """BASELINE.json config 5: one 1 GiB block, 32-bit indices, N = 2^30 + 1."""
+    from bwtc_amd import hip
+    size = 1 << 30
+    d = synth.gen_dna(size, 5)
+    with hip.Context(0, size) as ctx:
+        bwt, lf, freqs = ctx.bwt_block(d, 8)
+    assert (freqs == np.bincount(d, minlength=256)).all()
+    rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
+    assert rc == 0
+    assert hashlib.sha256(inv.tobytes()).digest() == hashlib.sha256(d.tobytes()).digest()
