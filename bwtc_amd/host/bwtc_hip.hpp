@@ -1,0 +1,365 @@
+// Host-side C++ mirror of the reference's operator surface for the hot path, on top of the
+// C ABI (include/bwtc_hip.h).  Same class and method names, argument meaning and error
+// behaviour as pjmikkol/bwtc so that call sites and tests read like the reference's:
+//
+//   BWTBlock            BWTBlock.hpp:39-72, BWTBlock.cpp:61-108
+//   OutStream           Streams.hpp:42-50   (+ MemoryOutStream = test/TestStreams.hpp:38-125,
+//                                              RawOutStream = Streams.hpp:66-101)
+//   BWTransform         bwtransforms/BWTransform.hpp:48-70, BWTransform.cpp:38-76
+//   HipBWTransform      the new back-end (what INTEGRATION.md adds to the reference), 'g'
+//   BWTManager          bwtransforms/BWTManager.hpp:41-58, BWTManager.cpp:36-80
+//   EntropyEncoder      EntropyCoders.hpp:44-66, EntropyCoders.cpp:38-51
+//   HuffmanEncoder      HuffmanCoders.hpp, HuffmanCoders.cpp:46-61
+//   Compressor          Compressor.hpp:76-117, Compressor.cpp:36-118
+//
+// There is NO CPU back-end here: 'd'/'s' are rejected, the GPU library is the only
+// transformer, and every failure of the library is fatal (the reference exits on I/O errors
+// too, Streams.cpp:51-55).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bwtc_hip.h"
+
+namespace bwtc {
+
+typedef uint8_t byte;
+typedef uint32_t uint32;
+typedef uint64_t uint64;
+
+inline void hipFatal(int rc, const char* what) {
+  if (rc != 0) {
+    std::fprintf(stderr, "bwtc-hip: %s failed with code %d\n", what, rc);
+    std::exit(1);
+  }
+}
+
+// ---- streams ---------------------------------------------------------------------------
+class OutStream {
+ public:
+  virtual ~OutStream() {}
+  virtual void writeByte(byte b) = 0;
+  virtual void writeBlock(const byte* begin, const byte* end) = 0;
+  virtual long int getPos() = 0;
+  virtual void write48bits(uint64 to_written, long int position) = 0;
+  virtual void flush() = 0;
+};
+
+class MemoryOutStream : public OutStream {
+ public:
+  std::vector<byte> data;
+  void writeByte(byte b) { data.push_back(b); }
+  void writeBlock(const byte* begin, const byte* end) { data.insert(data.end(), begin, end); }
+  long int getPos() { return (long int)data.size(); }
+  void write48bits(uint64 v, long int position) {
+    for (int i = 0; i < 6; ++i) data[position + i] = (byte)(v >> (8 * (5 - i)));
+  }
+  void flush() {}
+};
+
+class RawOutStream : public OutStream {
+ public:
+  explicit RawOutStream(const std::string& file) : m_to(0), m_own(true), m_pos(0) {
+    m_to = file.empty() ? stdout : std::fopen(file.c_str(), "wb");
+    m_own = !file.empty();
+    if (!m_to) { std::perror(file.c_str()); std::exit(1); }     // Streams.cpp:51-55
+  }
+  ~RawOutStream() { if (m_to) { std::fflush(m_to); if (m_own) std::fclose(m_to); } }
+  void writeByte(byte b) { std::fputc(b, m_to); ++m_pos; }
+  void writeBlock(const byte* begin, const byte* end) {
+    std::fwrite(begin, 1, end - begin, m_to);
+    m_pos += end - begin;
+  }
+  long int getPos() { return m_pos; }
+  void write48bits(uint64 v, long int position) {               // Streams.cpp:106-117
+    std::fflush(m_to);
+    std::fseek(m_to, position, SEEK_SET);
+    for (int i = 0; i < 6; ++i) std::fputc((int)((v >> (8 * (5 - i))) & 0xff), m_to);
+    std::fseek(m_to, 0, SEEK_END);
+  }
+  void flush() { std::fflush(m_to); }
+ private:
+  FILE* m_to;
+  bool m_own;
+  long int m_pos;
+};
+
+class InStream {
+ public:
+  virtual ~InStream() {}
+  virtual size_t readBlock(byte* to, size_t max_block_size) = 0;
+};
+
+class MemoryInStream : public InStream {
+ public:
+  MemoryInStream(const byte* p, size_t n) : m_p(p), m_n(n), m_pos(0) {}
+  size_t readBlock(byte* to, size_t max) {
+    const size_t k = std::min(max, m_n - m_pos);
+    std::copy(m_p + m_pos, m_p + m_pos + k, to);
+    m_pos += k;
+    return k;
+  }
+ private:
+  const byte* m_p; size_t m_n, m_pos;
+};
+
+class RawInStream : public InStream {
+ public:
+  explicit RawInStream(const std::string& file) {
+    m_from = file.empty() ? stdin : std::fopen(file.c_str(), "rb");
+    m_own = !file.empty();
+    if (!m_from) { std::perror(file.c_str()); std::exit(1); }
+  }
+  ~RawInStream() { if (m_own && m_from) std::fclose(m_from); }
+  size_t readBlock(byte* to, size_t max) { return std::fread(to, 1, max, m_from); }
+ private:
+  FILE* m_from; bool m_own;
+};
+
+// ---- BWTBlock ----------------------------------------------------------------------------
+class BWTBlock {
+ public:
+  BWTBlock() : m_begin(0), m_length(0), m_isTransformed(true) {}
+  BWTBlock(byte* data, uint32 length, bool isTransformed)
+      : m_begin(data), m_length(length), m_isTransformed(isTransformed) {}
+  void setTransformed(bool t) { assert(m_isTransformed != t); m_isTransformed = t; }
+  bool isTransformed() const { return m_isTransformed; }
+  size_t size() const { return m_length; }
+  byte* begin() { return m_begin; }
+  const byte* begin() const { return m_begin; }
+  byte* end() { return m_begin + m_length; }
+  std::vector<uint32>& LFpowers() { return m_LFpowers; }
+  const std::vector<uint32>& LFpowers() const { return m_LFpowers; }
+  void setBegin(byte* b) { m_begin = b; }
+  void setSize(uint32 n) { m_length = n; }
+  void prepareLFpowers(uint32 startingPoints) {                 // BWTBlock.cpp:104-108
+    if (m_length <= 256 || startingPoints == 0) m_LFpowers.resize(1);
+    else if (startingPoints <= 256) m_LFpowers.resize(startingPoints);
+    else m_LFpowers.resize(256);
+  }
+  size_t writeHeader(OutStream* out) const {                    // BWTBlock.cpp:61-86
+    std::vector<byte> h(2048);
+    const uint32 n = bwtc_hip_host_bwtblock_header(&m_LFpowers[0], (uint32)m_LFpowers.size(),
+                                                   &h[0], (uint32)h.size());
+    out->writeBlock(&h[0], &h[0] + n);
+    return n;
+  }
+ private:
+  byte* m_begin;
+  uint32 m_length;
+  std::vector<uint32> m_LFpowers;
+  bool m_isTransformed;
+};
+
+// ---- transforms --------------------------------------------------------------------------
+class BWTransform {
+ public:
+  BWTransform() {}
+  virtual ~BWTransform() {}
+  virtual void doTransform(byte* begin, uint32 length, std::vector<uint32>& LF) const = 0;
+  virtual void doTransform(byte* begin, uint32 length, std::vector<uint32>& LF,
+                           uint32 freqs[256]) const = 0;
+  // block wrappers, BWTransform.cpp:38-64
+  virtual void doTransform(BWTBlock& block) {
+    std::reverse(block.begin(), block.end());
+    byte next = *block.end();
+    *block.end() = 0;
+    doTransform(block.begin(), (uint32)block.size() + 1, block.LFpowers());
+    block.setTransformed(true);
+    *(block.begin() + block.LFpowers()[0]) = *block.end();
+    *block.end() = next;
+  }
+  virtual void doTransform(BWTBlock& block, uint32 freqs[256]) {
+    std::reverse(block.begin(), block.end());
+    byte next = *block.end();
+    *block.end() = 0;
+    doTransform(block.begin(), (uint32)block.size() + 1, block.LFpowers(), freqs);
+    block.setTransformed(true);
+    *(block.begin() + block.LFpowers()[0]) = *block.end();
+    *block.end() = next;
+  }
+  virtual uint64 maxSizeInBytes(uint64 block_size) const = 0;
+  virtual uint64 maxBlockSize(uint64 memory_budget) const = 0;
+  virtual uint64 suggestedBlockSize(uint64 memory_budget) const = 0;
+ private:
+  BWTransform(const BWTransform&);
+  const BWTransform& operator=(const BWTransform&);
+};
+
+// The MI355X back-end.  One context (= one GPU, one stream, one persistent HBM workspace).
+class HipBWTransform : public BWTransform {
+ public:
+  explicit HipBWTransform(uint32 maxBlockSize, int device = 0) : m_ctx(0) {
+    hipFatal(bwtc_hip_create(device, maxBlockSize, &m_ctx), "bwtc_hip_create");
+  }
+  virtual ~HipBWTransform() { bwtc_hip_destroy(m_ctx); }
+  void doTransform(byte* begin, uint32 length, std::vector<uint32>& LF) const {
+    hipFatal(bwtc_hip_bwt(m_ctx, begin, length, &LF[0], (uint32)LF.size(), 0), "bwtc_hip_bwt");
+  }
+  void doTransform(byte* begin, uint32 length, std::vector<uint32>& LF, uint32 freqs[256]) const {
+    hipFatal(bwtc_hip_bwt(m_ctx, begin, length, &LF[0], (uint32)LF.size(), freqs), "bwtc_hip_bwt");
+  }
+  // whole block on the device: reverse, sentinel, transform, end-of-block patch; the byte at
+  // *block.end() is never touched, so neighbouring slices may be in flight on other GPUs
+  void doTransform(BWTBlock& block) {
+    hipFatal(bwtc_hip_bwt_block(m_ctx, block.begin(), (uint32)block.size(), &block.LFpowers()[0],
+                                (uint32)block.LFpowers().size(), 0), "bwtc_hip_bwt_block");
+    block.setTransformed(true);
+  }
+  void doTransform(BWTBlock& block, uint32 freqs[256]) {
+    hipFatal(bwtc_hip_bwt_block(m_ctx, block.begin(), (uint32)block.size(), &block.LFpowers()[0],
+                                (uint32)block.LFpowers().size(), freqs), "bwtc_hip_bwt_block");
+    block.setTransformed(true);
+  }
+  uint64 maxSizeInBytes(uint64 n) const { return bwtc_hip_workspace_bytes((uint32)n); }
+  uint64 maxBlockSize(uint64) const { return 0x7fffffffu - 2; }
+  uint64 suggestedBlockSize(uint64) const { return 256u << 20; }
+  bwtc_hip_ctx* context() const { return m_ctx; }
+ private:
+  bwtc_hip_ctx* m_ctx;
+};
+
+class BWTManager {
+ public:
+  BWTManager() : m_startingPoints(1), m_maxBlock(1u << 20), m_device(0) {}
+  explicit BWTManager(uint32 startingPoints) : m_startingPoints(startingPoints), m_maxBlock(1u << 20), m_device(0) {}
+  ~BWTManager() { for (size_t i = 0; i < m_transformers.size(); ++i) delete m_transformers[i]; }
+  void doTransform(BWTBlock& block) {                            // BWTManager.cpp:46-51
+    assert(!block.isTransformed());
+    block.prepareLFpowers(m_startingPoints);
+    m_transformers[0]->doTransform(block);
+  }
+  void doTransform(BWTBlock& block, uint32* freqs) {             // BWTManager.cpp:53-58
+    assert(!block.isTransformed());
+    block.prepareLFpowers(m_startingPoints);
+    m_transformers[0]->doTransform(block, freqs);
+  }
+  // maxBlockSize / device are what the GPU back-end needs to size its workspace
+  void setMaxBlockSize(uint32 n) { m_maxBlock = n; }
+  void setDevice(int d) { m_device = d; }
+  void initialize(char choice) {                                 // BWTManager.cpp:74-80
+    if (!isValidChoice(choice)) {
+      std::fprintf(stderr, "bwtc-hip: BWT algorithm '%c' is not available (only 'g')\n", choice);
+      std::exit(1);
+    }
+    m_transformers.push_back(new HipBWTransform(m_maxBlock, m_device));
+  }
+  void setStartingPoints(uint32 sp) {                            // BWTManager.cpp:60-64
+    if (sp < 1) sp = 1; else if (sp > 256) sp = 256;
+    m_startingPoints = sp;
+  }
+  uint32 getStartingPoints() const { return m_startingPoints; }
+  static bool isValidChoice(char c) { return c == 'g' || c == 'a'; }
+  bwtc_hip_ctx* hipContext() const {
+    return static_cast<HipBWTransform*>(m_transformers[0])->context();
+  }
+ private:
+  std::vector<BWTransform*> m_transformers;
+  uint32 m_startingPoints, m_maxBlock;
+  int m_device;
+};
+
+// ---- entropy coding ------------------------------------------------------------------------
+class EntropyEncoder {
+ public:
+  virtual ~EntropyEncoder() {}
+  virtual size_t transformAndEncode(BWTBlock& block, BWTManager& bwtm, OutStream* out) = 0;
+};
+
+class HuffmanEncoder : public EntropyEncoder {
+ public:
+  HuffmanEncoder() {}
+  // HuffmanCoders.cpp:51-61: transform, writeBlockHeader, encodeData, finishBlock -- all in
+  // one library call; the record already carries its 48-bit length.
+  size_t transformAndEncode(BWTBlock& block, BWTManager& bwtm, OutStream* out) {
+    assert(!block.isTransformed());
+    m_record.resize(bwtc_hip_compress_bound((uint32)block.size()));
+    uint64_t n = 0;
+    hipFatal(bwtc_hip_transform_and_encode(bwtm.hipContext(), block.begin(), (uint32)block.size(),
+                                           bwtm.getStartingPoints(), &m_record[0], m_record.size(),
+                                           &n), "bwtc_hip_transform_and_encode");
+    block.setTransformed(true);
+    out->writeBlock(&m_record[0], &m_record[0] + n);
+    return (size_t)n;
+  }
+ private:
+  std::vector<byte> m_record;
+};
+
+inline EntropyEncoder* giveEntropyEncoder(char encoder) {        // EntropyCoders.cpp:38-51
+  if (encoder == 'H') return new HuffmanEncoder();
+  std::fprintf(stderr, "bwtc-hip: entropy coder '%c' is not built yet (only 'H')\n", encoder);
+  std::exit(1);
+}
+
+// ---- Compressor ----------------------------------------------------------------------------
+struct Options {                                                  // Compressor.hpp:40-48
+  Options(size_t memLimit_, char entropyCoder_) : memLimit(memLimit_), entropyCoder(entropyCoder_) {}
+  size_t memLimit;
+  char entropyCoder;
+};
+
+namespace detail {
+inline size_t writePacked(uint64 v, OutStream* out) {             // utils::packInteger
+  size_t n = 0;
+  do { byte b = (byte)(v & 0x7F); v >>= 7; if (v) b |= 0x80; out->writeByte(b); ++n; } while (v);
+  return n;
+}
+}  // namespace detail
+
+class Compressor {
+ public:
+  // takes ownership of the streams, like the reference (Compressor.cpp:49-53)
+  Compressor(InStream* in, OutStream* out, size_t memLimit, char entropyCoder)
+      : m_in(in), m_out(out), m_coder(giveEntropyEncoder(entropyCoder)),
+        m_options(memLimit, entropyCoder) {}
+  ~Compressor() { delete m_in; delete m_out; delete m_coder; }
+
+  size_t bwtBlockSize() const {                                   // Compressor.cpp:77-79
+    return std::min(static_cast<size_t>(m_options.memLimit * 0.185),
+                    static_cast<size_t>(0x7fffffff - 1));
+  }
+  void initializeBwtAlgorithm(char choice, uint32 startingPoints, int device = 0) {
+    m_bwtmanager.setMaxBlockSize((uint32)bwtBlockSize());
+    m_bwtmanager.setDevice(device);
+    m_bwtmanager.initialize(choice);                              // Compressor.cpp:60-63
+    m_bwtmanager.setStartingPoints(startingPoints);
+  }
+  size_t writeGlobalHeader() { m_out->writeByte((byte)m_options.entropyCoder); return 1; }
+
+  // Compressor.cpp:65-118 with no precompression: every read of bwtBlockSize bytes is one
+  // precompressor block holding one BWT block (pbBlockSize == bwtBlockSize, :81).
+  size_t compress(size_t threads) {
+    if (threads != 1) { std::fprintf(stderr, "Supporting only single thread!\n"); return 0; }
+    size_t compressedSize = writeGlobalHeader();
+    const size_t bs = bwtBlockSize();
+    std::vector<byte> buf(bs + 1);
+    for (;;) {
+      const size_t got = m_in->readBlock(&buf[0], bs);
+      if (got == 0) break;
+      compressedSize += detail::writePacked(got, m_out);          // PrecompressorBlock.cpp:64-90
+      compressedSize += detail::writePacked(1, m_out);
+      m_out->writeByte(0); ++compressedSize;                      // empty grammar
+      BWTBlock block(&buf[0], (uint32)got, false);
+      compressedSize += m_coder->transformAndEncode(block, m_bwtmanager, m_out);
+    }
+    m_out->writeByte(0); ++compressedSize;                        // writeEmptyHeader, :115
+    m_out->flush();
+    return compressedSize;
+  }
+  OutStream* out() { return m_out; }
+ private:
+  InStream* m_in;
+  OutStream* m_out;
+  EntropyEncoder* m_coder;
+  BWTManager m_bwtmanager;
+  Options m_options;
+};
+
+}  // namespace bwtc

@@ -1,0 +1,70 @@
+// compress -- command-line front end with the reference's flag surface (compress.cpp:107-145)
+// on top of the MI355X back-end.  Output files decode with the reference's `uncompress`.
+//
+//   compress [options] [input] [output]
+//     -m, --mem MB       memory budget; BWT block = 0.185 * MB * 1e6 bytes   (default 100)
+//     -s, --starts N     starting points for the inverse transform, 1..256    (default 8)
+//         --bwt C        BWT algorithm: g (GPU) or a (auto = g)              (default a)
+//     -e, --enc C        entropy coder: H (Huffman)                          (default H)
+//     -i, --stdin        read from standard input
+//     -c, --stdout       write to standard output
+//     -d, --device N     GPU to use                                          (default 0)
+//     -v, --verb N       verbosity
+// Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc B/b/m/M/u
+// (wavelet coders) are rejected, --prepr is not offered.
+#include <getopt.h>
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "bwtc_hip.hpp"
+
+int main(int argc, char** argv) {
+  size_t mem = 100;
+  unsigned starts = 8;
+  char bwt = 'a', enc = 'H';
+  bool from_stdin = false, to_stdout = false;
+  int verbosity = 0, device = 0;
+  static option longopts[] = {{"mem", required_argument, 0, 'm'},   {"starts", required_argument, 0, 's'},
+                              {"bwt", required_argument, 0, 'b'},   {"enc", required_argument, 0, 'e'},
+                              {"stdin", no_argument, 0, 'i'},       {"stdout", no_argument, 0, 'c'},
+                              {"device", required_argument, 0, 'd'}, {"verb", required_argument, 0, 'v'},
+                              {"help", no_argument, 0, 'h'},        {0, 0, 0, 0}};
+  int o;
+  while ((o = getopt_long(argc, argv, "m:s:e:icd:v:h", longopts, 0)) != -1) {
+    switch (o) {
+      case 'm': mem = std::strtoul(optarg, 0, 10); break;
+      case 's': starts = (unsigned)std::strtoul(optarg, 0, 10); break;
+      case 'b': bwt = optarg[0]; break;
+      case 'e': enc = optarg[0]; break;
+      case 'i': from_stdin = true; break;
+      case 'c': to_stdout = true; break;
+      case 'd': device = std::atoi(optarg); break;
+      case 'v': verbosity = std::atoi(optarg); break;
+      default:
+        std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e H] [-i] [-c] [input] [output]\n");
+        return o == 'h' ? 0 : 1;
+    }
+  }
+  if (!bwtc::BWTManager::isValidChoice(bwt)) {                    // compress.cpp:86-96
+    std::fprintf(stderr, "Invalid choice for BWT-algorithm: %c (this build offers g)\n", bwt);
+    return 1;
+  }
+  if (mem < 1) mem = 1;
+  std::string in_name, out_name;
+  if (!from_stdin && optind < argc) in_name = argv[optind++];
+  if (!to_stdout) {
+    if (optind < argc) out_name = argv[optind++];
+    else if (!in_name.empty()) out_name = in_name + ".bwtc";
+  }
+  if (!from_stdin && in_name.empty()) { std::fprintf(stderr, "no input\n"); return 1; }
+
+  const auto t0 = std::chrono::steady_clock::now();
+  bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name),
+                              mem * 1000000, enc);                // compress.cpp:192-193
+  compressor.initializeBwtAlgorithm(bwt, starts, device);
+  const size_t compressed = compressor.compress(1);
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (verbosity > 0) std::fprintf(stderr, "Compressed size: %zu bytes, %.3f s\n", compressed, s);
+  return 0;
+}

@@ -1,0 +1,104 @@
+// GPU test program for the C++ host mirror (bwtc_amd/host/bwtc_hip.hpp), shaped after the
+// reference's own tests:
+//   raw transform + inverse on random data      test/InverseBwtTest.cpp:51-114
+//   LF powers against an independently built SA  test/LFpowersTest.cpp:49-181 (via the oracle)
+//   Compressor -> decompressor round trips       test/CompressorAndDecompressorTest.cpp:61-205
+// TEST INFRASTRUCTURE: links the oracle (liboracle.so) as the checker / decoder.
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "bwtc_hip.hpp"
+#include "../../oracle/bwtc_oracle.h"
+
+using namespace bwtc;
+
+static int failures = 0;
+#define CHECK(c, ...) do { if (!(c)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+static std::vector<byte> randomData(std::mt19937& rng, size_t n, int sigma) {
+  std::vector<byte> d(n);
+  for (size_t i = 0; i < n; ++i) d[i] = (byte)(rng() % sigma);
+  return d;
+}
+static std::vector<byte> repetitiveData(std::mt19937& rng, size_t n) {   // :52-59
+  std::vector<byte> seed = randomData(rng, n / 40 + 1, 256), d;
+  while (d.size() < n) d.insert(d.end(), seed.begin(), seed.end());
+  d.resize(n);
+  return d;
+}
+
+static void testRawTransformAndInverse(std::mt19937& rng) {
+  HipBWTransform transform(1u << 20);
+  for (int round = 0; round < 12; ++round) {
+    const size_t n = 1 + rng() % 200000;
+    const int sigma = (round % 3 == 0) ? 4 : 256;
+    std::vector<byte> orig = randomData(rng, n, sigma);
+    std::vector<byte> t(orig.rbegin(), orig.rend());              // caller reverses ...
+    t.push_back(0);                                               // ... and plants the sentinel
+    const uint32 sp = (uint32)(1 + rng() % std::min<size_t>(256, n));
+    std::vector<uint32> LF(sp), LFo(sp);
+    uint32 freqs[256] = {0}, freqso[256] = {0};
+    std::vector<byte> o = t;
+    transform.doTransform(&t[0], (uint32)n + 1, LF, freqs);
+    orc_bwt_raw(&o[0], (uint32)n + 1, &LFo[0], sp, freqso);
+    CHECK(t == o, "raw transform bytes differ (n=%zu)", n);
+    CHECK(LF == LFo, "LF powers differ (n=%zu sp=%u)", n, sp);
+    CHECK(std::memcmp(freqs, freqso, sizeof freqs) == 0, "freqs differ");
+  }
+}
+
+static void testBlockTransformViaManager(std::mt19937& rng) {
+  BWTManager manager(8);
+  manager.setMaxBlockSize(1u << 20);
+  manager.initialize('g');
+  for (int round = 0; round < 8; ++round) {
+    const size_t n = 1 + rng() % 300000;
+    manager.setStartingPoints(1 + rng() % 300);
+    std::vector<byte> data = round % 2 ? repetitiveData(rng, n) : randomData(rng, n, 256);
+    std::vector<byte> buf(data);
+    buf.push_back(0xEE);
+    BWTBlock block(&buf[0], (uint32)n, false);
+    uint32 freqs[256] = {0};
+    manager.doTransform(block, freqs);
+    CHECK(block.isTransformed(), "block not marked transformed");
+    CHECK(buf[n] == 0xEE, "byte after the block was modified");
+    std::vector<byte> inv(buf.begin(), buf.begin() + n);
+    const int rc = orc_inverse_bwt_block(&inv[0], (uint32)n, &block.LFpowers()[0], (uint32)block.LFpowers().size());
+    CHECK(rc == 0, "inverse failed rc=%d", rc);
+    CHECK(inv == data, "inverse does not reproduce the input");
+  }
+}
+
+static void testCompressorRoundTrip(std::mt19937& rng) {
+  struct Case { size_t size, mem; unsigned sp; bool rep; };
+  const Case cases[] = {{100, 1000, 1, false},     {1000, 2000, 3, true},      {100000, 1000000, 8, false},
+                        {100000, 100000, 30, true}, {700000, 1000000, 8, true}, {3000000, 100000000, 16, false}};
+  for (const Case& c : cases) {
+    std::vector<byte> data = c.rep ? repetitiveData(rng, c.size) : randomData(rng, c.size, 256);
+    MemoryOutStream* out = new MemoryOutStream();
+    Compressor compressor(new MemoryInStream(&data[0], data.size()), out, c.mem, 'H');
+    compressor.initializeBwtAlgorithm('g', c.sp);
+    const size_t reported = compressor.compress(1);
+    CHECK(reported == out->data.size(), "compress() returned %zu, stream holds %zu", reported, out->data.size());
+    // the oracle's own compressor must produce the very same stream ...
+    std::vector<byte> want(orc_compress_bound(data.size()) + 100000 * 8);
+    const size_t wn = orc_compress_H(&data[0], data.size(), compressor.bwtBlockSize(), c.sp, &want[0], want.size());
+    CHECK(wn == out->data.size() && std::memcmp(&want[0], &out->data[0], wn) == 0,
+          "stream differs from the oracle's (size %zu mem %zu)", c.size, c.mem);
+    // ... and decode back to the input
+    std::vector<byte> back(data.size() + 16);
+    const size_t bn = orc_decompress_H(&out->data[0], out->data.size(), &back[0], back.size());
+    CHECK(bn == data.size() && std::memcmp(&back[0], &data[0], bn) == 0, "round trip failed (size %zu)", c.size);
+  }
+}
+
+int main() {
+  std::mt19937 rng(12345);
+  testRawTransformAndInverse(rng);
+  testBlockTransformViaManager(rng);
+  testCompressorRoundTrip(rng);
+  std::printf(failures ? "%d FAILURES\n" : "host mirror: all tests passed\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,44 @@
+"""GPU tests of the C++ host mirror (bwtc_amd/host): the C++ test program shaped after the
+reference's InverseBwtTest / LFpowersTest / CompressorAndDecompressorTest, and the `compress`
+command line tool, whose output must decode (here: with the oracle's decoder) to the input."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bwtc_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_mirror_program():
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+    assert os.path.exists(exe), "build with __graft_entry__.build() / make -C bwtc_amd/host"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    assert "all tests passed" in r.stdout
+
+
+def test_compress_cli_roundtrip(tmp_path, oracle):
+    exe = os.path.join(ROOT, "bwtc_amd", "host", "compress")
+    assert os.path.exists(exe)
+    data = np.concatenate([synth.gen_text(3_000_000, 3), synth.gen_random_bytes(500_000, 1),
+                           np.zeros(100_000, np.uint8)])
+    src = tmp_path / "input.bin"
+    dst = tmp_path / "input.bin.bwtc"
+    src.write_bytes(data.tobytes())
+    # --mem 10 -> BWT blocks of 1.85 MB -> two blocks
+    r = subprocess.run([exe, "-m", "10", "-s", "8", "--bwt", "g", "-e", "H", "-v", "1", str(src), str(dst)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    stream = np.frombuffer(dst.read_bytes(), np.uint8)
+    assert stream[0] == ord("H")
+    back = oracle.oracle_decompress_H(stream, data.size + 8)
+    assert back is not None and back.tobytes() == data.tobytes()
+    assert stream.tobytes() == oracle.oracle_compress_H(data, int(10 * 1000000 * 0.185), 8).tobytes()
+    # rejected choices, as the reference's validators do (compress.cpp:86-96)
+    r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
+    assert r.returncode != 0
