@@ -3,6 +3,7 @@
 #include "radix_sort.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace bwtc_hip {
@@ -399,7 +400,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, total;
+      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -427,6 +428,7 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_small = take(1024 * 4);
   a.off_ent = take(2u << 20);
   a.off_comp = take(huffman_compress_bound(cap));
+  a.off_sweep = take(SweepWs::small_words() * 4);
   a.total = o;
   return a;
 }
@@ -464,6 +466,11 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_small = reinterpret_cast<u32*>(base + a.off_small);
   d_ent = base + a.off_ent;
   d_comp = base + a.off_comp;
+  d_sweep = reinterpret_cast<u32*>(base + a.off_sweep);
+  {
+    const char* e = std::getenv("BWTC_HIP_SORT");
+    use_sweep = e && std::strcmp(e, "sweep") == 0;
+  }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
   BWTC_HIP_TRY(hipEventCreate(&ev_begin));
@@ -519,6 +526,26 @@ static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
   return p;
 }
 
+static constexpr int kSmallError = 522;   // sticky error word of the chained sort
+
+template <typename K>
+void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
+                           bool probe_it, int bit_lo) {
+  if (use_sweep) {
+    SweepWs ws;
+    ws.hist_all = d_sweep;
+    ws.bases = d_sweep + kSweepMaxPasses * kChains * kRadixBins;
+    ws.tickets = d_sweep + 2 * kSweepMaxPasses * kChains * kRadixBins;
+    ws.status = d_table;
+    ws.error = d_small + kSmallError;
+    radix_sort_pairs_sweep<K>(k0, k1, v0, v1, n, nbits, ws, stream, ks, vs, probe_it ? &probe : nullptr,
+                              bit_lo);
+  } else {
+    radix_sort_pairs<K>(k0, k1, v0, v1, n, nbits, d_table, d_partial, stream, ks, vs,
+                        probe_it ? &probe : nullptr, bit_lo);
+  }
+}
+
 // rank[pairs_s[i]] = pairs_r[i] for i < m, made cache-friendly: the pairs (two arrays of
 // `cap` words inside one 8*cap-byte region) are first partitioned by the top 16 bits of the
 // destination with two stable radix passes (tmp = another 8*cap-byte region), after which
@@ -531,8 +558,7 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
   const int lo = bits > 16 ? bits - 16 : 0;
   u32 *ws = pairs, *wr = pairs + cap;
   if (m >= kPairsMin && bits > 12)
-    radix_sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, d_table, d_partial, st, &ws,
-                          &wr, nullptr, lo);
+    sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, &ws, &wr, false, lo);
   hipLaunchKernelGGL(k_scatter_pairs, dim3((ceil_div(m, 256 * kSimpleE) + 7u) / 8u * 8u), dim3(256), 0, st,
                      d_rank, ws, wr, m);
 }
@@ -569,7 +595,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
                        d_V0, n, plan.k, plan.w);
     u64* ks = nullptr; u32* vs = nullptr;
-    radix_sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, d_table, d_partial, st, &ks, &vs, &probe);
+    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     aidx = (vs == d_V0) ? d_V1 : d_V0;
     aidx_other = vs;
@@ -588,7 +614,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
                        d_V0, n, plan.k, plan.w);
     u32* ks = nullptr; u32* vs = nullptr;
-    radix_sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, d_table, d_partial, st, &ks, &vs, &probe);
+    sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     aidx = (vs == d_V0) ? d_V1 : d_V0;
     aidx_other = vs;
@@ -603,8 +629,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     scatter_rank_pairs(pairs, static_cast<u32*>(d_R1), n, n);
   }
   stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
-  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipStreamSynchronize(st));
+  if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
   u32 m = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
 
   u64* K64a = static_cast<u64*>(d_R1);
@@ -623,8 +650,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     const int nbits = b1 + b2;
     const bool timed = n_sort_events + 2 <= kMaxSortEvents;
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    radix_sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, d_table, d_partial, st, &k64s,
-                          &v64s, &probe);
+    sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, &k64s, &v64s, true);
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     stats.sort_pass_items += (u64)m * (u64)((nbits + kRadixBits - 1) / kRadixBits);
     u32* next_aidx = (v64s == aidx) ? aidx_other : aidx;
@@ -644,8 +670,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
                          v64s, aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx,
                          aglob_other, d_GRP, (u32*)nullptr, (u32*)nullptr);
     }
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 8, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipStreamSynchronize(st));
+    if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
     m = h_small[kSmallCounts];
     groups = h_small[kSmallCounts + 1];
     aidx_other = v64s;

@@ -47,6 +47,9 @@ struct BwtEngine {
   u32* d_aggA = nullptr;   // rerank tile aggregates
   u32* d_aggB = nullptr;
   u32* d_aggC = nullptr;
+  u32* d_sweep = nullptr;  // chained radix sort: histograms, bases, tickets (SweepWs::small_words)
+  bool use_sweep = false;  // BWTC_HIP_SORT=sweep selects the chained single-read passes (measured
+                           // slower on MI355X than the XCD-contiguous three-kernel passes)
   u8* d_comp = nullptr;    // compressed-block staging, huffman_compress_bound(max_block)
   u8* d_ent = nullptr;     // 2 MiB of small tables for the entropy front-end
   u32* d_small = nullptr;  // [0..255] freqs, [256..511] lf, [512] pidx, [520..521] counts
@@ -69,6 +72,10 @@ struct BwtEngine {
   // its inverse.  d_T must be followed by >= 8 zero bytes.
   // hist = byte histogram of d_T[0..n-1] (drives the width of the initial sort key).
   int suffix_sort(u32 n, const u32* hist, bool lone_sentinel);
+  // radix sort front door: picks the chained single-read passes or the classic ones
+  template <typename K>
+  void sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
+                  bool probe_it, int bit_lo = 0);
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
   // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).

@@ -24,10 +24,13 @@ static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int
   BWTC_HIP_TRY(hipMemcpyAsync(k0, keys, n * sizeof(K), hipMemcpyHostToDevice, e.stream));
   BWTC_HIP_TRY(hipMemcpyAsync(e.d_V0, vals, n * 4, hipMemcpyHostToDevice, e.stream));
   K* ks; u32* vs;
-  radix_sort_pairs<K>(k0, k1, e.d_V0, e.d_V1, n, nbits, e.d_table, e.d_partial, e.stream, &ks, &vs);
+  BWTC_HIP_TRY(hipMemsetAsync(e.d_small, 0, 1024 * 4, e.stream));
+  e.sort_pairs<K>(k0, k1, e.d_V0, e.d_V1, n, nbits, &ks, &vs, false);
   BWTC_HIP_TRY(hipMemcpyAsync(keys, ks, n * sizeof(K), hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(hipMemcpyAsync(vals, vs, n * 4, hipMemcpyDeviceToHost, e.stream));
+  BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 522, e.d_small + 522, 4, hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  if (e.h_small[522]) return -3;
   BWTC_HIP_TRY(hipGetLastError());
   return 0;
 }

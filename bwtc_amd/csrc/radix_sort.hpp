@@ -232,4 +232,271 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
   *v_sorted = vin;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Chained single-read variant ("sweep"): no per-pass histogram kernel.
+//
+// One kernel reads the keys once and builds the global digit histogram of every pass (the
+// multiset of keys does not change between passes); k_radix_bases turns them into the
+// global base of every digit.  The pass kernel then ranks a tile exactly like
+// k_radix_scatter, publishes its 256 digit counts, and gets the counts of all earlier tiles
+// by decoupled look-back over per-(tile, digit) status words (2 flag bits + 30-bit value,
+// relaxed agent-scope atomics, one word = one granule).
+//
+// Progress: tiles are handed out by a ticket counter, so every tile a workgroup waits for
+// was claimed by a workgroup that is already resident, and the lowest unfinished tile never
+// waits; nothing depends on dispatch order or XCD placement.  (Per-XCD chains would keep the
+// output seams in one L2, but the per-chain digit bases change with every pass and would
+// need the histogram pass back.)  Every spin is bounded: on timeout the tile publishes an
+// error word, raises *error and writes nothing; waiters that read the error word do the same.
+// ---------------------------------------------------------------------------------------
+constexpr int kChains = 1;
+constexpr int kSweepMaxPasses = 8;
+constexpr u32 kStAgg = 1u << 30, kStIncl = 2u << 30, kStErr = 3u << 30, kStMask = (1u << 30) - 1u;
+constexpr u32 kSweepSpinLimit = 1u << 22;
+
+struct SweepWs {
+  u32* hist_all;   // [kSweepMaxPasses][kChains][256]
+  u32* bases;      // [kSweepMaxPasses][kChains][256]
+  u32* tickets;    // [kSweepMaxPasses][kChains]
+  u32* status;     // [ntiles][256]
+  u32* error;      // 1 word, sticky
+  static constexpr u64 small_words() { return 2ull * kSweepMaxPasses * kChains * 256 + kSweepMaxPasses * kChains + 64; }
+};
+
+template <typename K>
+__global__ __launch_bounds__(kRadixTPB) void k_radix_hist_all(const K* __restrict__ keys, u64 n,
+                                                              int bit_lo, int npasses,
+                                                              u32 tiles_per_chain, u32 ntiles,
+                                                              u32* __restrict__ hist_all) {
+  constexpr int E = RadixCfg<K>::E;
+  constexpr int TILE = kRadixTPB * E;
+  __shared__ u32 hist[kSweepMaxPasses][kRadixBins][4];      // 4 interleaved copies per bin
+  for (u32 i = threadIdx.x; i < kSweepMaxPasses * kRadixBins * 4; i += kRadixTPB) (&hist[0][0][0])[i] = 0;
+  __syncthreads();
+  const u32 chain = blockIdx.x % kChains;
+  const u32 nper = gridDim.x / kChains;
+  const u32 first = chain * tiles_per_chain;
+  const u32 last = min(first + tiles_per_chain, ntiles);
+  const u32 copy = threadIdx.x & 3u;
+  for (u32 tile = first + blockIdx.x / kChains; tile < last; tile += nper) {
+    const u64 base = (u64)tile * TILE + threadIdx.x;
+    K k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const u64 i = base + (u64)e * kRadixTPB; k[e] = i < n ? keys[i] : (K)0; }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (base + (u64)e * kRadixTPB < n) {
+        for (int p = 0; p < npasses; ++p)
+          atomicAdd(&hist[p][radix_digit(k[e], bit_lo + p * kRadixBits)][copy], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < (u32)npasses * kRadixBins; i += kRadixTPB) {
+    const u32 p = i / kRadixBins, d = i % kRadixBins;
+    const u32 c = hist[p][d][0] + hist[p][d][1] + hist[p][d][2] + hist[p][d][3];
+    if (c) atomicAdd(&hist_all[((u64)p * kChains + chain) * kRadixBins + d], c);
+  }
+}
+
+// grid = npasses blocks of 256: bases[p][c][d] = #keys with smaller digit + #keys with digit d
+// in earlier chains.
+static __global__ __launch_bounds__(kRadixBins) void k_radix_bases(const u32* __restrict__ hist_all,
+                                                                   u32* __restrict__ bases) {
+  __shared__ u32 scr[kRadixBins / kWave + 1];
+  const u32 p = blockIdx.x, d = threadIdx.x;
+  u32 total = 0;
+  for (int c = 0; c < kChains; ++c) total += hist_all[((u64)p * kChains + c) * kRadixBins + d];
+  u32 unused;
+  u32 run = block_scan_excl_add<kRadixBins>(total, scr, &unused);
+  for (int c = 0; c < kChains; ++c) {
+    bases[((u64)p * kChains + c) * kRadixBins + d] = run;
+    run += hist_all[((u64)p * kChains + c) * kRadixBins + d];
+  }
+}
+
+template <typename K>
+__global__ __launch_bounds__(kRadixTPB) void k_radix_sweep(
+    const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
+    u32* __restrict__ vout, u64 n, int shift, u32 ntiles, u32 tiles_per_chain,
+    const u32* __restrict__ bases, u32* __restrict__ status, u32* __restrict__ tickets,
+    u32* __restrict__ error) {
+  constexpr int E = RadixCfg<K>::E;
+  constexpr int TILE = kRadixTPB * E;
+  constexpr int kStageBytes = TILE * (int)(sizeof(K) + sizeof(u32));
+  constexpr int kCntBytes = kRadixWaves * kRadixBins * (int)sizeof(u32);
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStageBytes > kCntBytes ? kStageBytes : kCntBytes];
+  K* s_key = reinterpret_cast<K*>(s_raw);
+  u32* s_val = reinterpret_cast<u32*>(s_raw + TILE * sizeof(K));
+  u32 (*s_cnt)[kRadixBins] = reinterpret_cast<u32 (*)[kRadixBins]>(s_raw);
+  __shared__ u32 s_base[kRadixBins];
+  __shared__ u32 s_gofs[kRadixBins];
+  __shared__ u32 s_scr[kRadixTPB / kWave + 1];
+  __shared__ u32 s_claim[3];                       // chain (always 0 with one chain), ticket, abort
+
+  const u32 tid = threadIdx.x;
+  const u32 wave = tid / kWave, lane = tid % kWave;
+
+  if (tid == 0) {
+    u32 chain = 0xFFFFFFFFu, ticket = 0;
+    for (u32 k = 0; k < (u32)kChains; ++k) {
+      const u32 c = (blockIdx.x + k) % (u32)kChains;
+      const u32 cfirst = c * tiles_per_chain;
+      if (cfirst >= ntiles) continue;
+      const u32 ccount = min(tiles_per_chain, ntiles - cfirst);
+      const u32 t = atomicAdd(&tickets[c], 1u);
+      if (t < ccount) { chain = c; ticket = t; break; }
+    }
+    s_claim[0] = chain; s_claim[1] = ticket; s_claim[2] = 0;
+  }
+  for (u32 i = tid; i < kRadixWaves * kRadixBins; i += kRadixTPB) (&s_cnt[0][0])[i] = 0;
+  __syncthreads();
+  const u32 chain = s_claim[0], ticket = s_claim[1];
+  if (chain == 0xFFFFFFFFu) return;                // every tile already claimed
+  const u32 chain_first = chain * tiles_per_chain;
+  const u32 tile = chain_first + ticket;
+  const u64 tile_base = (u64)tile * TILE;
+  const u64 left = n - tile_base;
+  const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
+
+  const u32 wslot = wave * (kWave * E) + lane;
+  K k[E];
+  u32 v[E];
+  u32 r[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const u32 slot = wslot + e * kWave;
+    const bool ok = slot < tile_n;
+    k[e] = ok ? kin[tile_base + slot] : (K)0;
+    v[e] = ok ? vin[tile_base + slot] : 0u;
+  }
+
+  volatile u32* my_cnt = &s_cnt[wave][0];
+  const u64 lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const bool ok = (wslot + e * kWave) < tile_n;
+    const u32 d = radix_digit(k[e], shift);
+    const u64 m = match_any<kRadixBits>(d, ok);
+    u32 prev = 0;
+    if (ok) prev = my_cnt[d];
+    __builtin_amdgcn_wave_barrier();
+    r[e] = prev + (u32)__popcll(m & lt_mask);
+    if (ok && (m >> lane) == 1ull) my_cnt[d] = prev + (u32)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  u32 dig_total = 0;
+  if (tid < kRadixBins) {
+#pragma unroll
+    for (int w = 0; w < kRadixWaves; ++w) {
+      const u32 c = s_cnt[w][tid];
+      s_cnt[w][tid] = dig_total;
+      dig_total += c;
+    }
+  }
+  // publish this tile's digit counts, then look back along the chain
+  u32 excl = 0;
+  if (tid < kRadixBins) {
+    u32* my_status = status + (u64)tile * kRadixBins + tid;
+    if (ticket == 0) {
+      __hip_atomic_store(my_status, kStIncl | dig_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my_status, kStAgg | dig_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool bad = false;
+      u32 t = ticket;
+      while (t > 0) {
+        --t;
+        const u32* st = status + (u64)(chain_first + t) * kRadixBins + tid;
+        u32 val = 0, spins = 0;
+        for (;;) {
+          val = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (val >> 30) break;
+          if (++spins > kSweepSpinLimit) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        const u32 flag = val >> 30;
+        if (flag == 0 || flag == 3) { bad = true; break; }
+        excl += val & kStMask;
+        if (flag == 2) break;
+      }
+      if (bad) {
+        s_claim[2] = 1;
+        atomicOr(error, 1u);
+        __hip_atomic_store(my_status, kStErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_store(my_status, kStIncl | (excl + dig_total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  u32 unused;
+  const u32 dig_base = block_scan_excl_add<kRadixTPB>(tid < kRadixBins ? dig_total : 0u, s_scr, &unused);
+  if (tid < kRadixBins) {
+    s_base[tid] = dig_base;
+    s_gofs[tid] = bases[(u64)chain * kRadixBins + tid] + excl - dig_base;
+  }
+  __syncthreads();
+  if (s_claim[2]) return;                          // a look-back timed out: write nothing
+
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((wslot + e * kWave) < tile_n) {
+      const u32 d = radix_digit(k[e], shift);
+      r[e] += s_base[d] + s_cnt[wave][d];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((wslot + e * kWave) < tile_n) {
+      s_key[r[e]] = k[e];
+      s_val[r[e]] = v[e];
+    }
+  }
+  __syncthreads();
+  for (u32 i = tid; i < tile_n; i += kRadixTPB) {
+    const K kk = s_key[i];
+    const u32 dst = s_gofs[radix_digit(kk, shift)] + i;
+    kout[dst] = kk;
+    vout[dst] = s_val[i];
+  }
+}
+
+// Same contract as radix_sort_pairs; ws.status needs ntiles * 256 words.
+template <typename K>
+static inline void radix_sort_pairs_sweep(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
+                                          const SweepWs& ws, hipStream_t st, K** k_sorted,
+                                          u32** v_sorted, ScatterProbe* probe = nullptr,
+                                          int bit_lo = 0) {
+  K* kin = k0; K* kout = k1;
+  u32* vin = v0; u32* vout = v1;
+  const int npasses = (nbits - bit_lo + kRadixBits - 1) / kRadixBits;
+  if (n > 1 && npasses > 0) {
+    const u32 ntiles = ceil_div(n, radix_tile<K>());
+    const u32 per_chain = (ntiles + kChains - 1) / kChains;
+    (void)hipMemsetAsync(ws.hist_all, 0, (size_t)npasses * kChains * kRadixBins * 4, st);
+    (void)hipMemsetAsync(ws.tickets, 0, (size_t)kSweepMaxPasses * kChains * 4, st);
+    const u32 hist_blocks = kChains * (per_chain < 768u ? per_chain : 768u);
+    hipLaunchKernelGGL(k_radix_hist_all<K>, dim3(hist_blocks), dim3(kRadixTPB), 0, st, kin, n, bit_lo,
+                       npasses, per_chain, ntiles, ws.hist_all);
+    hipLaunchKernelGGL(k_radix_bases, dim3(npasses), dim3(kRadixBins), 0, st, ws.hist_all, ws.bases);
+    for (int p = 0; p < npasses; ++p) {
+      (void)hipMemsetAsync(ws.status, 0, (size_t)ntiles * kRadixBins * 4, st);
+      const bool timed = probe && probe->begin(st);
+      hipLaunchKernelGGL(k_radix_sweep<K>, dim3(((ntiles + 7u) / 8u) * 8u), dim3(kRadixTPB), 0, st,
+                         kin, vin, kout, vout, n, bit_lo + p * kRadixBits, ntiles, per_chain,
+                         ws.bases + (size_t)p * kChains * kRadixBins, ws.status,
+                         ws.tickets + p * kChains, ws.error);
+      if (timed) probe->end(st, n * 2 * (sizeof(K) + sizeof(u32)));
+      K* tk = kin; kin = kout; kout = tk;
+      u32* tv = vin; vin = vout; vout = tv;
+    }
+  }
+  *k_sorted = kin;
+  *v_sorted = vin;
+}
+
 }  // namespace bwtc_hip

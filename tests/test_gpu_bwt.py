@@ -192,3 +192,30 @@ def test_baseline_1GiB_single_block(oracle):
     rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
     assert rc == 0
     assert hashlib.sha256(inv.tobytes()).digest() == hashlib.sha256(d.tobytes()).digest()
+
+
+def test_chained_sort_variant(oracle, monkeypatch):
+    """The opt-in chained single-read radix passes (BWTC_HIP_SORT=sweep; decoupled look-back
+    with bounded spins) must give the same results as the default passes."""
+    from bwtc_amd import hip
+    monkeypatch.setenv("BWTC_HIP_SORT", "sweep")
+    with hip.Context(0, 4 << 20) as ctx:
+        rng = np.random.default_rng(77)
+        for n, nbits in [(8193, 32), (300001, 32), (1 << 20, 20)]:
+            k = rng.integers(0, 1 << nbits, n, dtype=np.uint64).astype(np.uint32)
+            v = np.arange(n, dtype=np.uint32)
+            gk, gv = ctx.test_sort(k, v, nbits)
+            order = np.argsort(k, kind="stable")
+            assert (gk == k[order]).all() and (gv == v[order]).all()
+        k = rng.integers(0, 1 << 50, 700001, dtype=np.uint64)
+        v = np.arange(k.size, dtype=np.uint32)
+        gk, gv = ctx.test_sort(k, v, 50)
+        order = np.argsort(k, kind="stable")
+        assert (gk == k[order]).all() and (gv == v[order]).all()
+        d = synth.gen_text(3 << 20, 3)
+        a = ctx.bwt_block(d, 8)
+        b = oracle.oracle_bwt_block(d[:1 << 20], 8)
+        a1 = ctx.bwt_block(d[:1 << 20], 8)
+        assert (a1[0] == b[0]).all() and (a1[1] == b[1]).all()
+        rc, inv = oracle.oracle_inverse_bwt_block(a[0], a[1])
+        assert rc == 0 and (inv == d).all()
