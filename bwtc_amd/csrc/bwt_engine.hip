@@ -76,9 +76,11 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------
-// K2  initial keys.  The alphabet is remapped to dense codes of w bits (order preserving,
-//     byte 0 -> code 0) and the key of suffix i is its first k characters packed MSB-first,
-//     k*w <= bits of K; characters past the end read the zero padding.  Slot j holds suffix
+// K2  initial keys.  The alphabet is remapped to dense codes 0..sigma-1 (order preserving,
+//     byte 0 -> code 0) and the key of suffix i is its first k characters as a base-sigma
+//     number, most significant first (sigma^k <= 2^bits of K; mixed-radix packing wastes no
+//     fractional bits: 10 characters of a 45-symbol text fit 55 bits = 7 radix passes);
+//     characters past the end read the zero padding.  Slot j holds suffix
 //     i = n-1-j (descending!).  Feeding the stable sort in descending suffix order puts,
 //     inside every group of equal keys, the suffixes shorter than k first and
 //     shortest-first -- exactly "proper prefix sorts first" -- without spending key bits.
@@ -87,7 +89,7 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
                                                    K* __restrict__ keys, u32* __restrict__ idx,
-                                                   u32 n, int k, int w) {
+                                                   u32 n, int k, u32 sigma) {
   __shared__ u8 s_lut[256];
   s_lut[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
   if (j >= n) return;
   const u32 i = n - 1u - j;
   K key = 0;
-  for (int t = 0; t < k; ++t) key = (K)(key << w) | (K)s_lut[T[i + t]];
+  for (int t = 0; t < k; ++t) key = (K)(key * (K)sigma) + (K)s_lut[T[i + t]];
   keys[j] = key;
   idx[j] = i;
 }
@@ -500,13 +502,30 @@ static constexpr int kSmallFreqs = 0, kSmallLf = 256, kSmallPidx = 512, kSmallCo
 // bytes in 32 bits, 9 characters of text in 64 bits.  32 bits are used when the order-0
 // entropy says the 32-bit key already separates almost all suffixes; the choice only
 // changes speed, never the result.
-struct KeyPlan { int w, k; bool wide; u8 lut[256]; };
+struct KeyPlan { int k, bits; u32 sigma; bool wide; u8 lut[256]; };
+
+// most characters per 8-bit radix pass for keys of at most `maxbits` bits; ties -> longer key
+static void best_packing(u32 sigma, int maxbits, int* k_out, int* bits_out) {
+  double best = -1.0;
+  unsigned __int128 pow = 1;
+  *k_out = 1; *bits_out = 8;
+  for (int k = 1; k <= 32; ++k) {
+    pow *= sigma;
+    if (pow > ((unsigned __int128)1 << maxbits)) break;
+    int bits = 0;
+    for (unsigned __int128 v = pow - 1; v; v >>= 1) ++bits;
+    if (bits == 0) bits = 1;
+    const int passes = (bits + kRadixBits - 1) / kRadixBits;
+    const double ratio = (double)k / passes;
+    if (ratio >= best) { best = ratio; *k_out = k; *bits_out = bits; }
+  }
+}
 
 // lone_sentinel: the only zero byte of T is the terminator planted at T[n-1].  It then
 // shares code 0 with the smallest real symbol instead of costing a code of its own (DNA
-// stays at 2 bits per character): a suffix whose key window reaches the terminator has
-// length <= k, and all of those are split off as singletons in true order by the
-// "shorter first" rule of the initial ranking, so the merged code is never compared.
+// stays at 4 symbols): a suffix whose key window reaches the terminator has length <= k,
+// and all of those are split off as singletons in true order by the "shorter first" rule
+// of the initial ranking, so the merged code is never compared.
 static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
   KeyPlan p;
   int sigma = 0;
@@ -518,11 +537,14 @@ static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
   }
   for (int c = lone_sentinel ? 1 : 0; c < 256; ++c)
     if (hist[c]) { const double q = hist[c] / total; h0 -= q * std::log2(q); }
-  p.w = sigma <= 1 ? 1 : bit_width_u64((u64)sigma - 1);
-  const int k32 = std::min(32 / p.w, 32), k64 = std::min(64 / p.w, 32);
+  p.sigma = (u32)(sigma < 2 ? 2 : sigma);
+  int k32, b32, k64, b64;
+  best_packing(p.sigma, 32, &k32, &b32);
+  best_packing(p.sigma, 64, &k64, &b64);
   const double need = std::log2((double)n + 1.0) + 2.0;
   p.wide = (k64 > k32) && (k32 * h0 < need);
   p.k = p.wide ? k64 : k32;
+  p.bits = p.wide ? b64 : b32;
   return p;
 }
 
@@ -575,7 +597,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   std::memcpy(h_small + kSmallLut, plan.lut, 256);
   BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallLut, h_small + kSmallLut, 256, hipMemcpyHostToDevice, st));
   const u8* d_lut = reinterpret_cast<const u8*>(d_small + kSmallLut);
-  const int key_bits = plan.k * plan.w;
+  const int key_bits = plan.bits;
   // suffixes of length <= k are finished by the initial ranking (a suffix of length exactly
   // k is a proper prefix of every other suffix with the same key)
   const u32 short_len = (u32)plan.k;
@@ -593,7 +615,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
     hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.w);
+                       d_V0, n, plan.k, plan.sigma);
     u64* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
@@ -612,7 +634,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
     hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.w);
+                       d_V0, n, plan.k, plan.sigma);
     u32* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));

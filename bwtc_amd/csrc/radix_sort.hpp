@@ -38,12 +38,16 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
                                                           u32* __restrict__ table, u64 n,
                                                           int shift, u32 ntiles) {
   constexpr int E = RadixCfg<K>::E;
-  __shared__ u32 hist[kRadixBins];
-  if (threadIdx.x < kRadixBins) hist[threadIdx.x] = 0;
+  // 16 interleaved copies per bin (copy = lane & 15): equal digits of neighbouring lanes land
+  // on different LDS addresses and banks, so skewed digit distributions (text, DNA, all-equal
+  // blocks) do not serialise the ds_add.
+  __shared__ u32 hist[kRadixBins * 16];
+  for (u32 i = threadIdx.x; i < kRadixBins * 16; i += kRadixTPB) hist[i] = 0;
   __syncthreads();
   const u64 tile_base = (u64)blockIdx.x * (kRadixTPB * E);
   const u32 wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const u64 wbase = tile_base + (u64)wave * (kWave * E) + lane;
+  const u32 copy = lane & 15u;
   K k[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -53,10 +57,15 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     u64 i = wbase + (u64)e * kWave;
-    if (i < n) atomicAdd(&hist[radix_digit(k[e], shift)], 1u);
+    if (i < n) atomicAdd(&hist[radix_digit(k[e], shift) * 16u + copy], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < kRadixBins) table[(u64)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < kRadixBins) {
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c += hist[threadIdx.x * 16u + r];
+    table[(u64)threadIdx.x * ntiles + blockIdx.x] = c;
+  }
 }
 
 template <typename K>
