@@ -670,6 +670,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     u64* k64s = nullptr;
     u32* v64s = nullptr;
     const int nbits = b1 + b2;
+    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u: h=%llu m=%u groups=%u b1=%d b2=%d\n", stats.rounds, (unsigned long long)h, m, groups, b1, b2);
     const bool timed = n_sort_events + 2 <= kMaxSortEvents;
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, &k64s, &v64s, true);

@@ -120,14 +120,15 @@ __global__ __launch_bounds__(kStatTPB) void k_run_stats(const u32* __restrict__ 
                                                         u32 nsec, u32* __restrict__ run_freqs,
                                                         unsigned long long* __restrict__ gbits) {
   __shared__ u32 s_first[257];
-  __shared__ u32 hist[256];
+  __shared__ u32 hist[256 * 8];      // 8 interleaved copies per symbol (copy = lane & 7)
   __shared__ u32 s_g0;
   for (u32 i = threadIdx.x; i <= nsec; i += kStatTPB) s_first[i] = first_run[i];
-  hist[threadIdx.x] = 0;
+  for (u32 i = threadIdx.x; i < 256 * 8; i += kStatTPB) hist[i] = 0;
   if (threadIdx.x == 0) s_g0 = 0;
   __syncthreads();
   const u32 base = blockIdx.x * kStatTile;
   const u32 s0 = section_of(s_first, nsec, base);
+  u32 gsum = 0;                     // gamma bits of this thread's runs in section s0
   for (int e = 0; e < kStatE; ++e) {
     const u32 r = base + e * kStatTPB + threadIdx.x;
     if (r >= n_runs) break;
@@ -135,16 +136,20 @@ __global__ __launch_bounds__(kStatTPB) void k_run_stats(const u32* __restrict__ 
     const u32 sym = run_sym[r];
     const u32 g = gamma_bits(len);
     if (r < s_first[s0 + 1]) {
-      atomicAdd(&hist[sym], 1u);
-      atomicAdd(&s_g0, g);
+      atomicAdd(&hist[sym * 8u + (threadIdx.x & 7u)], 1u);
+      gsum += g;
     } else {
       const u32 s = section_of(s_first, nsec, r);
       atomicAdd(&run_freqs[s * 256u + sym], 1u);
       atomicAdd(&gbits[s], (unsigned long long)g);
     }
   }
+  gsum = wave_scan_add(gsum, lane_id());
+  if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
   __syncthreads();
-  const u32 c = hist[threadIdx.x];
+  u32 c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c += hist[threadIdx.x * 8u + k];
   if (c) atomicAdd(&run_freqs[s0 * 256u + threadIdx.x], c);
   if (threadIdx.x == 0 && s_g0) atomicAdd(&gbits[s0], (unsigned long long)s_g0);
 }
@@ -212,42 +217,52 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_u64(const u32* __restrict__
   for (u32 i = b; i < e; ++i) { tile_base[i] = off; off += tile_bits[i]; }
 }
 
-// per section: adj[s] = base_bit[s] - P[first_run[s]], P = global exclusive bit prefix
+// per section: adj[s] = base_bit[s] - P[first_run[s]], P = global exclusive bit prefix.
+// One wave per section sums the code lengths of the runs between the start of the tile that
+// holds first_run[s] and first_run[s] itself.
 template <int STREAM>
-__global__ __launch_bounds__(256) void k_section_adjust(
+__global__ __launch_bounds__(kWave) void k_section_adjust(
     const u32* __restrict__ run_start, const u8* __restrict__ run_sym,
     const u32* __restrict__ first_run, u32 nsec, const u8* __restrict__ clen_tab,
     const unsigned long long* __restrict__ tile_base,
     const unsigned long long* __restrict__ base_bit, unsigned long long* __restrict__ adj) {
-  const u32 s = threadIdx.x;
+  const u32 s = blockIdx.x;
   if (s >= nsec) return;
+  const u32 lane = threadIdx.x;
   const u32 r0 = first_run[s];
   const u32 t = r0 / kPackTile;
-  unsigned long long P = tile_base[t];
-  // runs [t*tile, r0) may belong to section s-1 (or earlier): walk sections backwards lazily
-  u32 sec = s;
-  for (u32 r = r0; r-- > t * kPackTile;) {
+  u32 sum = 0;
+  for (u32 r = t * kPackTile + lane; r < r0; r += kWave) {
+    u32 sec = s;                              // runs before r0 belong to an earlier section
     while (r < first_run[sec]) --sec;
-    P += item_bits<STREAM>(r, sec, run_start, run_sym, clen_tab);
+    sum += item_bits<STREAM>(r, sec, run_start, run_sym, clen_tab);
   }
-  adj[s] = base_bit[s] - P;
+  sum = wave_scan_add(sum, lane);
+  if (lane == kWave - 1) adj[s] = base_bit[s] - (tile_base[t] + sum);
 }
 
-__device__ __forceinline__ void or_bits(u32* __restrict__ out32, unsigned long long pos,
+// ORs `nbits` bits of `value` into an MSB-first bit stream at bit position `pos` of the word
+// array `words` (bit p is bit 7 - p%8 of byte p/8): work on big-endian 32-bit words and
+// byte-swap each contribution into the little-endian store.
+__device__ __forceinline__ void or_bits(u32* words, unsigned long long pos,
                                         unsigned long long value, u32 nbits) {
-  // MSB-first stream: bit `pos` is bit (7 - pos%8) of byte pos/8.  Work on big-endian
-  // 32-bit words and byte-swap each contribution into the little-endian store.
   while (nbits) {
     const u32 o = (u32)(pos & 31ull);
     const u32 take = min(nbits, 32u - o);
     const u32 chunk = (u32)((value >> (nbits - take)) & ((take == 32u) ? 0xFFFFFFFFull : ((1ull << take) - 1ull)));
     const u32 be = chunk << (32u - o - take);
-    if (be) atomicOr(&out32[pos >> 5], __builtin_bswap32(be));
+    if (be) atomicOr(&words[pos >> 5], __builtin_bswap32(be));
     pos += take;
     nbits -= take;
   }
 }
 
+constexpr u32 kPackWinWords = 4096;   // LDS staging window: 16 KiB of output per tile
+
+// The bits of one tile of runs cover a contiguous stretch of the output (plus, when the tile
+// crosses a section start, the header bytes in between).  They are assembled in an LDS window
+// with ds_or and flushed with one global OR per non-zero word; only tiles whose stretch does
+// not fit the window fall back to one global OR per code.
 template <int STREAM>
 __global__ __launch_bounds__(kPackTPB) void k_pack_emit(
     const u32* __restrict__ run_start, const u8* __restrict__ run_sym, u32 n_runs,
@@ -256,9 +271,14 @@ __global__ __launch_bounds__(kPackTPB) void k_pack_emit(
     const unsigned long long* __restrict__ adj, u32* __restrict__ out32) {
   __shared__ u32 s_first[257];
   __shared__ u32 scr[kPackTPB / kWave + 1];
+  __shared__ u32 s_win[kPackWinWords];
+  __shared__ unsigned long long s_lohi[2];
   for (u32 i = threadIdx.x; i <= nsec; i += kPackTPB) s_first[i] = first_run[i];
+  for (u32 i = threadIdx.x; i < kPackWinWords; i += kPackTPB) s_win[i] = 0;
   __syncthreads();
-  const u32 r0 = blockIdx.x * kPackTile + threadIdx.x * kPackE;
+  const u32 tile_first = blockIdx.x * kPackTile;
+  const u32 tile_last = min(tile_first + (u32)kPackTile, n_runs) - 1u;   // last run of the tile
+  const u32 r0 = tile_first + threadIdx.x * kPackE;
   u32 nb[kPackE];
   u32 sum = 0, s_begin = 0;
   if (r0 < n_runs) {
@@ -277,19 +297,43 @@ __global__ __launch_bounds__(kPackTPB) void k_pack_emit(
   }
   u32 total;
   const u32 off = block_scan_excl_add<kPackTPB>(sum, scr, &total);
-  if (r0 >= n_runs) return;
   unsigned long long P = tile_base[blockIdx.x] + off;
-  u32 s = s_begin;
+  // first and last bit position of the tile (positions grow with the run index)
+  if (r0 < n_runs) {
+    if (threadIdx.x == 0) s_lohi[0] = adj[s_begin] + P;
+    if (tile_last >= r0 && tile_last < r0 + kPackE) {
+      u32 s = s_begin;
+      unsigned long long q = P;
+      for (u32 r = r0; r < tile_last; ++r) q += nb[r - r0];
+      while (tile_last >= s_first[s + 1]) ++s;
+      s_lohi[1] = adj[s] + q + nb[tile_last - r0];
+    }
+  }
+  __syncthreads();
+  const unsigned long long wbase = s_lohi[0] >> 5;
+  const unsigned long long nwords = ((s_lohi[1] + 31ull) >> 5) - wbase;
+  const bool staged = nwords <= (unsigned long long)kPackWinWords;
+  if (r0 < n_runs) {
+    u32 s = s_begin;
 #pragma unroll
-  for (int e = 0; e < kPackE; ++e) {
-    const u32 r = r0 + e;
-    if (r >= n_runs) break;
-    while (r >= s_first[s + 1]) ++s;
-    unsigned long long value;
-    if (STREAM == 0) value = code_tab[s * 256u + run_sym[r]];
-    else value = run_start[r + 1] - run_start[r];
-    or_bits(out32, adj[s] + P, value, nb[e]);
-    P += nb[e];
+    for (int e = 0; e < kPackE; ++e) {
+      const u32 r = r0 + e;
+      if (r >= n_runs) break;
+      while (r >= s_first[s + 1]) ++s;
+      unsigned long long value;
+      if (STREAM == 0) value = code_tab[s * 256u + run_sym[r]];
+      else value = run_start[r + 1] - run_start[r];
+      const unsigned long long pos = adj[s] + P;
+      if (staged) or_bits(s_win, pos - (wbase << 5), value, nb[e]);
+      else or_bits(out32, pos, value, nb[e]);
+      P += nb[e];
+    }
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (u32 w = threadIdx.x; w < (u32)nwords; w += kPackTPB) {
+    const u32 v = s_win[w];
+    if (v) atomicOr(&out32[wbase + w], v);
   }
 }
 
@@ -431,7 +475,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   hipLaunchKernelGGL(k_pack_count<0>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
                      n_runs, d_first_run, nsec, d_clen, d_tile);
   hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, st, d_tile, d_tile_base, ptiles);
-  hipLaunchKernelGGL(k_section_adjust<0>, dim3(1), dim3(256), 0, st, d_run_start, d_run_sym,
+  hipLaunchKernelGGL(k_section_adjust<0>, dim3(nsec), dim3(kWave), 0, st, d_run_start, d_run_sym,
                      d_first_run, nsec, d_clen, d_tile_base, d_base_bit, d_adj);
   hipLaunchKernelGGL(k_pack_emit<0>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
                      n_runs, d_first_run, nsec, d_clen, d_code, d_tile_base, d_adj, out32);
@@ -440,7 +484,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   hipLaunchKernelGGL(k_pack_count<1>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
                      n_runs, d_first_run, nsec, d_clen, d_tile);
   hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, st, d_tile, d_tile_base, ptiles);
-  hipLaunchKernelGGL(k_section_adjust<1>, dim3(1), dim3(256), 0, st, d_run_start, d_run_sym,
+  hipLaunchKernelGGL(k_section_adjust<1>, dim3(nsec), dim3(kWave), 0, st, d_run_start, d_run_sym,
                      d_first_run, nsec, d_clen, d_tile_base, d_base_bit, d_adj);
   hipLaunchKernelGGL(k_pack_emit<1>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
                      n_runs, d_first_run, nsec, d_clen, d_code, d_tile_base, d_adj, out32);

@@ -14,7 +14,21 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 kinds = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or ["text", "dna", "random"]
 sizes = [int(a) for a in args] or [16, 64]
 ctx = hip.Context(0, (max(sizes) << 20) + 64)
-for kind, gen, seed in [("text", synth.gen_text, 3), ("dna", synth.gen_dna, 2), ("random", synth.gen_random_bytes, 1)]:
+def gen_zeros(n, seed):
+    return np.zeros(n, np.uint8)
+
+
+def gen_period(n, seed):
+    return np.tile(np.frombuffer(b"abcabcabd" * 113, np.uint8), n // 1017 + 1)[:n].copy()
+
+
+def gen_reptext(n, seed):
+    base = synth.gen_text(1 << 20, seed)
+    return np.tile(base, n // base.size + 1)[:n].copy()
+
+
+for kind, gen, seed in [("text", synth.gen_text, 3), ("dna", synth.gen_dna, 2), ("random", synth.gen_random_bytes, 1),
+                        ("zeros", gen_zeros, 0), ("period", gen_period, 0), ("reptext", gen_reptext, 3)]:
     if kind not in kinds:
         continue
     for mib in sizes:
