@@ -90,4 +90,8 @@ u64 huffman_compress_bound(u64 size);
 int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                           const u32* freqs, u8* d_out, u64 out_cap, u64* out_bytes);
 
+// Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).
+// Returns -4 when an LF power does not lie on the LF walk (corrupt header or data).
+int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const u32* lf, u32 n_lf);
+
 }  // namespace bwtc_hip

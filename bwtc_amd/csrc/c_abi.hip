@@ -146,6 +146,27 @@ int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d
   return e.transform(d_in, d_out, size, false, lf, n_lf, freqs);
 }
 
+int bwtc_hip_inverse_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                               const uint32_t* lf, uint32_t n_lf) {
+  if (!ctx || (!block && size) || !lf || n_lf == 0) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  if (size == 0) return 0;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, block, size);
+  if (rc) return rc;
+  rc = inverse_bwt_device(e, e.d_in, e.d_in, size, lf, n_lf);
+  if (rc) return rc;
+  return stage_out(e, block, size);
+}
+
+int bwtc_hip_inverse_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint8_t* d_out,
+                                      uint32_t size, const uint32_t* lf, uint32_t n_lf) {
+  if (!ctx || ((!d_bwt || !d_out) && size) || !lf || n_lf == 0) return -1;
+  if (size > ctx->eng.max_block) return -1;
+  return inverse_bwt_device(ctx->eng, d_bwt, d_out, size, lf, n_lf);
+}
+
 uint64_t bwtc_hip_compress_bound(uint32_t size) { return huffman_compress_bound(size); }
 
 int bwtc_hip_huffman_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,

@@ -33,7 +33,8 @@ EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_n_lf", "bwtc_hip_bwt",
-    "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_compress_bound",
+    "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
+    "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
@@ -70,6 +71,8 @@ def load():
     L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
     L.bwtc_hip_bwt_block.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
     L.bwtc_hip_bwt_block_device.argtypes = [_vp, _vp, _vp, _u32, _vp, _u32, _vp]
+    L.bwtc_hip_inverse_bwt_block.argtypes = [_vp, _vp, _u32, _vp, _u32]
+    L.bwtc_hip_inverse_bwt_block_device.argtypes = [_vp, _vp, _vp, _u32, _vp, _u32]
     L.bwtc_hip_compress_bound.restype = _u64
     L.bwtc_hip_compress_bound.argtypes = [_u32]
     L.bwtc_hip_huffman_encode_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u64,
@@ -190,6 +193,21 @@ class Context:
                                                   _ptr(lf), n_lf, _ptr(freqs)),
                "bwtc_hip_bwt_block_device")
         return lf, freqs
+
+    def inverse_bwt_block(self, bwt, lf):
+        """InverseBWTransform::doTransform(BWTBlock&): returns the original block; raises
+        BwtcHipError (code -4) when an LF power does not lie on the LF walk."""
+        b = np.array(bwt, dtype=np.uint8, copy=True)
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        _check(self.lib.bwtc_hip_inverse_bwt_block(self.handle, _ptr(b), b.size, _ptr(lf), lf.size),
+               "bwtc_hip_inverse_bwt_block")
+        return b
+
+    def inverse_bwt_block_device(self, d_bwt_ptr, d_out_ptr, size, lf):
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        _check(self.lib.bwtc_hip_inverse_bwt_block_device(self.handle, _vp(d_bwt_ptr), _vp(d_out_ptr),
+                                                          size, _ptr(lf), lf.size),
+               "bwtc_hip_inverse_bwt_block_device")
 
     def compress_bound(self, size):
         return int(self.lib.bwtc_hip_compress_bound(size))

@@ -84,6 +84,21 @@ int bwtc_hip_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size, uint32_
 int bwtc_hip_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_in, uint8_t* d_out,
                               uint32_t size, uint32_t* lf, uint32_t n_lf, uint32_t* freqs);
 
+/* ---- inverse transform ---------------------------------------------------------------- */
+
+/* Replaces InverseBWTransform::doTransform(BWTBlock&) (bwtransforms/InverseBWT.cpp:47-51) and
+ * the MTL-SA walk behind it (bwtransforms/MtlSaInverseBWT.cpp:246-362): block[0..size-1]
+ * (host) holds a transformed block as the forward path leaves it, lf[0..n_lf-1] its LF powers
+ * (lf[0] = end-of-block row); on return block holds the original bytes.  The reference needs
+ * block[size] as scratch (InverseBWT.cpp:49); this entry point does not touch it.
+ * Returns -4 if an LF power is inconsistent with the data. */
+int bwtc_hip_inverse_bwt_block(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                               const uint32_t* lf, uint32_t n_lf);
+
+/* Same with device pointers (may alias); lf is a HOST array. */
+int bwtc_hip_inverse_bwt_block_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint8_t* d_out,
+                                      uint32_t size, const uint32_t* lf, uint32_t n_lf);
+
 /* ---- 'H' entropy coder (HuffmanCoders.cpp) ------------------------------------------- */
 
 /* Upper bound of the bytes one encoded BWT block of `size` input bytes can take. */
