@@ -8,6 +8,7 @@
 //   BWTransform         bwtransforms/BWTransform.hpp:48-70, BWTransform.cpp:38-76
 //   HipBWTransform      the new back-end (what INTEGRATION.md adds to the reference), 'g'
 //   BWTManager          bwtransforms/BWTManager.hpp:41-58, BWTManager.cpp:36-80
+//   InverseBWTransform  bwtransforms/InverseBWT.hpp:45-55, InverseBWT.cpp:42-51 (+ HipInverseBWTransform)
 //   EntropyEncoder      EntropyCoders.hpp:44-66, EntropyCoders.cpp:38-51
 //   HuffmanEncoder      HuffmanCoders.hpp, HuffmanCoders.cpp:46-61
 //   Compressor          Compressor.hpp:76-117, Compressor.cpp:36-118
@@ -264,6 +265,46 @@ class BWTManager {
   uint32 m_startingPoints, m_maxBlock;
   int m_device;
 };
+
+// ---- inverse transform ---------------------------------------------------------------------
+// bwtransforms/InverseBWT.hpp:45-55.  The raw virtual takes the N = size + 1 byte layout the
+// reference's wrapper builds (bwt[N-1] = bwt[LF[0]], InverseBWT.cpp:47-51).
+class InverseBWTransform {
+ public:
+  virtual ~InverseBWTransform() {}
+  virtual uint64 maxBlockSize(uint64 memory_budget) const = 0;
+  virtual void doTransform(byte* bwt, uint32 n, const std::vector<uint32>& LFpow) = 0;
+  virtual void doTransform(BWTBlock& block) {
+    byte* data = block.begin();
+    *block.end() = data[block.LFpowers()[0]];
+    doTransform(block.begin(), (uint32)block.size() + 1, block.LFpowers());
+  }
+};
+
+class HipInverseBWTransform : public InverseBWTransform {
+ public:
+  explicit HipInverseBWTransform(uint32 maxBlockSize, int device = 0) : m_ctx(0) {
+    hipFatal(bwtc_hip_create(device, maxBlockSize, &m_ctx), "bwtc_hip_create");
+  }
+  virtual ~HipInverseBWTransform() { bwtc_hip_destroy(m_ctx); }
+  uint64 maxBlockSize(uint64) const { return 0x7fffffffu - 2; }
+  void doTransform(byte* bwt, uint32 n, const std::vector<uint32>& LFpow) {
+    // n counts the borrowed end byte; the library rebuilds it from LFpow[0] itself
+    hipFatal(bwtc_hip_inverse_bwt_block(m_ctx, bwt, n - 1, &LFpow[0], (uint32)LFpow.size()),
+             "bwtc_hip_inverse_bwt_block");
+  }
+  void doTransform(BWTBlock& block) {     // *block.end() is not needed and not touched
+    hipFatal(bwtc_hip_inverse_bwt_block(m_ctx, block.begin(), (uint32)block.size(),
+                                        &block.LFpowers()[0], (uint32)block.LFpowers().size()),
+             "bwtc_hip_inverse_bwt_block");
+  }
+ private:
+  bwtc_hip_ctx* m_ctx;
+};
+
+inline InverseBWTransform* giveInverseTransformer(uint32 maxBlockSize, int device = 0) {
+  return new HipInverseBWTransform(maxBlockSize, device);     // InverseBWT.cpp:42-45
+}
 
 // ---- entropy coding ------------------------------------------------------------------------
 class EntropyEncoder {

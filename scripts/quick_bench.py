@@ -41,5 +41,9 @@ for kind, gen, seed in [("text", synth.gen_text, 3), ("dna", synth.gen_dna, 2), 
             st = ctx.stats()
             if best is None or st.ms_total < best[0]:
                 best = (st.ms_total, st.ms_sort, st.rounds, st.active_sum / st.n, wall, st.sort_pass_items / st.n)
+        inv = ctx.inverse_bwt_block(bwt, lf)
+        assert (inv == d).all()
+        ims = ctx.stats().ms_total
+        print("%-6s %4d MiB: inverse %7.2f ms -> %8.1f MB/s" % (kind, mib, ims, (mib << 20) / 1e6 / (ims / 1e3)), flush=True)
         print("%-6s %4d MiB: device %8.2f ms (sort %8.2f) rounds %2d R_eff %.2f passes/N %.1f  -> %8.1f MB/s (wall %.2fs)"
               % (kind, mib, best[0], best[1], best[2], best[3], best[5], (mib << 20) / 1e6 / (best[0] / 1e3), best[4]), flush=True)

@@ -71,6 +71,27 @@ static void testBlockTransformViaManager(std::mt19937& rng) {
   }
 }
 
+// test/InverseBwtTest.cpp:51-114 with both directions on the GPU
+static void testInverseTransformer(std::mt19937& rng) {
+  BWTManager manager(8);
+  manager.setMaxBlockSize(1u << 20);
+  manager.initialize('g');
+  InverseBWTransform* inverse = giveInverseTransformer(1u << 20);
+  for (int round = 0; round < 8; ++round) {
+    const size_t n = 1 + rng() % 500000;
+    manager.setStartingPoints(1 + rng() % 256);
+    std::vector<byte> data = round % 2 ? repetitiveData(rng, n) : randomData(rng, n, round % 4 ? 256 : 3);
+    std::vector<byte> buf(data);
+    buf.push_back(0x77);
+    BWTBlock block(&buf[0], (uint32)n, false);
+    manager.doTransform(block);
+    inverse->doTransform(block);
+    CHECK(std::equal(data.begin(), data.end(), buf.begin()), "GPU inverse(GPU forward) != input (n=%zu)", n);
+    CHECK(buf[n] == 0x77, "byte after the block was modified");
+  }
+  delete inverse;
+}
+
 static void testCompressorRoundTrip(std::mt19937& rng) {
   struct Case { size_t size, mem; unsigned sp; bool rep; };
   const Case cases[] = {{100, 1000, 1, false},     {1000, 2000, 3, true},      {100000, 1000000, 8, false},
@@ -98,6 +119,7 @@ int main() {
   std::mt19937 rng(12345);
   testRawTransformAndInverse(rng);
   testBlockTransformViaManager(rng);
+  testInverseTransformer(rng);
   testCompressorRoundTrip(rng);
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all tests passed\n", failures);
   return failures ? 1 : 0;
