@@ -170,6 +170,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (u32 i = tid; i < tile_n; i += kRadixTPB) {
     const K kk = s_key[i];
     const u32 dst = s_gofs[radix_digit(kk, shift)] + i;
+    // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
+    // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
     kout[dst] = kk;
     vout[dst] = s_val[i];
   }
