@@ -70,13 +70,19 @@ def main():
     for name, gen, size, seed, sp in [("C1_random_1MiB", synth.gen_random_bytes, 1 << 20, 1, 8),
                                       ("C2_dna_4MiB", synth.gen_dna, 4 << 20, 2, 8),
                                       ("C3_text_4MiB", synth.gen_text, 4 << 20, 3, 8),
-                                      ("C3_text_16MiB", synth.gen_text, 16 << 20, 3, 8)]:
+                                      ("C3_text_16MiB", synth.gen_text, 16 << 20, 3, 8),
+                                      ("C2_dna_64MiB", synth.gen_dna, 64 << 20, 2, 8)]:
         d = gen(size, seed)
         bwt, lf, freqs = oracle_lib.ref_bwt_block(d, sp)
+        # 'H' record of the block: the oracle's encoder (pinned by the reference's golden
+        # stream in streams.json) over the reference's BWT output
+        rec = oracle_lib.oracle_huffman_encode_block(bwt, lf, freqs)
         big.append({"name": name, "gen": gen.__name__, "size": size, "seed": seed, "sp": sp,
                     "input_sha256": hashlib.sha256(d.tobytes()).hexdigest(),
                     "bwt_sha256": hashlib.sha256(bwt.tobytes()).hexdigest(),
-                    "lf": [int(x) for x in lf]})
+                    "lf": [int(x) for x in lf],
+                    "h_record_bytes": int(rec.size),
+                    "h_record_sha256": hashlib.sha256(rec.tobytes()).hexdigest()})
         print(name, big[-1]["bwt_sha256"][:16], big[-1]["lf"][:3])
     with open(os.path.join(HERE, "bwt_large.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py (reference libdivsufsort via oracle/_ref)",

@@ -76,3 +76,18 @@ def test_encode_large_text(hip_ctx, oracle):
     back = oracle.oracle_decompress_H(np.frombuffer(_stream(rec.tobytes(), size), np.uint8), size + 8)
     assert back is not None and back.tobytes() == data.tobytes()
     print("32 MiB text -> %d bytes (ratio %.3f)" % (rec.size, rec.size / size))
+
+
+def test_baseline_configs_bwt_and_H_record(hip_ctx):
+    """BASELINE.json configs 1 (1 MiB random + Huffman coder) and 2 (64 MiB DNA) plus the text
+    blocks: BWT bytes and the whole 'H' record against the committed checksums
+    (tests/golden/bwt_large.json; BWT by the reference's divsufsort)."""
+    import hashlib
+    cases = json.load(open(os.path.join(G, "bwt_large.json")))["cases"]
+    assert any(c["name"] == "C2_dna_64MiB" for c in cases)
+    for c in cases:
+        d = getattr(synth, c["gen"])(c["size"], c["seed"])
+        rec, bwt = hip_ctx.transform_and_encode(d, c["sp"])
+        assert hashlib.sha256(bwt.tobytes()).hexdigest() == c["bwt_sha256"], c["name"]
+        assert rec.size == c["h_record_bytes"], c["name"]
+        assert hashlib.sha256(rec.tobytes()).hexdigest() == c["h_record_sha256"], c["name"]
