@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bwtc_hip.hpp"
+#include "bwtc_hip_decode.hpp"
 #include "../../oracle/bwtc_oracle.h"
 
 using namespace bwtc;
@@ -115,12 +116,52 @@ static void testCompressorRoundTrip(std::mt19937& rng) {
   }
 }
 
+// Compressor -> Decompressor entirely through this framework (GPU forward + inverse, host
+// entropy coder), and Decompressor on streams produced by the oracle's restatement of the
+// reference's Compressor, including the golden stream recorded from the reference itself.
+static void testDecompressor(std::mt19937& rng) {
+  struct Case { size_t size, mem; unsigned sp; bool rep; };
+  const Case cases[] = {{1, 1000, 1, false}, {300, 1000, 2, true}, {100000, 200000, 8, false},
+                        {1500000, 2000000, 30, true}, {4000000, 100000000, 8, false}};
+  for (const Case& c : cases) {
+    std::vector<byte> data = c.rep ? repetitiveData(rng, c.size) : randomData(rng, c.size, c.size % 2 ? 5 : 256);
+    MemoryOutStream* packed = new MemoryOutStream();
+    {
+      Compressor compressor(new MemoryInStream(&data[0], data.size()), packed, c.mem, 'H');
+      compressor.initializeBwtAlgorithm('g', c.sp);
+      compressor.compress(1);
+      std::vector<byte> stream = packed->data;              // copy before the compressor dies
+      MemoryOutStream* plain = new MemoryOutStream();
+      Decompressor d(new MemoryInStream(&stream[0], stream.size()), plain);
+      const size_t n = d.decompress(1);
+      CHECK(n == data.size() && plain->data == data, "Compressor->Decompressor round trip (size %zu)", c.size);
+    }
+    // a stream written by the oracle's compressor
+    std::vector<byte> ostream(orc_compress_bound(data.size()) + 100000 * 8);
+    const size_t bs = std::min(static_cast<size_t>(c.mem * 0.185), static_cast<size_t>(0x7fffffff - 1));
+    ostream.resize(orc_compress_H(&data[0], data.size(), bs, c.sp, &ostream[0], ostream.size()));
+    MemoryOutStream* plain = new MemoryOutStream();
+    Decompressor d(new MemoryInStream(&ostream[0], ostream.size()), plain);
+    d.decompress(1);
+    CHECK(plain->data == data, "Decompressor on the oracle's stream (size %zu)", c.size);
+  }
+  // the reference's own 31-byte stream for "abracadabra"
+  const byte golden[] = {0x48, 0x0b, 0x01, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x14, 0x00, 0x00, 0x00, 0x00, 0x0a, 0x01,
+                         0x0b, 0x08, 0x72, 0x05, 0x03, 0xa1, 0x0c, 0x2d, 0x74, 0x63, 0x07, 0x40, 0xfd, 0x30, 0x00};
+  MemoryOutStream* plain = new MemoryOutStream();
+  Decompressor d(new MemoryInStream(golden, sizeof golden), plain);
+  d.decompress(1);
+  CHECK(plain->data.size() == 11 && std::memcmp(&plain->data[0], "abracadabra", 11) == 0,
+        "reference golden stream does not decode to abracadabra");
+}
+
 int main() {
   std::mt19937 rng(12345);
   testRawTransformAndInverse(rng);
   testBlockTransformViaManager(rng);
   testInverseTransformer(rng);
   testCompressorRoundTrip(rng);
+  testDecompressor(rng);
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all tests passed\n", failures);
   return failures ? 1 : 0;
 }

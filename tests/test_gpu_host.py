@@ -39,6 +39,12 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     back = oracle.oracle_decompress_H(stream, data.size + 8)
     assert back is not None and back.tobytes() == data.tobytes()
     assert stream.tobytes() == oracle.oracle_compress_H(data, int(10 * 1000000 * 0.185), 8).tobytes()
+    # and back through this repository's own uncompress (host 'H' decoder + GPU inverse BWT)
+    unexe = os.path.join(ROOT, "bwtc_amd", "host", "uncompress")
+    out = tmp_path / "roundtrip.bin"
+    r = subprocess.run([unexe, "-v", "1", str(dst), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data.tobytes()
     # rejected choices, as the reference's validators do (compress.cpp:86-96)
     r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
     assert r.returncode != 0
