@@ -69,9 +69,12 @@ def main():
     from bwtc_amd import hip, synth
     from bwtc_amd.farm import Farm
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    farm = Farm(backend="nccl", device=dev)          # "nccl" is RCCL on ROCm
+    # one GPU per rank; the modulo only matters when ranks are rehearsed on a smaller box
+    gpu = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    # "nccl" is RCCL on ROCm; BWTC_BENCH_BACKEND=gloo rehearses the N>1 path without it
+    farm = Farm(backend=os.environ.get("BWTC_BENCH_BACKEND", "nccl"), device=dev)
     rank, world = farm.rank, farm.world
 
     size = args.size_mib << 20
@@ -81,7 +84,7 @@ def main():
     host = synth.gen_text(size, seed)
     d_in = torch.from_numpy(host).to(dev)
     d_out = torch.empty_like(d_in)
-    ctx = hip.Context(local_rank, size)
+    ctx = hip.Context(gpu, size)
     have_encode = hasattr(ctx, "huffman_encode_device")
     d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev) if have_encode else None
     torch.cuda.synchronize()
