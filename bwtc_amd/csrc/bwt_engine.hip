@@ -89,17 +89,26 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
                                                    K* __restrict__ keys, u32* __restrict__ idx,
-                                                   u32 n, int k, u32 sigma) {
+                                                   u32 n, int k, u32 sigma, K top) {
+  // four consecutive slots (= four consecutive suffixes) per thread: the first key is built
+  // from k characters, the next three by rolling one character out and one in
+  // (top = sigma^(k-1)), so a thread reads k+3 bytes instead of 4k.
   __shared__ u8 s_lut[256];
   s_lut[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
-  const u32 j = blockIdx.x * 256u + threadIdx.x;
-  if (j >= n) return;
-  const u32 i = n - 1u - j;
+  const u32 j0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (j0 >= n) return;
+  const u32 cnt = min(4u, n - j0);
+  const u32 i_low = n - j0 - cnt;                   // suffix of slot j0 + cnt - 1
   K key = 0;
-  for (int t = 0; t < k; ++t) key = (K)(key * (K)sigma) + (K)s_lut[T[i + t]];
-  keys[j] = key;
-  idx[j] = i;
+  for (int t = 0; t < k; ++t) key = (K)(key * (K)sigma) + (K)s_lut[T[i_low + t]];
+  for (u32 s = 0; s < cnt; ++s) {
+    const u32 i = i_low + s;
+    const u32 slot = n - 1u - i;
+    keys[slot] = key;
+    idx[slot] = i;
+    key = (K)((key - (K)s_lut[T[i]] * top) * (K)sigma) + (K)s_lut[T[i + k]];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -614,8 +623,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   if (plan.wide) {
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
-    hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.sigma);
+    u64 top = 1;
+    for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
+    hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
+                       d_V0, n, plan.k, plan.sigma, top);
     u64* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
@@ -633,8 +644,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   } else {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
-    hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.sigma);
+    u32 top = 1;
+    for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
+    hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
+                       d_V0, n, plan.k, plan.sigma, top);
     u32* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
