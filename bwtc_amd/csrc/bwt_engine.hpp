@@ -18,6 +18,8 @@
 #include "common.hpp"
 #include "bwtc_hip.h"
 #include "radix_sort.hpp"
+#include <utility>
+#include <vector>
 
 namespace bwtc_hip {
 
@@ -89,6 +91,17 @@ u64 huffman_compress_bound(u64 size);
 // complete BWT-block record (48-bit length, BWTBlock header, sections, payloads) to d_out.
 int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                           const u32* freqs, u8* d_out, u64 out_cap, u64* out_bytes);
+
+// What the WaveletTree constructor first computes for every section of a transformed block
+// (utils::calculateRunsAndCharacters, Utils.cpp:128-147; WaveletTree.hpp:294-308).
+struct WaveletSectionStats {
+  std::vector<u32> sections;                                  // section lengths
+  std::vector<u32> run_freqs;                                 // [section][256] runs per symbol
+  std::vector<u64> total_runs;                                // runs per section
+  std::vector<std::vector<std::pair<u32, u32> > > dist;       // per section: (run length, count), ascending
+};
+int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
+                                 WaveletSectionStats* out);
 
 // Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).
 // Returns -4 when an LF power does not lie on the LF walk (corrupt header or data).

@@ -224,6 +224,36 @@ int bwtc_hip_transform_and_encode(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t si
   return 0;
 }
 
+int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                                   const uint32_t* freqs, uint32_t* n_sections,
+                                   uint32_t* section_len, uint32_t* run_freqs,
+                                   uint64_t* total_runs, uint32_t* dist_offset,
+                                   uint32_t* dist_len, uint32_t* dist_cnt, uint32_t dist_cap) {
+  if (!ctx || (!bwt && size) || !freqs || !n_sections || !section_len || !run_freqs ||
+      !total_runs || !dist_offset || !dist_len || !dist_cnt) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, bwt, size);
+  if (rc) return rc;
+  WaveletSectionStats st;
+  rc = wavelet_section_stats_device(e, e.d_in, size, freqs, &st);
+  if (rc) return rc;
+  const uint32_t nsec = (uint32_t)st.sections.size();
+  *n_sections = nsec;
+  uint32_t at = 0;
+  for (uint32_t s = 0; s < nsec; ++s) {
+    section_len[s] = st.sections[s];
+    total_runs[s] = st.total_runs[s];
+    std::memcpy(run_freqs + (size_t)s * 256, &st.run_freqs[(size_t)s * 256], 1024);
+    dist_offset[s] = at;
+    if ((uint64_t)at + st.dist[s].size() > dist_cap) return -1;
+    for (size_t i = 0; i < st.dist[s].size(); ++i) { dist_len[at] = st.dist[s][i].first; dist_cnt[at] = st.dist[s][i].second; ++at; }
+  }
+  dist_offset[nsec] = at;
+  return 0;
+}
+
 void bwtc_hip_host_huffman_lengths(const uint64_t* freqs, uint8_t* clen) {
   bwtc::utils::calculateHuffmanLengths(freqs, clen);
 }

@@ -13,7 +13,9 @@
 #include "bwt_engine.hpp"
 #include "entropy_host.hpp"
 #include "scan.hpp"
+#include <algorithm>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace bwtc_hip {
@@ -491,6 +493,136 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   BWTC_HIP_TRY(hipStreamSynchronize(st));
   BWTC_HIP_TRY(hipGetLastError());
   *out_bytes = total;
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Run scanner of the wavelet coders: utils::calculateRunsAndCharacters (Utils.cpp:128-147),
+// the first thing the WaveletTree constructor does with a section (WaveletTree.hpp:294-308).
+// Per section: runs per symbol, total runs, and the run-length distribution
+// (std::map<runLength, count> in the reference).  Lengths below kLenDense are counted in a
+// dense per-section table (LDS-aggregated for the tile's first section), longer ones are
+// appended to an overflow list; the host folds both into sorted (length, count) pairs.
+// ---------------------------------------------------------------------------------------
+constexpr u32 kLenDense = 4096;
+constexpr u32 kLenLds = 256;
+
+__global__ __launch_bounds__(kStatTPB) void k_run_length_dist(
+    const u32* __restrict__ run_start, u32 n_runs, const u32* __restrict__ first_run, u32 nsec,
+    u32* __restrict__ dense, u32* __restrict__ over_sec, u32* __restrict__ over_len,
+    u32* __restrict__ over_count, u32 over_cap) {
+  __shared__ u32 s_first[257];
+  __shared__ u32 s_hist[kLenLds];
+  for (u32 i = threadIdx.x; i <= nsec; i += kStatTPB) s_first[i] = first_run[i];
+  for (u32 i = threadIdx.x; i < kLenLds; i += kStatTPB) s_hist[i] = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * kStatTile;
+  const u32 s0 = section_of(s_first, nsec, base);
+  for (int e = 0; e < kStatE; ++e) {
+    const u32 r = base + e * kStatTPB + threadIdx.x;
+    if (r >= n_runs) break;
+    const u32 len = run_start[r + 1] - run_start[r];
+    const bool in_s0 = r < s_first[s0 + 1];
+    if (in_s0 && len < kLenLds) { atomicAdd(&s_hist[len], 1u); continue; }
+    const u32 s = in_s0 ? s0 : section_of(s_first, nsec, r);
+    if (len < kLenDense) atomicAdd(&dense[(u64)s * kLenDense + len], 1u);
+    else {
+      const u32 slot = atomicAdd(over_count, 1u);
+      if (slot < over_cap) { over_sec[slot] = s; over_len[slot] = len; }
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < kLenLds; i += kStatTPB) {
+    const u32 c = s_hist[i];
+    if (c) atomicAdd(&dense[(u64)s0 * kLenDense + i], c);
+  }
+}
+
+int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
+                                 WaveletSectionStats* out) {
+  hipStream_t st = e.stream;
+  if (!freqs || !out) return -1;
+  if ((u64)size > e.cap) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  out->sections = bwtc::deduceSections(freqs);
+  const u32 nsec = (u32)out->sections.size();
+  out->run_freqs.assign((size_t)nsec * 256, 0);
+  out->total_runs.assign(nsec, 0);
+  out->dist.assign(nsec, std::vector<std::pair<u32, u32> >());
+  if (size == 0 || nsec == 0) return 0;
+
+  u32* d_run_start = static_cast<u32*>(e.d_R1);
+  u8* d_run_sym = static_cast<u8*>(e.d_R2);
+  u32* d_tile = e.d_V0;
+  u32* d_sec = reinterpret_cast<u32*>(e.d_ent);
+  u32* d_sec_start = d_sec;
+  u32* d_first_run = d_sec + 512;
+  u32* d_nruns = d_sec + 1024;
+  u32* d_over_count = d_sec + 1025;
+  u32* d_run_freqs = d_sec + 2048;
+  unsigned long long* d_gbits = reinterpret_cast<unsigned long long*>(d_sec + 2048 + 65536);
+  u32* d_dense = e.d_G0;                      // nsec * kLenDense words
+  u32* d_over_sec = e.d_G1;
+  u32* d_over_len = e.d_GRP;
+  const u32 over_cap = (u32)std::min<u64>(e.cap, 1u << 24);
+  if ((u64)nsec * kLenDense > e.cap) return -2;    // tiny contexts cannot hold the dense table
+
+  std::vector<u32> sec_start(nsec);
+  { u64 acc = 0; for (u32 s = 0; s < nsec; ++s) { sec_start[s] = (u32)acc; acc += out->sections[s]; } }
+  BWTC_HIP_TRY(hipMemcpyAsync(d_sec_start, sec_start.data(), nsec * 4, hipMemcpyHostToDevice, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_run_freqs, 0, (65536 + 512) * 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_over_count, 0, 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_dense, 0, (u64)nsec * kLenDense * 4, st));
+  const u32 rtiles = ceil_div(size, kRunTile);
+  const int aligned = (reinterpret_cast<uintptr_t>(d_bwt) & 15u) == 0;
+  hipLaunchKernelGGL(k_runs_count, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, aligned);
+  exclusive_scan_u32(d_tile, rtiles, e.d_partial, st);
+  hipLaunchKernelGGL(k_runs_emit, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
+  BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  const u32 n_runs = e.h_small[0];
+  if (n_runs == 0 || n_runs > size) return -3;
+  const u32 stiles = ceil_div(n_runs, kStatTile);
+  hipLaunchKernelGGL(k_run_stats, dim3(stiles), dim3(kStatTPB), 0, st, d_run_start, d_run_sym,
+                     n_runs, d_first_run, nsec, d_run_freqs, d_gbits);
+  hipLaunchKernelGGL(k_run_length_dist, dim3(stiles), dim3(kStatTPB), 0, st, d_run_start, n_runs,
+                     d_first_run, nsec, d_dense, d_over_sec, d_over_len, d_over_count, over_cap);
+  std::vector<u32> first(nsec + 1), dense((size_t)nsec * kLenDense);
+  u32 n_over = 0;
+  BWTC_HIP_TRY(hipMemcpyAsync(out->run_freqs.data(), d_run_freqs, (size_t)nsec * 1024, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(dense.data(), d_dense, dense.size() * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  if (n_over > over_cap) return -2;
+  std::vector<u32> osec(n_over), olen(n_over);
+  if (n_over) {
+    BWTC_HIP_TRY(hipMemcpyAsync(osec.data(), d_over_sec, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(olen.data(), d_over_len, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipStreamSynchronize(st));
+  }
+  BWTC_HIP_TRY(hipGetLastError());
+  std::vector<std::vector<u32> > long_runs(nsec);
+  for (u32 i = 0; i < n_over; ++i) long_runs[osec[i]].push_back(olen[i]);
+  for (u32 s = 0; s < nsec; ++s) {
+    out->total_runs[s] = first[s + 1] - first[s];
+    std::vector<std::pair<u32, u32> >& d = out->dist[s];
+    for (u32 l = 1; l < kLenDense; ++l) {
+      const u32 c = dense[(size_t)s * kLenDense + l];
+      if (c) d.push_back(std::make_pair(l, c));
+    }
+    std::vector<u32>& lr = long_runs[s];
+    std::sort(lr.begin(), lr.end());
+    for (size_t i = 0; i < lr.size();) {
+      size_t j = i;
+      while (j < lr.size() && lr[j] == lr[i]) ++j;
+      d.push_back(std::make_pair(lr[i], (u32)(j - i)));
+      i = j;
+    }
+  }
   return 0;
 }
 

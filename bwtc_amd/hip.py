@@ -36,7 +36,7 @@ EXPORTS = [
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
-    "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_section_stats", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -80,6 +80,7 @@ def load():
     L.bwtc_hip_huffman_encode.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u64,
                                           ctypes.POINTER(_u64)]
     L.bwtc_hip_transform_and_encode.argtypes = [_vp, _vp, _u32, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_section_stats.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32]
     L.bwtc_hip_host_huffman_lengths.restype = None
     L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
     L.bwtc_hip_host_huffman_codes.restype = None
@@ -208,6 +209,27 @@ class Context:
         _check(self.lib.bwtc_hip_inverse_bwt_block_device(self.handle, _vp(d_bwt_ptr), _vp(d_out_ptr),
                                                           size, _ptr(lf), lf.size),
                "bwtc_hip_inverse_bwt_block_device")
+
+    def wavelet_section_stats(self, bwt, freqs):
+        """utils::calculateRunsAndCharacters per section (WaveletTree ctor front-end): returns
+        (section lengths, run_freqs[section][256], total runs, [dict(length -> count)])."""
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        nsec = _u32(0)
+        sec = np.zeros(256, np.uint32)
+        rf = np.zeros(256 * 256, np.uint32)
+        tot = np.zeros(256, np.uint64)
+        off = np.zeros(257, np.uint32)
+        cap = max(1 << 16, bwt.size // 8 + 4096)
+        dl = np.zeros(cap, np.uint32)
+        dc = np.zeros(cap, np.uint32)
+        _check(self.lib.bwtc_hip_wavelet_section_stats(self.handle, _ptr(bwt), bwt.size, _ptr(freqs),
+                                                       ctypes.byref(nsec), _ptr(sec), _ptr(rf), _ptr(tot),
+                                                       _ptr(off), _ptr(dl), _ptr(dc), cap),
+               "bwtc_hip_wavelet_section_stats")
+        n = nsec.value
+        dist = [dict(zip(dl[off[s]:off[s + 1]].tolist(), dc[off[s]:off[s + 1]].tolist())) for s in range(n)]
+        return sec[:n].copy(), rf.reshape(256, 256)[:n].copy(), tot[:n].copy(), dist
 
     def compress_bound(self, size):
         return int(self.lib.bwtc_hip_compress_bound(size))

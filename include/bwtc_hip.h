@@ -129,6 +129,22 @@ int bwtc_hip_transform_and_encode(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t si
                                   uint32_t starting_points, uint8_t* out, uint64_t out_cap,
                                   uint64_t* out_bytes);
 
+/* ---- wavelet coders: run scanner (front-end statistics only) ---------------------------- */
+
+/* utils::calculateRunsAndCharacters (Utils.cpp:128-147) for every section of a transformed
+ * block, as the WaveletTree constructor needs it (WaveletTree.hpp:294-308): bwt = host buffer
+ * of `size` bytes, freqs = the histogram the transform returned.  Outputs (host):
+ *   *n_sections, section_len[256], run_freqs[256*256] ([section][symbol]), total_runs[256],
+ *   dist_offset[257] and the (dist_len[i], dist_cnt[i]) pairs of section s in
+ *   [dist_offset[s], dist_offset[s+1]), ascending by length (the reference's std::map order).
+ * Returns -1 if dist_cap pairs do not suffice.  The tree construction and the arithmetic
+ * coder behind it are not built yet. */
+int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                                   const uint32_t* freqs, uint32_t* n_sections,
+                                   uint32_t* section_len, uint32_t* run_freqs,
+                                   uint64_t* total_runs, uint32_t* dist_offset,
+                                   uint32_t* dist_len, uint32_t* dist_cnt, uint32_t dist_cap);
+
 /* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the
  * small-table steps the encoder runs between its device passes, exported so the host logic
  * can be checked on its own:

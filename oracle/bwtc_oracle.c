@@ -247,6 +247,41 @@ uint64_t orc_run_frequencies_store(uint64_t *run_freqs, uint8_t *runseq, uint32_
     return runs;
 }
 
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* utils::calculateRunsAndCharacters, Utils.cpp:128-147: maximal runs of the section, runs per
+ * symbol, and the std::map<run length, count> the WaveletTree constructor consumes
+ * (WaveletTree.hpp:294-308), here as pairs in the map's iteration order. */
+uint64_t orc_runs_and_characters(uint64_t *run_freqs, const uint8_t *src, size_t len,
+                                 uint32_t *dist_len, uint32_t *dist_cnt, size_t cap, size_t *n_pairs)
+{
+    uint64_t runs = 0;
+    size_t i = 0, k = 0, np = 0;
+    uint32_t *lens = (uint32_t *)malloc((len ? len : 1) * sizeof(uint32_t));
+    while (i < len) {
+        size_t j = i + 1;
+        while (j < len && src[j] == src[i]) ++j;
+        ++run_freqs[src[i]];
+        lens[runs++] = (uint32_t)(j - i);
+        i = j;
+    }
+    qsort(lens, runs, sizeof(uint32_t), cmp_u32);
+    while (k < runs) {
+        size_t j = k;
+        while (j < runs && lens[j] == lens[k]) ++j;
+        if (np < cap) { dist_len[np] = lens[k]; dist_cnt[np] = (uint32_t)(j - k); }
+        ++np;
+        k = j;
+    }
+    free(lens);
+    *n_pairs = np;
+    return runs;
+}
+
 typedef struct { uint64_t w; uint32_t sym; } wsym;
 static int cmp_wsym(const void *a, const void *b)
 {

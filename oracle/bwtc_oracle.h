@@ -31,6 +31,11 @@ uint64_t orc_pack_integer(uint64_t v, int *bytes_needed);
 uint64_t orc_run_frequencies(uint64_t *run_freqs, const uint8_t *src, size_t len);
 uint64_t orc_run_frequencies_store(uint64_t *run_freqs, uint8_t *runseq, uint32_t *runlen,
                                    const uint8_t *src, size_t len);
+/* utils::calculateRunsAndCharacters: returns total runs; run_freqs[256] incremented; the run
+ * length distribution comes back as up to cap (length, count) pairs ascending by length
+ * (*n_pairs = number written, or cap+1.. if it did not fit) */
+uint64_t orc_runs_and_characters(uint64_t *run_freqs, const uint8_t *src, size_t len,
+                                 uint32_t *dist_len, uint32_t *dist_cnt, size_t cap, size_t *n_pairs);
 int  orc_huffman_lengths(const uint64_t freqs[256], uint32_t clen[256]);
 void orc_huffman_codes(const uint32_t clen[256], uint32_t code[256]);
 /* bit strings are returned one bit per byte (0/1) for easy comparison with the

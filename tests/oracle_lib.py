@@ -47,6 +47,8 @@ def lib():
         L.orc_pack_integer.argtypes = [ctypes.c_uint64, _vp]
         L.orc_run_frequencies.restype = ctypes.c_uint64
         L.orc_run_frequencies.argtypes = [_vp, _vp, _sz]
+        L.orc_runs_and_characters.restype = ctypes.c_uint64
+        L.orc_runs_and_characters.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp]
         L.orc_huffman_lengths.argtypes = [_vp, _vp]
         L.orc_huffman_codes.argtypes = [_vp, _vp]
         L.orc_binary_code.restype = _sz
@@ -120,6 +122,26 @@ def oracle_suffix_array(T):
     sa = np.zeros(T.size, np.uint32)
     lib().orc_suffix_array(_ptr(T), T.size, _ptr(sa))
     return sa
+
+
+def oracle_runs_and_characters(section):
+    """(run_freqs[256], total runs, {run length: count}) of one section."""
+    section = np.ascontiguousarray(section, dtype=np.uint8)
+    rf = np.zeros(256, np.uint64)
+    cap = section.size + 1
+    dl = np.zeros(cap, np.uint32)
+    dc = np.zeros(cap, np.uint32)
+    npairs = ctypes.c_size_t(0)
+    runs = lib().orc_runs_and_characters(_ptr(rf), _ptr(section), section.size, _ptr(dl), _ptr(dc), cap,
+                                         ctypes.byref(npairs))
+    return rf, int(runs), dict(zip(dl[:npairs.value].tolist(), dc[:npairs.value].tolist()))
+
+
+def oracle_sections(freqs):
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    out = np.zeros(256, np.uint32)
+    n = lib().orc_sections(_ptr(freqs), _ptr(out))
+    return out[:n].copy()
 
 
 def oracle_huffman_encode_block(bwt, lf, freqs):

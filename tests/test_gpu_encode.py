@@ -91,3 +91,23 @@ def test_baseline_configs_bwt_and_H_record(hip_ctx):
         assert hashlib.sha256(bwt.tobytes()).hexdigest() == c["bwt_sha256"], c["name"]
         assert rec.size == c["h_record_bytes"], c["name"]
         assert hashlib.sha256(rec.tobytes()).hexdigest() == c["h_record_sha256"], c["name"]
+
+
+def test_wavelet_run_scanner_matches_oracle(hip_ctx, oracle):
+    """utils::calculateRunsAndCharacters per section (what the WaveletTree constructor starts
+    from): GPU front-end against the oracle's restatement, section by section."""
+    rng = np.random.default_rng(31)
+    long_runs = np.repeat(rng.integers(0, 6, 4000).astype(np.uint8), rng.integers(1, 9000, 4000))
+    for name, data in [("text", synth.gen_text(3 << 20, 3)), ("dna", synth.gen_dna(1 << 20, 2)),
+                       ("random", synth.gen_random_bytes(300000, 1)), ("long_runs", long_runs),
+                       ("one_run", np.full(50000, 9, np.uint8))]:
+        bwt, lf, freqs = hip_ctx.bwt_block(data, 8)
+        sec, rf, tot, dist = hip_ctx.wavelet_section_stats(bwt, freqs)
+        assert (sec == oracle.oracle_sections(freqs)).all(), name
+        beg = 0
+        for s in range(sec.size):
+            orf, oruns, odist = oracle.oracle_runs_and_characters(bwt[beg:beg + int(sec[s])])
+            assert (rf[s].astype(np.uint64) == orf).all(), (name, s)
+            assert int(tot[s]) == oruns, (name, s)
+            assert dist[s] == odist, (name, s)
+            beg += int(sec[s])

@@ -138,3 +138,16 @@ def test_compress_roundtrip_like_reference_test(oracle):
             s = oracle.oracle_compress_H(d, block, sp)
             r = oracle.oracle_decompress_H(s, size + 8)
             assert r is not None and r.tobytes() == d.tobytes()
+
+
+def test_runs_and_characters_known_answers(oracle):
+    # the run counts of test/UtilsTest.cpp:79-129 hold for calculateRunsAndCharacters too
+    ka = _load("utils_known_answers.json")
+    for c in ka["run_frequencies"]:
+        rf, runs, dist = oracle.oracle_runs_and_characters(np.frombuffer(c["input"].encode(), np.uint8))
+        for k, v in c["expect"].items():
+            assert rf[ord(k)] == v
+        assert runs == sum(c["expect"].values()) == sum(dist.values())
+        assert sum(l * n for l, n in dist.items()) == len(c["input"])
+    rf, runs, dist = oracle.oracle_runs_and_characters(np.frombuffer(b"abdbcarraaa", np.uint8))
+    assert runs == 8 and dist == {1: 6, 2: 1, 3: 1}
