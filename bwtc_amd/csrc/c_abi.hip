@@ -90,6 +90,28 @@ int bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, i
   return 0;
 }
 
+void* bwtc_hip_malloc(bwtc_hip_ctx* ctx, uint64_t bytes) {
+  if (!ctx || hipSetDevice(ctx->eng.device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+void bwtc_hip_free(bwtc_hip_ctx* ctx, void* d_ptr) {
+  if (ctx && d_ptr && hipSetDevice(ctx->eng.device) == hipSuccess) (void)hipFree(d_ptr);
+}
+int bwtc_hip_memcpy_to_device(bwtc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
+  if (!ctx || (!d_dst && bytes) || (!src && bytes)) return -1;
+  BWTC_HIP_TRY(hipSetDevice(ctx->eng.device));
+  if (bytes) BWTC_HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int bwtc_hip_memcpy_to_host(bwtc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes) {
+  if (!ctx || (!dst && bytes) || (!d_src && bytes)) return -1;
+  BWTC_HIP_TRY(hipSetDevice(ctx->eng.device));
+  if (bytes) BWTC_HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 uint32_t bwtc_hip_n_lf(uint32_t size, uint32_t starting_points) {
   if (starting_points < 1) starting_points = 1;          // BWTManager.cpp:60-64
   else if (starting_points > 256) starting_points = 256;

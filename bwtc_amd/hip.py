@@ -32,7 +32,8 @@ class KernelTimers(ctypes.Structure):
 EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
-    "bwtc_hip_get_kernel_timers", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_get_kernel_timers", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
+    "bwtc_hip_memcpy_to_host", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
@@ -66,6 +67,12 @@ def load():
     L.bwtc_hip_get_stats.argtypes = [_vp, ctypes.POINTER(Stats)]
     L.bwtc_hip_set_profiling.argtypes = [_vp, ctypes.c_int]
     L.bwtc_hip_get_kernel_timers.argtypes = [_vp, ctypes.POINTER(KernelTimers), ctypes.c_int]
+    L.bwtc_hip_malloc.restype = _vp
+    L.bwtc_hip_malloc.argtypes = [_vp, _u64]
+    L.bwtc_hip_free.restype = None
+    L.bwtc_hip_free.argtypes = [_vp, _vp]
+    L.bwtc_hip_memcpy_to_device.argtypes = [_vp, _vp, _vp, _u64]
+    L.bwtc_hip_memcpy_to_host.argtypes = [_vp, _vp, _vp, _u64]
     L.bwtc_hip_n_lf.restype = _u32
     L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
     L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
@@ -156,6 +163,27 @@ class Context:
                "bwtc_hip_get_kernel_timers")
         return {"scatter_launches": int(k.scatter_launches), "scatter_bytes": int(k.scatter_bytes),
                 "scatter_ms": float(k.scatter_ms)}
+
+    # ---- device buffers without a HIP binding of one's own ------------------------------
+    def dmalloc(self, nbytes):
+        p = self.lib.bwtc_hip_malloc(self.handle, nbytes)
+        if not p:
+            raise BwtcHipError("bwtc_hip_malloc(%d) failed" % nbytes)
+        return p
+
+    def dfree(self, ptr):
+        self.lib.bwtc_hip_free(self.handle, _vp(ptr))
+
+    def to_device(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self.lib.bwtc_hip_memcpy_to_device(self.handle, _vp(d_ptr), _ptr(arr), arr.nbytes),
+               "bwtc_hip_memcpy_to_device")
+
+    def to_host(self, d_ptr, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        _check(self.lib.bwtc_hip_memcpy_to_host(self.handle, _ptr(out), _vp(d_ptr), nbytes),
+               "bwtc_hip_memcpy_to_host")
+        return out
 
     def bwt_block(self, data, starting_points=8):
         """BWTManager::doTransform(block, freqs): returns (bwt bytes, LFpowers, freqs).

@@ -57,6 +57,13 @@ int  bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out);
 int  bwtc_hip_set_profiling(bwtc_hip_ctx* ctx, int on);
 int  bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, int reset);
 
+/* Device buffers for callers of the *_device entry points that do not link the HIP runtime
+ * themselves (allocation on the context's GPU; copies are synchronous). */
+void* bwtc_hip_malloc(bwtc_hip_ctx* ctx, uint64_t bytes);
+void  bwtc_hip_free(bwtc_hip_ctx* ctx, void* d_ptr);
+int   bwtc_hip_memcpy_to_device(bwtc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
+int   bwtc_hip_memcpy_to_host(bwtc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+
 /* LF powers a block of `size` bytes gets for `starting_points`
  * (BWTManager::setStartingPoints clamp, bwtransforms/BWTManager.cpp:60-64, then
  * BWTBlock::prepareLFpowers, BWTBlock.cpp:104-108). */

@@ -219,3 +219,48 @@ def test_chained_sort_variant(oracle, monkeypatch):
         assert (a1[0] == b[0]).all() and (a1[1] == b[1]).all()
         rc, inv = oracle.oracle_inverse_bwt_block(a[0], a[1])
         assert rc == 0 and (inv == d).all()
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """One context per worker thread (the farm's unit): two threads transform different blocks
+    on the same GPU at the same time."""
+    import threading
+    from bwtc_amd import hip
+    blocks = [synth.gen_text(3 << 20, 3), synth.gen_dna(2 << 20, 2)]
+    results = [None, None]
+
+    def work(i):
+        with hip.Context(0, 4 << 20) as ctx:
+            for _ in range(3):
+                results[i] = ctx.bwt_block(blocks[i], 8)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(2):
+        rc, inv = oracle.oracle_inverse_bwt_block(results[i][0], results[i][1])
+        assert rc == 0 and (inv == blocks[i]).all()
+
+
+def test_device_pointers_unaligned_and_aliased(hip_ctx, oracle):
+    """bwtc_hip_bwt_block_device / _inverse_ / huffman_encode_device on caller-owned device
+    buffers (as bench.py uses them), including odd source offsets and in == out."""
+    d = synth.gen_text(1 << 20, 3)
+    want = oracle.oracle_bwt_block(d, 8)
+    buf = hip_ctx.dmalloc(d.size + 64)
+    out = hip_ctx.dmalloc(hip_ctx.compress_bound(d.size))
+    try:
+        for off in (0, 1, 7):
+            ptr = buf + off
+            hip_ctx.to_device(ptr, d)
+            lf, freqs = hip_ctx.bwt_block_device(ptr, ptr, d.size, 8)          # in place
+            got = hip_ctx.to_host(ptr, d.size)
+            assert (got == want[0]).all() and (lf == want[1]).all() and (freqs == want[2]).all(), off
+            hip_ctx.inverse_bwt_block_device(ptr, ptr, d.size, lf)
+            assert (hip_ctx.to_host(ptr, d.size) == d).all(), off
+        hip_ctx.to_device(buf, want[0])
+        n = hip_ctx.huffman_encode_device(buf, d.size, want[1], want[2], out)
+        assert hip_ctx.to_host(out, n).tobytes() == oracle.oracle_huffman_encode_block(*want).tobytes()
+    finally:
+        hip_ctx.dfree(buf)
+        hip_ctx.dfree(out)
