@@ -64,6 +64,7 @@ struct BwtEngine {
   int n_sort_events = 0;
 
   bwtc_hip_stats stats;
+  u32 wavelet_state = 4;   // FSM8 state carried from block to block by one WaveletEncoder
   ScatterProbe probe;
 
   static u64 workspace_bytes(u32 max_block);
@@ -99,9 +100,18 @@ struct WaveletSectionStats {
   std::vector<u32> run_freqs;                                 // [section][256] runs per symbol
   std::vector<u64> total_runs;                                // runs per section
   std::vector<std::vector<std::pair<u32, u32> > > dist;       // per section: (run length, count), ascending
+  std::vector<u32> first_run;                                 // first run of every section, + total
 };
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
                                  WaveletSectionStats* out);
+
+// WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
+// 112-157, 159-163) for a device-resident transformed block.  Run scanning on the GPU, tree
+// building and range coding on `threads` host threads (wavelet_host.cpp); *fsm8_state is the
+// probability model's carried state (4 for a fresh encoder).  The record goes to host memory.
+int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                          const u32* freqs, unsigned threads, u32* fsm8_state,
+                          std::vector<u8>* record);
 
 // Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).
 // Returns -4 when an LF power does not lie on the LF walk (corrupt header or data).

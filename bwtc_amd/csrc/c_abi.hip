@@ -3,8 +3,10 @@
 #include "radix_sort.hpp"
 #include "bwtc_hip.h"
 #include "entropy_host.hpp"
+#include "wavelet_host.hpp"
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace bwtc_hip;
@@ -273,6 +275,95 @@ int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32
     for (size_t i = 0; i < st.dist[s].size(); ++i) { dist_len[at] = st.dist[s][i].first; dist_cnt[at] = st.dist[s][i].second; ++at; }
   }
   dist_offset[nsec] = at;
+  return 0;
+}
+
+static unsigned pick_threads(uint32_t threads) {
+  if (threads) return threads;
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? hc : 1;
+}
+
+void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { if (ctx) ctx->eng.wavelet_state = 4; }
+
+int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                   const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                   uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                   uint64_t* out_bytes) {
+  if (!ctx || (!d_bwt && size) || !lf || !freqs || !out || !out_bytes) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  std::vector<u8> rec;
+  u32 state = e.wavelet_state;
+  int rc = wavelet_encode_device(e, d_bwt, size, lf, n_lf, freqs, pick_threads(threads), &state, &rec);
+  if (rc) return rc;
+  if (rec.size() > out_cap) return -1;
+  e.wavelet_state = state;
+  std::memcpy(out, rec.data(), rec.size());
+  *out_bytes = rec.size();
+  return 0;
+}
+
+int bwtc_hip_wavelet_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                            const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                            uint32_t threads, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes) {
+  if (!ctx || (!bwt && size)) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  int rc = stage_in(e, bwt, size);
+  if (rc) return rc;
+  return bwtc_hip_wavelet_encode_device(ctx, e.d_in, size, lf, n_lf, freqs, threads, out, out_cap, out_bytes);
+}
+
+int bwtc_hip_transform_and_encode_wavelet(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                                          uint32_t starting_points, uint32_t threads,
+                                          uint8_t* out, uint64_t out_cap, uint64_t* out_bytes) {
+  if (!ctx || (!block && size) || !out || !out_bytes) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  uint32_t lf[256];
+  uint32_t freqs[256];
+  std::memset(freqs, 0, sizeof freqs);                    // WaveletCoders.cpp:78-79
+  const uint32_t n_lf = bwtc_hip_n_lf(size, starting_points);
+  int rc = stage_in(e, block, size);
+  if (rc) return rc;
+  rc = e.transform(e.d_in, e.d_in, size, false, lf, n_lf, freqs);
+  if (rc) return rc;
+  rc = stage_out(e, block, size);                         // the run scanner reuses the workspace
+  if (rc) return rc;
+  return bwtc_hip_wavelet_encode_device(ctx, e.d_in, size, lf, n_lf, freqs, threads, out, out_cap, out_bytes);
+}
+
+int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_run,
+                                   const uint8_t* run_sym, const uint32_t* run_start,
+                                   const uint32_t* run_freqs, const uint32_t* dist_offset,
+                                   const uint32_t* dist_len, const uint32_t* dist_cnt,
+                                   uint32_t threads, uint32_t* state, uint8_t* out,
+                                   uint64_t out_cap, uint64_t* out_bytes) {
+  if (!first_run || !run_sym || !run_start || !run_freqs || !dist_offset || !dist_len || !dist_cnt ||
+      !state || !out || !out_bytes || n_sections > 256) return -1;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t> > > dist(n_sections);
+  std::vector<bwtc::wavelet::SectionRuns> secs(n_sections);
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    for (uint32_t i = dist_offset[s]; i < dist_offset[s + 1]; ++i) dist[s].push_back(std::make_pair(dist_len[i], dist_cnt[i]));
+    secs[s].symbols = run_sym + first_run[s];
+    secs[s].starts = run_start + first_run[s];
+    secs[s].n_runs = first_run[s + 1] - first_run[s];
+    secs[s].run_freqs = run_freqs + (size_t)s * 256;
+    secs[s].dist = dist[s].data();
+    secs[s].n_dist = dist[s].size();
+  }
+  std::vector<bwtc::wavelet::SectionOutput> outs;
+  bwtc::wavelet::encodeSections(secs, pick_threads(threads), state, &outs);
+  uint64_t n = 0;
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    if (n + outs[s].bytes.size() > out_cap) return -1;
+    std::memcpy(out + n, outs[s].bytes.data(), outs[s].bytes.size());
+    n += outs[s].bytes.size();
+  }
+  *out_bytes = n;
   return 0;
 }
 

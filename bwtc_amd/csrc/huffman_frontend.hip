@@ -12,6 +12,7 @@
 // code in entropy_host.cpp.
 #include "bwt_engine.hpp"
 #include "entropy_host.hpp"
+#include "wavelet_host.hpp"
 #include "scan.hpp"
 #include <algorithm>
 #include <cstring>
@@ -605,6 +606,7 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
     BWTC_HIP_TRY(hipStreamSynchronize(st));
   }
   BWTC_HIP_TRY(hipGetLastError());
+  out->first_run = first;
   std::vector<std::vector<u32> > long_runs(nsec);
   for (u32 i = 0; i < n_over; ++i) long_runs[osec[i]].push_back(olen[i]);
   for (u32 s = 0; s < nsec; ++s) {
@@ -623,6 +625,48 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
       i = j;
     }
   }
+  return 0;
+}
+
+
+int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                          const u32* freqs, unsigned threads, u32* fsm8_state,
+                          std::vector<u8>* record) {
+  if (!freqs || !lf || !record || !fsm8_state || n_lf == 0 || n_lf > 256) return -1;
+  // header: WaveletEncoder::writeBlockHeader, WaveletCoders.cpp:173-219
+  std::vector<uint8_t>& rec = *record;
+  rec.assign(6, 0);
+  bwtc::writeBWTBlockHeader(lf, n_lf, rec);
+  WaveletSectionStats st;
+  int rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st);
+  if (rc) return rc;
+  const u32 nsec = (u32)st.sections.size();
+  rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
+  for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
+  if (size && nsec) {
+    // the runs themselves: symbols and start offsets, left in the workspace by the scanner
+    const u32 n_runs = st.first_run[nsec];
+    std::vector<u8> run_sym(n_runs);
+    std::vector<u32> run_start((size_t)n_runs + 1);
+    BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
+    BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
+    BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+    std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
+    for (u32 s = 0; s < nsec; ++s) {
+      bwtc::wavelet::SectionRuns& r = secs[s];
+      r.symbols = run_sym.data() + st.first_run[s];
+      r.starts = run_start.data() + st.first_run[s];
+      r.n_runs = st.first_run[s + 1] - st.first_run[s];
+      r.run_freqs = &st.run_freqs[(size_t)s * 256];
+      r.dist = st.dist[s].data();
+      r.n_dist = st.dist[s].size();
+    }
+    std::vector<bwtc::wavelet::SectionOutput> outs;
+    bwtc::wavelet::encodeSections(secs, threads, fsm8_state, &outs);
+    for (u32 s = 0; s < nsec; ++s) rec.insert(rec.end(), outs[s].bytes.begin(), outs[s].bytes.end());
+  }
+  const u64 len = rec.size() - 6;                                   // finishBlock
+  for (int i = 0; i < 6; ++i) rec[i] = (uint8_t)(len >> (8 * (5 - i)));
   return 0;
 }
 

@@ -37,7 +37,8 @@ EXPORTS = [
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
-    "bwtc_hip_wavelet_section_stats", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
+    "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -88,6 +89,13 @@ def load():
                                           ctypes.POINTER(_u64)]
     L.bwtc_hip_transform_and_encode.argtypes = [_vp, _vp, _u32, _u32, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_section_stats.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32]
+    L.bwtc_hip_transform_and_encode_wavelet.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_reset.restype = None
+    L.bwtc_hip_wavelet_reset.argtypes = [_vp]
+    L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64,
+                                                 ctypes.POINTER(_u64)]
     L.bwtc_hip_host_huffman_lengths.restype = None
     L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
     L.bwtc_hip_host_huffman_codes.restype = None
@@ -258,6 +266,51 @@ class Context:
         n = nsec.value
         dist = [dict(zip(dl[off[s]:off[s + 1]].tolist(), dc[off[s]:off[s + 1]].tolist())) for s in range(n)]
         return sec[:n].copy(), rf.reshape(256, 256)[:n].copy(), tot[:n].copy(), dist
+
+    def wavelet_reset(self):
+        """Start a new stream: the 'B' coder's carried model state goes back to its initial value."""
+        self.lib.bwtc_hip_wavelet_reset(self.handle)
+
+    def wavelet_encode(self, bwt, lf, freqs, threads=0):
+        """WaveletEncoder ('B'): writeBlockHeader + encodeData + finishBlock on a transformed block."""
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        cap = self.compress_bound(bwt.size)
+        out = np.zeros(cap, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_wavelet_encode(self.handle, _ptr(bwt), bwt.size, _ptr(lf), lf.size,
+                                                _ptr(freqs), threads, _ptr(out), cap, ctypes.byref(n)),
+               "bwtc_hip_wavelet_encode")
+        return out[:n.value].copy()
+
+    def wavelet_encode_device(self, d_bwt_ptr, size, lf, freqs, out, threads=0):
+        """Same on a device-resident block; `out` is a host uint8 array; returns bytes written."""
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_wavelet_encode_device(self.handle, _vp(d_bwt_ptr), size, _ptr(lf), lf.size,
+                                                       _ptr(freqs), threads, _ptr(out), out.size,
+                                                       ctypes.byref(n)),
+               "bwtc_hip_wavelet_encode_device")
+        return int(n.value)
+
+    def transform_and_encode_wavelet(self, data, starting_points=8, threads=0):
+        """WaveletEncoder::transformAndEncode ('B'): returns (record, bwt bytes)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        buf = np.empty(data.size + 1, np.uint8)
+        buf[:data.size] = data
+        buf[data.size] = 0x5A
+        cap = self.compress_bound(data.size)
+        out = np.zeros(cap, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_transform_and_encode_wavelet(self.handle, _ptr(buf), data.size,
+                                                              starting_points, threads, _ptr(out), cap,
+                                                              ctypes.byref(n)),
+               "bwtc_hip_transform_and_encode_wavelet")
+        if buf[data.size] != 0x5A:
+            raise BwtcHipError("byte after the block was modified")
+        return out[:n.value].copy(), buf[:data.size].copy()
 
     def compress_bound(self, size):
         return int(self.lib.bwtc_hip_compress_bound(size))

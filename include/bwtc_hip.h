@@ -144,13 +144,46 @@ int bwtc_hip_transform_and_encode(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t si
  *   *n_sections, section_len[256], run_freqs[256*256] ([section][symbol]), total_runs[256],
  *   dist_offset[257] and the (dist_len[i], dist_cnt[i]) pairs of section s in
  *   [dist_offset[s], dist_offset[s+1]), ascending by length (the reference's std::map order).
- * Returns -1 if dist_cap pairs do not suffice.  The tree construction and the arithmetic
- * coder behind it are not built yet. */
+ * Returns -1 if dist_cap pairs do not suffice. */
 int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
                                    const uint32_t* freqs, uint32_t* n_sections,
                                    uint32_t* section_len, uint32_t* run_freqs,
                                    uint64_t* total_runs, uint32_t* dist_offset,
                                    uint32_t* dist_len, uint32_t* dist_cnt, uint32_t dist_cap);
+
+/* WaveletEncoder::transformAndEncode (WaveletCoders.cpp:77-87) for coder 'B' (FSM8 model):
+ * block (host, left transformed) -> encoded BWT-block record in `out` (host).  The transform
+ * and the run scanner run on the GPU; tree building and the range coder are bit-serial and
+ * run on `threads` host threads, one section at a time per thread (0 = all cores).  The
+ * coder's model state is carried from call to call like the reference's encoder object
+ * carries it from block to block; bwtc_hip_wavelet_reset starts a new stream. */
+int bwtc_hip_transform_and_encode_wavelet(bwtc_hip_ctx* ctx, uint8_t* block, uint32_t size,
+                                          uint32_t starting_points, uint32_t threads,
+                                          uint8_t* out, uint64_t out_cap, uint64_t* out_bytes);
+/* Same for an already transformed block (host). */
+int bwtc_hip_wavelet_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,
+                            const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                            uint32_t threads, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes);
+/* Same for a transformed block that is resident on the device (the record still goes to host
+ * memory: the coder runs there). */
+int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                   const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                   uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                   uint64_t* out_bytes);
+void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
+
+/* Host half of the 'B' coder alone (no device work): the sections' runs as the GPU scanner
+ * delivers them -> the concatenated section payloads (packed bitsInRoot, tree shape, range-coded
+ * bytes per section).  first_run[n_sections+1] delimits every section's runs inside
+ * run_sym[] / run_start[] (run_start has one extra entry: the end of the last run);
+ * run_freqs[n_sections*256]; the run-length distribution of section s is the pairs
+ * [dist_offset[s], dist_offset[s+1]).  *state is the model state carried in and out. */
+int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_run,
+                                   const uint8_t* run_sym, const uint32_t* run_start,
+                                   const uint32_t* run_freqs, const uint32_t* dist_offset,
+                                   const uint32_t* dist_len, const uint32_t* dist_cnt,
+                                   uint32_t threads, uint32_t* state, uint8_t* out,
+                                   uint64_t out_cap, uint64_t* out_bytes);
 
 /* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the
  * small-table steps the encoder runs between its device passes, exported so the host logic

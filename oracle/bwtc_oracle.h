@@ -59,6 +59,12 @@ size_t orc_compress_H(const uint8_t *in, size_t size, size_t block_size,
 size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_cap);
 size_t orc_compress_bound(size_t size);
 
+/* ---- 'B' wavelet coder (oracle/wavelet_oracle.c; WaveletCoders.cpp, WaveletTree.hpp) ---- */
+size_t orc_wavelet_encode_block(const uint8_t *bwt, uint32_t size, const uint32_t *lf, uint32_t n_lf,
+                                const uint32_t freqs[256], uint8_t *out, size_t out_cap);
+size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_t starting_points,
+                      uint8_t *out, size_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

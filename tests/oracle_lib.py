@@ -67,6 +67,10 @@ def lib():
         L.orc_compress_H.argtypes = [_vp, _sz, _sz, _u32, _vp, _sz]
         L.orc_decompress_H.restype = _sz
         L.orc_decompress_H.argtypes = [_vp, _sz, _vp, _sz]
+        L.orc_compress_B.restype = _sz
+        L.orc_compress_B.argtypes = [_vp, _sz, _sz, _u32, _vp, _sz]
+        L.orc_wavelet_encode_block.restype = _sz
+        L.orc_wavelet_encode_block.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _sz]
         L.orc_compress_bound.restype = _sz
         L.orc_compress_bound.argtypes = [_sz]
         _lib = L
@@ -162,6 +166,16 @@ def oracle_compress_H(data, block_size, sp=8):
     cap = lib().orc_compress_bound(data.size) + nblocks * 8192
     out = np.zeros(cap, np.uint8)
     n = lib().orc_compress_H(_ptr(data), data.size, block_size, sp, _ptr(out), cap)
+    return out[:n].copy()
+
+
+def oracle_compress_B(data, block_size, sp=8):
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    data = np.ascontiguousarray(data)
+    nblocks = (data.size + block_size - 1) // max(block_size, 1) + 1
+    cap = lib().orc_compress_bound(data.size) + nblocks * 8192
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_compress_B(_ptr(data), data.size, block_size, sp, _ptr(out), cap)
     return out[:n].copy()
 
 

@@ -97,3 +97,89 @@ def test_sections_and_block_header_match_oracle(oracle):
         ka = H.bwtc_hip_host_bwtblock_header(_p(lf), n_lf, _p(oa), oa.size)
         kb = L.orc_write_bwtblock_header(_p(lf), n_lf, _p(ob))
         assert ka == kb and (oa[:ka] == ob[:kb]).all()
+
+
+def _runs_of(section):
+    """(symbols, starts incl. end) of the maximal runs of a byte array (numpy)."""
+    s = np.asarray(section, np.uint8)
+    heads = np.concatenate([[0], np.flatnonzero(s[1:] != s[:-1]) + 1]).astype(np.uint32)
+    return s[heads], np.concatenate([heads, [s.size]]).astype(np.uint32)
+
+
+def _host_wavelet_payload(H, bwt, sections, state=4, threads=2):
+    import ctypes
+    first = [0]
+    syms, starts, rfs, doff, dl, dc = [], [], [], [0], [], []
+    beg = 0
+    for n in sections:
+        sy, st = _runs_of(bwt[beg:beg + int(n)])
+        syms.append(sy)
+        starts.append(st[:-1] + np.uint32(beg))
+        first.append(first[-1] + sy.size)
+        rfs.append(np.bincount(sy, minlength=256).astype(np.uint32))
+        lens = np.diff(st.astype(np.int64))
+        u, c = np.unique(lens, return_counts=True)
+        dl.append(u.astype(np.uint32)); dc.append(c.astype(np.uint32)); doff.append(doff[-1] + u.size)
+        beg += int(n)
+    run_sym = np.concatenate(syms).astype(np.uint8)
+    run_start = np.concatenate(starts + [np.array([beg], np.uint32)]).astype(np.uint32)
+    first = np.array(first, np.uint32); rf = np.concatenate(rfs); doff = np.array(doff, np.uint32)
+    dl = np.concatenate(dl); dc = np.concatenate(dc)
+    out = np.zeros(2 * bwt.size + 65536 * len(sections), np.uint8)
+    n = ctypes.c_uint64(0)
+    st = ctypes.c_uint32(state)
+    rc = H.bwtc_hip_host_wavelet_sections(len(sections), _p(first), _p(run_sym), _p(run_start), _p(rf), _p(doff),
+                                          _p(dl), _p(dc), threads, ctypes.byref(st), _p(out), out.size,
+                                          ctypes.byref(n))
+    assert rc == 0
+    return out[:n.value].tobytes(), st.value
+
+
+def test_wavelet_host_half_matches_oracle(oracle):
+    """The product's host half of the 'B' coder (tree, shape, FSM8/range coder, section
+    parallelism with the carried model state) against the oracle's literal restatement of
+    WaveletEncoder, on transformed blocks with one and with many sections."""
+    from bwtc_amd import synth
+    H = _host()
+    rng = np.random.default_rng(12)
+    cases = [np.frombuffer(b"abracadabra", np.uint8), np.frombuffer(b"a", np.uint8),
+             np.full(30000, 65, np.uint8), synth.gen_text(200000, 3), synth.gen_dna(150000, 2),
+             synth.gen_random_bytes(120000, 1),
+             np.repeat(rng.integers(0, 5, 2000).astype(np.uint8), rng.integers(1, 300, 2000)),
+             (rng.geometric(0.2, 90000) % 256).astype(np.uint8)]
+    for d in cases:
+        bwt, lf, freqs = oracle.oracle_bwt_block(d, 4)
+        sections = oracle.oracle_sections(freqs)
+        cap = oracle.lib().orc_compress_bound(bwt.size)
+        want = np.zeros(cap, np.uint8)
+        lfa = np.ascontiguousarray(lf, np.uint32)
+        n = oracle.lib().orc_wavelet_encode_block(_p(bwt), bwt.size, _p(lfa), lfa.size, _p(freqs), _p(want), cap)
+        want = want[:n].tobytes()
+        hdr = np.zeros(2048, np.uint8)
+        k = oracle.lib().orc_write_bwtblock_header(_p(lfa), lfa.size, _p(hdr))
+        skip = 6 + k + 1 + sum(len(_packed(int(x))) for x in sections)
+        for threads in (1, 3):
+            got, _ = _host_wavelet_payload(H, bwt, sections, 4, threads)
+            assert got == want[skip:], (d.size, threads)
+
+
+def _packed(v):
+    b = bytearray()
+    while True:
+        x = v & 0x7F
+        v >>= 7
+        b.append(x | (0x80 if v else 0))
+        if not v:
+            return bytes(b)
+
+
+def test_wavelet_golden_stream_from_reference(oracle):
+    # SURVEY.md 8c(5): the reference's own 'B' stream for "abracadabra"
+    c = [x for x in json.load(open(os.path.join(G, "streams.json")))["cases"] if x["coder"] == "B"][0]
+    s = oracle.oracle_compress_B(c["input_ascii"].encode(), c["block_size"], c["sp"])
+    assert s.tobytes() == bytes.fromhex(c["stream_hex"])
+    H = _host()
+    d = np.frombuffer(c["input_ascii"].encode(), np.uint8)
+    bwt, lf, freqs = oracle.oracle_bwt_block(d, c["sp"])
+    got, _ = _host_wavelet_payload(H, bwt, oracle.oracle_sections(freqs))
+    assert bytes.fromhex(c["stream_hex"])[17:-1] == got
