@@ -38,9 +38,12 @@ def cpu_baseline(size_mib_sample, seed, coder):
     bwt, lf, fr = (oracle_lib.ref_bwt_block if use_ref else oracle_lib.oracle_bwt_block)(d, 8)
     t_bwt = time.perf_counter() - t0
     t_enc = 0.0
-    if coder == "H":
+    if coder in ("H", "B"):
         t1 = time.perf_counter()
-        oracle_lib.oracle_huffman_encode_block(bwt, lf, fr)
+        if coder == "H":
+            oracle_lib.oracle_huffman_encode_block(bwt, lf, fr)
+        else:
+            oracle_lib.oracle_wavelet_encode_block(bwt, lf, fr)
         t_enc = time.perf_counter() - t1
     mb = d.size / 1e6
     return {
@@ -51,7 +54,7 @@ def cpu_baseline(size_mib_sample, seed, coder):
                   "1 thread%s" % (size_mib_sample, seed,
                                   "the reference's divbwtf (oracle/_ref)" if use_ref
                                   else "oracle/bwtc_oracle.c",
-                                  "; 'H' encode by the oracle port" if coder == "H" else ""),
+                                  "; '%s' encode by the oracle port" % coder if coder else ""),
     }
 
 
@@ -61,6 +64,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mib", type=int, default=256)
+    ap.add_argument("--coder", choices=["B", "H"], default="B",
+                    help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -85,15 +90,24 @@ def main():
     d_in = torch.from_numpy(host).to(dev)
     d_out = torch.empty_like(d_in)
     ctx = hip.Context(gpu, size)
-    have_encode = hasattr(ctx, "huffman_encode_device")
-    d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev) if have_encode else None
+    d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev)
+    h_comp = np.empty(ctx.compress_bound(size), np.uint8)      # the 'B' coder runs on host threads
+    cores = os.cpu_count() or 1
+    threads = max(1, cores // max(world, 1))
     torch.cuda.synchronize()
     comp = [0]
 
-    def step():
-        lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
-        if have_encode:
-            comp[0] = ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
+    def step_for(coder):
+        def step():
+            lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
+            if coder == "H":
+                comp[0] = ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
+            else:
+                ctx.wavelet_reset()
+                comp[0] = ctx.wavelet_encode_device(d_out.data_ptr(), size, lf, freqs, h_comp, threads)
+        return step
+
+    step = step_for(args.coder)
 
     for _ in range(args.warmup):
         step()
@@ -133,9 +147,11 @@ def main():
             "config": {"workload": "C3: %d MiB enwik8-style synthetic text block per GPU "
                                    "(splitmix64 token generator, seed %s), 8 starting points"
                                    % (args.size_mib, "3" if world == 1 else "30+rank"),
-                       "stages": "BWT (suffix sort + BWT + LFpowers + freqs)" +
-                                 (" + 'H' run-length/Huffman encode" if have_encode else
-                                  " only; entropy front-end not built yet"),
+                       "stages": "BWT (suffix sort + BWT + LFpowers + freqs) on the GPU + " +
+                                 ("'B' wavelet coder: run scanner on the GPU, tree + range coder on %d host "
+                                  "threads (bit-serial by the format)" % threads if args.coder == "B" else
+                                  "'H' run-length/Huffman coder on the GPU"),
+                       "coder": args.coder,
                        "blocks_per_gpu": 1, "parallelism": "block farm, no collective"},
             "device_ms_bwt": round(st.ms_total, 3), "rounds": st.rounds,
             "R_eff": round(st.active_sum / max(st.n, 1), 3),
@@ -143,7 +159,15 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_mib, seed, "H" if have_encode else "")
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_mib, seed, args.coder)
+        # the other coder on the same block, two untimed-region steps, for orientation
+        other = "H" if args.coder == "B" else "B"
+        ostep = step_for(other)
+        ostep()
+        t1 = time.perf_counter()
+        ostep()
+        out["other_coder"] = {"coder": other, "MBps": round(size / 1e6 / (time.perf_counter() - t1), 2),
+                              "compressed_bytes": int(comp[0])}
         print(json.dumps(out), flush=True)
     farm.close()
 

@@ -281,7 +281,7 @@ int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32
 static unsigned pick_threads(uint32_t threads) {
   if (threads) return threads;
   const unsigned hc = std::thread::hardware_concurrency();
-  return hc ? hc : 1;
+  return hc ? (hc < 64 ? hc : 64) : 1;      // sections are at most 256 and very unequal
 }
 
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { if (ctx) ctx->eng.wavelet_state = 4; }

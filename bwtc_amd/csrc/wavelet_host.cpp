@@ -3,7 +3,10 @@
 #include "wavelet_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -147,11 +150,29 @@ uint32_t findParametersForSemiFixedCodes(std::vector<LenSym>& freqs, uint64_t to
 }
 
 // ---- the tree ----------------------------------------------------------------------------
+// bit sequence of a tree node (and of a node's "gap" vector), 64 bits per word
+class PackedBits {
+ public:
+  PackedBits() : n_(0) {}
+  void push(bool b) {
+    if ((n_ & 63) == 0) w_.push_back(0);
+    w_.back() |= static_cast<uint64_t>(b) << (n_ & 63);
+    ++n_;
+  }
+  bool operator[](size_t i) const { return (w_[i >> 6] >> (i & 63)) & 1; }
+  size_t size() const { return n_; }
+  void release() { std::vector<uint64_t>().swap(w_); n_ = 0; }
+ private:
+  std::vector<uint64_t> w_;
+  size_t n_;
+};
+
 struct Node {
   int left, right;
   bool hasSymbol;
   uint32_t symbol;
-  Bits bits;
+  PackedBits bits;
+  PackedBits gaps;     // filled by the parent during the breadth-first walk
   Node() : left(-1), right(-1), hasSymbol(false), symbol(0) {}
 };
 
@@ -232,31 +253,59 @@ class Tree {
     SymbolSink sink = {codes};
     collectCodes(nodes, root, path, sink);
 
-    // pushMessage / pushRun, :1484-1494, :1251-1275
-    Bits escape;
-    for (uint64_t r = 0; r < in.n_runs; ++r) {
-      const Bits& code = codes[in.symbols[r]];
+    // pushMessage / pushRun, :1484-1494, :1251-1275.  Every run appends its symbol's code bits
+    // to the nodes on the root->leaf path and its length code to the leaf's integer subtree.
+    // Both paths are resolved once per symbol / per (symbol, small length) and then replayed.
+    std::vector<std::pair<int, uint8_t> > symPath[256];
+    int leafOf[256];
+    for (uint32_t c = 0; c < 256; ++c) {
+      leafOf[c] = -1;
+      if (codes[c].empty()) continue;
       int nd = root;
-      for (size_t i = 0; i < code.size(); ++i) {
-        nodes[nd].bits.push_back(code[i]);
-        nd = code[i] ? nodes[nd].right : nodes[nd].left;
+      for (size_t i = 0; i < codes[c].size(); ++i) {
+        symPath[c].push_back(std::make_pair(nd, codes[c][i]));
+        nd = codes[c][i] ? nodes[nd].right : nodes[nd].left;
       }
+      leafOf[c] = nd;
+    }
+    const uint32_t kCachedLengths = 512;
+    std::vector<std::pair<int, uint8_t> > steps;                  // replay pool
+    std::vector<std::pair<uint32_t, uint32_t> > cache(256 * kCachedLengths, std::make_pair(0u, 0u));
+    std::vector<std::pair<int, uint8_t> > scratch;
+    Bits lengthCode;
+    for (uint64_t r = 0; r < in.n_runs; ++r) {
+      const uint32_t c = in.symbols[r];
+      const std::vector<std::pair<int, uint8_t> >& sp = symPath[c];
+      for (size_t i = 0; i < sp.size(); ++i) nodes[sp[i].first].bits.push(sp[i].second);
       const uint32_t len = in.starts[r + 1] - in.starts[r];
+      std::pair<uint32_t, uint32_t>* slot = len < kCachedLengths ? &cache[c * kCachedLengths + len] : 0;
+      if (slot && slot->second) {
+        const std::pair<int, uint8_t>* q = &steps[slot->first];
+        for (uint32_t i = 0; i < slot->second; ++i) nodes[q[i].first].bits.push(q[i].second);
+        continue;
+      }
       std::map<uint32_t, Bits>::const_iterator it = integerCodes.find(len);
       if (it == integerCodes.end()) {
-        escape = integerCodes[0];
-        fixedIntegerCode(escape, len, W);
-        pushBelow(nd, escape, len);
+        lengthCode = integerCodes[0];
+        fixedIntegerCode(lengthCode, len, W);
       } else {
-        pushBelow(nd, it->second, len);
+        lengthCode = it->second;
+      }
+      scratch.clear();
+      pushBelow(leafOf[c], lengthCode, len, scratch);
+      if (slot) {
+        slot->first = static_cast<uint32_t>(steps.size());
+        slot->second = static_cast<uint32_t>(scratch.size());
+        steps.insert(steps.end(), scratch.begin(), scratch.end());
       }
     }
   }
 
-  // pushBits(node, bits, symbol), :1228-1249
-  void pushBelow(int nd, const Bits& bits, uint32_t symbol) {
+  // pushBits(node, bits, symbol), :1228-1249; `path` receives the (node, bit) steps taken
+  void pushBelow(int nd, const Bits& bits, uint32_t symbol, std::vector<std::pair<int, uint8_t> >& path) {
     for (size_t i = 0; i + 1 < bits.size(); ++i) {
-      nodes[nd].bits.push_back(bits[i]);
+      nodes[nd].bits.push(bits[i]);
+      path.push_back(std::make_pair(nd, bits[i]));
       int next = bits[i] ? nodes[nd].right : nodes[nd].left;
       if (next < 0) {
         next = add(false, 0);
@@ -264,7 +313,8 @@ class Tree {
       }
       nd = next;
     }
-    nodes[nd].bits.push_back(bits.back());
+    nodes[nd].bits.push(bits.back());
+    path.push_back(std::make_pair(nd, bits.back()));
     if (bits.back()) { if (nodes[nd].right < 0) { const int c = add(true, symbol); nodes[nd].right = c; } }
     else if (nodes[nd].left < 0) { const int c = add(true, symbol); nodes[nd].left = c; }
   }
@@ -311,56 +361,59 @@ class Tree {
   //   v.integer(bit)       bit coded with the integer model
   //   v.resetInternal()    before every internal node;  v.resetIntegerLevel() before every level
   template <typename Visitor>
-  void walk(Visitor& v) const {
-    std::deque<std::pair<int, Bits> > queue;
-    std::deque<int> integerNodes;
+  void walk(Visitor& v) {
+    std::deque<int> queue, integerNodes;
     {
-      const Node& r = nodes[root];
-      Bits leftGaps, rightGaps;
+      Node& r = nodes[root];
+      PackedBits* leftGaps = r.left >= 0 ? &nodes[r.left].gaps : 0;
+      PackedBits* rightGaps = r.right >= 0 ? &nodes[r.right].gaps : 0;
       bool prev = !r.bits[0];
-      for (size_t i = 0; i < r.bits.size(); ++i) {
+      for (size_t i = 0, n = r.bits.size(); i < n; ++i) {
         const bool bit = r.bits[i];
         v.pm(bit);
-        (bit ? rightGaps : leftGaps).push_back(prev != bit);
+        (bit ? rightGaps : leftGaps)->push(prev != bit);
         prev = bit;
       }
-      if (r.left >= 0) { if (nodes[r.left].hasSymbol) integerNodes.push_back(r.left); else queue.push_back(std::make_pair(r.left, leftGaps)); }
-      if (r.right >= 0) { if (nodes[r.right].hasSymbol) integerNodes.push_back(r.right); else queue.push_back(std::make_pair(r.right, rightGaps)); }
+      if (r.left >= 0) { if (nodes[r.left].hasSymbol) integerNodes.push_back(r.left); else queue.push_back(r.left); }
+      if (r.right >= 0) { if (nodes[r.right].hasSymbol) integerNodes.push_back(r.right); else queue.push_back(r.right); }
     }
     while (!queue.empty()) {
       v.resetInternal();
-      const int id = queue.front().first;
-      const Bits gaps = queue.front().second;
+      Node& nd = nodes[queue.front()];
       queue.pop_front();
-      const Node& nd = nodes[id];
+      const PackedBits& gaps = nd.gaps;
       const bool leftSym = nodes[nd.left].hasSymbol, rightSym = nodes[nd.right].hasSymbol;
+      const size_t n = nd.bits.size();
       bool prev = !nd.bits[0];
       if (leftSym && rightSym) {
-        for (size_t i = 0; i < nd.bits.size(); ++i) if (gaps[i]) v.gap(nd.bits[i], false);
+        for (size_t i = 0; i < n; ++i) if (gaps[i]) v.gap(nd.bits[i], false);
         integerNodes.push_back(nd.left);
         integerNodes.push_back(nd.right);
       } else if (leftSym) {
-        Bits rightGaps;
-        for (size_t i = 0; i < nd.bits.size(); ++i) {
-          const bool bit = nd.bits[i];
-          if (bit) rightGaps.push_back(prev != bit || gaps[i]);
-          if (prev || gaps[i]) { if (gaps[i]) v.gap(bit, true); else v.pm(bit); }
+        PackedBits& rightGaps = nodes[nd.right].gaps;
+        for (size_t i = 0; i < n; ++i) {
+          const bool bit = nd.bits[i], g = gaps[i];
+          if (bit) rightGaps.push(prev != bit || g);
+          if (prev || g) { if (g) v.gap(bit, true); else v.pm(bit); }
           prev = bit;
         }
-        queue.push_back(std::make_pair(nd.right, rightGaps));
+        queue.push_back(nd.right);
         integerNodes.push_back(nd.left);
       } else if (!rightSym) {
-        Bits leftGaps, rightGaps;
-        for (size_t i = 0; i < nd.bits.size(); ++i) {
-          const bool bit = nd.bits[i];
-          if (gaps[i]) v.gap(bit, true); else v.pm(bit);
-          (bit ? rightGaps : leftGaps).push_back(prev != bit || gaps[i]);
+        PackedBits& leftGaps = nodes[nd.left].gaps;
+        PackedBits& rightGaps = nodes[nd.right].gaps;
+        for (size_t i = 0; i < n; ++i) {
+          const bool bit = nd.bits[i], g = gaps[i];
+          if (g) v.gap(bit, true); else v.pm(bit);
+          (bit ? rightGaps : leftGaps).push(prev != bit || g);
           prev = bit;
         }
-        queue.push_back(std::make_pair(nd.left, leftGaps));
-        queue.push_back(std::make_pair(nd.right, rightGaps));
+        queue.push_back(nd.left);
+        queue.push_back(nd.right);
       }
+      nd.gaps.release();
     }
+    for (size_t i = 0; i < nodes.size(); ++i) nodes[i].gaps.release();   // symbol leaves' unused vectors
     std::deque<int> lefts, rights;
     while (!integerNodes.empty() || !lefts.empty() || !rights.empty()) {
       integerNodes.insert(integerNodes.end(), lefts.begin(), lefts.end());
@@ -370,7 +423,7 @@ class Tree {
       while (!integerNodes.empty()) {
         const Node& nd = nodes[integerNodes.front()];
         integerNodes.pop_front();
-        for (size_t i = 0; i < nd.bits.size(); ++i) v.integer(nd.bits[i]);
+        for (size_t i = 0, n = nd.bits.size(); i < n; ++i) v.integer(nd.bits[i]);
         if (nd.left >= 0 && (!nodes[nd.left].hasSymbol || nodes[nd.left].symbol == 0)) lefts.push_back(nd.left);
         if (nd.right >= 0 && (!nodes[nd.right].hasSymbol || nodes[nd.right].symbol == 0)) rights.push_back(nd.right);
       }
@@ -419,11 +472,20 @@ struct RangeCoder {                                                   // BitEnco
   void finish() { out->push_back(static_cast<uint8_t>(low >> 24)); out->insert(out->end(), 3, 255); low = 0; high = 0xFFFFFFFFu; }
 };
 
-// visitor 1: only the main model's state, for all eight possible starting states at once
+// visitor 1: only the main model's state, as a function of the (unknown) starting state.  The
+// eight images collapse to one value after the first change of bit value, from then on a
+// single state is tracked.
 struct StateTracker {
   uint32_t to[8];
-  StateTracker() { for (uint32_t i = 0; i < 8; ++i) to[i] = i; }
-  void step(bool bit) { for (uint32_t i = 0; i < 8; ++i) to[i] = nextState(8, to[i], bit); }
+  bool uniform;
+  StateTracker() : uniform(false) { for (uint32_t i = 0; i < 8; ++i) to[i] = i; }
+  void step(bool bit) {
+    if (uniform) { to[0] = nextState(8, to[0], bit); return; }
+    bool same = true;
+    for (uint32_t i = 0; i < 8; ++i) { to[i] = nextState(8, to[i], bit); same = same && to[i] == to[0]; }
+    uniform = same;
+  }
+  uint32_t image(uint32_t start) const { return uniform ? to[0] : to[start]; }
   void pm(bool bit) { step(bit); }
   void gap(bool bit, bool state) { if (state) step(bit); }
   void integer(bool) {}
@@ -451,12 +513,14 @@ struct Coder {
   void resetIntegerLevel() { ints.reset(); }
 };
 
+// runs f(i) for every i on a small thread pool, heaviest items first
 template <typename F>
-void parallelFor(size_t count, unsigned threads, F f) {
+void parallelFor(size_t count, unsigned threads, const uint64_t* weight, F f) {
   if (threads <= 1 || count <= 1) { for (size_t i = 0; i < count; ++i) f(i); return; }
   std::vector<std::thread> pool;
   std::vector<size_t> order(count);
   for (size_t i = 0; i < count; ++i) order[i] = i;
+  if (weight) std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
   size_t next = 0;
   std::mutex* m = new std::mutex();
   auto worker = [&]() {
@@ -475,12 +539,16 @@ void parallelFor(size_t count, unsigned threads, F f) {
 
 void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, uint32_t* fsm8_state,
                     std::vector<SectionOutput>* out) {
+  const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
+  const auto t0 = std::chrono::steady_clock::now();
   const size_t n = sections.size();
   std::vector<Tree> trees(n);
   std::vector<StateTracker> trans(n);
   out->assign(n, SectionOutput());
   // pass 1 (parallel): trees, headers, state transitions
-  parallelFor(n, threads, [&](size_t s) {
+  std::vector<uint64_t> weight(n);
+  for (size_t s = 0; s < n; ++s) weight[s] = sections[s].n_runs;
+  parallelFor(n, threads, weight.data(), [&](size_t s) {
     if (sections[s].n_runs == 0) return;
     trees[s].build(sections[s]);
     std::vector<uint8_t>& bytes = (*out)[s].bytes;
@@ -488,19 +556,26 @@ void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, 
     trees[s].shape(bytes);
     trees[s].walk(trans[s]);
   });
+  const auto t1 = std::chrono::steady_clock::now();
   // the one carried value: the main model's state at the start of every section
   std::vector<uint32_t> start(n);
   uint32_t state = *fsm8_state;
-  for (size_t s = 0; s < n; ++s) { start[s] = state; if (sections[s].n_runs) state = trans[s].to[state]; }
+  for (size_t s = 0; s < n; ++s) { start[s] = state; if (sections[s].n_runs) state = trans[s].image(state); }
   *fsm8_state = state;
   // pass 2 (parallel): range coding
-  parallelFor(n, threads, [&](size_t s) {
+  parallelFor(n, threads, weight.data(), [&](size_t s) {
     if (sections[s].n_runs == 0) return;
     Coder coder(start[s], &(*out)[s].bytes);
     trees[s].walk(coder);
     coder.rc.finish();                                                // endContextBlock, WaveletCoders.cpp:62-68
     Tree().nodes.swap(trees[s].nodes);
   });
+  if (debug) {
+    const auto t2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "wavelet host: build+state pass %.3f s, coding pass %.3f s, %u threads, %zu sections\n",
+                 std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
+                 threads, n);
+  }
 }
 
 }  // namespace wavelet

@@ -169,6 +169,16 @@ def oracle_compress_H(data, block_size, sp=8):
     return out[:n].copy()
 
 
+def oracle_wavelet_encode_block(bwt, lf, freqs):
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    lf = np.ascontiguousarray(lf, dtype=np.uint32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    cap = lib().orc_compress_bound(bwt.size)
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_wavelet_encode_block(_ptr(bwt), bwt.size, _ptr(lf), lf.size, _ptr(freqs), _ptr(out), cap)
+    return out[:n].copy()
+
+
 def oracle_compress_B(data, block_size, sp=8):
     data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     data = np.ascontiguousarray(data)
