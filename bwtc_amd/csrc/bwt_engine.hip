@@ -481,6 +481,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   {
     const char* e = std::getenv("BWTC_HIP_SORT");
     use_sweep = e && std::strcmp(e, "sweep") == 0;
+    const char* w = std::getenv("BWTC_HIP_WAVELET");
+    wavelet_on_host = w && std::strcmp(w, "host") == 0;
   }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
@@ -495,6 +497,9 @@ void BwtEngine::release() {
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);
   if (h_stage) (void)hipHostFree(h_stage);
+  if (d_wt) (void)hipFree(d_wt);
+  if (h_wt) (void)hipHostFree(h_wt);
+  d_wt = nullptr; h_wt = nullptr; wt_bytes = 0; h_wt_bytes = 0;
   if (ev_begin) (void)hipEventDestroy(ev_begin);
   if (ev_end) (void)hipEventDestroy(ev_end);
   for (int i = 0; i < kMaxSortEvents; ++i) if (ev_sort[i]) (void)hipEventDestroy(ev_sort[i]);

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "bwtc_hip.h"
 #include "radix_sort.hpp"
+#include "wavelet_host.hpp"
 #include <utility>
 #include <vector>
 
@@ -57,6 +58,12 @@ struct BwtEngine {
   u32* d_small = nullptr;  // [0..255] freqs, [256..511] lf, [512] pidx, [520..521] counts
   u32* h_small = nullptr;  // pinned mirror of d_small
   u8* h_stage = nullptr;   // pinned staging, cap + 32
+  void* d_wt = nullptr;    // wavelet stream workspace, sized by the block's step count (wavelet_tree.hip)
+  u64 wt_bytes = 0;
+  u8* h_wt = nullptr;      // pinned: tables up, packed streams down
+  u64 h_wt_bytes = 0;
+  u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
+  bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
 
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   static constexpr int kMaxSortEvents = 160;
@@ -70,6 +77,7 @@ struct BwtEngine {
   static u64 workspace_bytes(u32 max_block);
   int init(int dev, u32 max_block_size);
   void release();
+  int reserve_wavelet(u64 device_bytes, u64 host_bytes);
 
   // Sorts the suffixes of d_T[0..n-1]; on return d_SA holds the suffix array and d_rank
   // its inverse.  d_T must be followed by >= 8 zero bytes.
@@ -109,6 +117,12 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
 // 112-157, 159-163) for a device-resident transformed block.  Run scanning on the GPU, tree
 // building and range coding on `threads` host threads (wavelet_host.cpp); *fsm8_state is the
 // probability model's carried state (4 for a fresh encoder).  The record goes to host memory.
+// Steps of all runs of the block sorted into coding order, gap flags derived, skipped bits
+// dropped (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
+int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
+                           const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
+                           const u8** codes);
+
 int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                           const u32* freqs, unsigned threads, u32* fsm8_state,
                           std::vector<u8>* record);

@@ -15,6 +15,9 @@
 #include "wavelet_host.hpp"
 #include "scan.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -644,25 +647,57 @@ int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
   for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
   if (size && nsec) {
-    // the runs themselves: symbols and start offsets, left in the workspace by the scanner
     const u32 n_runs = st.first_run[nsec];
-    std::vector<u8> run_sym(n_runs);
-    std::vector<u32> run_start((size_t)n_runs + 1);
-    BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
-    BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
-    BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
     std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
     for (u32 s = 0; s < nsec; ++s) {
       bwtc::wavelet::SectionRuns& r = secs[s];
-      r.symbols = run_sym.data() + st.first_run[s];
-      r.starts = run_start.data() + st.first_run[s];
+      r.symbols = nullptr;
+      r.starts = nullptr;
       r.n_runs = st.first_run[s + 1] - st.first_run[s];
       r.run_freqs = &st.run_freqs[(size_t)s * 256];
       r.dist = st.dist[s].data();
       r.n_dist = st.dist[s].size();
     }
     std::vector<bwtc::wavelet::SectionOutput> outs;
-    bwtc::wavelet::encodeSections(secs, threads, fsm8_state, &outs);
+    // Tree bit vectors and traversal on the GPU (wavelet_tree.hip), models + range coder on the
+    // host.  Shapes the device path does not take (planStreams) and BWTC_HIP_WAVELET=host go
+    // through the host's own tree builder instead; both are this library's code and give the
+    // same bytes.
+    const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    bwtc::wavelet::StreamPlan plan;
+    bool on_device = !e.wavelet_on_host && bwtc::wavelet::planStreams(secs, &plan) &&
+                     plan.max_elements + (1u << 16) < (1ull << 32);
+    if (on_device) {
+      std::vector<u32> coded_pos;
+      const u8* codes = nullptr;
+      const auto t1 = std::chrono::steady_clock::now();
+      rc = wavelet_streams_device(e, n_runs, st.first_run, plan, &coded_pos, &codes);
+      if (rc) return rc;
+      const auto t2 = std::chrono::steady_clock::now();
+      bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes, threads, fsm8_state, &outs);
+      if (debug) {
+        const auto t3 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; plan %.1f ms, device streams %.1f ms, "
+                     "models + range coder %.1f ms on %u threads\n", n_runs, (unsigned long long)e.wt_elements,
+                     (unsigned long long)e.wt_coded, plan.group_type.size(),
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                     std::chrono::duration<double, std::milli>(t3 - t2).count(), threads);
+      }
+    } else {
+      // the runs themselves: symbols and start offsets, left in the workspace by the scanner
+      std::vector<u8> run_sym(n_runs);
+      std::vector<u32> run_start((size_t)n_runs + 1);
+      BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
+      BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
+      BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+      for (u32 s = 0; s < nsec; ++s) {
+        secs[s].symbols = run_sym.data() + st.first_run[s];
+        secs[s].starts = run_start.data() + st.first_run[s];
+      }
+      bwtc::wavelet::encodeSections(secs, threads, fsm8_state, &outs);
+    }
     for (u32 s = 0; s < nsec; ++s) rec.insert(rec.end(), outs[s].bytes.begin(), outs[s].bytes.end());
   }
   const u64 len = rec.size() - 6;                                   // finishBlock

@@ -228,8 +228,9 @@ class Tree {
   struct SymbolSink { Bits* codes; void operator()(uint32_t s, const Bits& p) { codes[s] = p; } };
   struct IntegerSink { std::map<uint32_t, Bits>* m; void operator()(uint32_t s, const Bits& p) { (*m)[s] = p; } };
 
-  // WaveletTree(const byte*, size_t), :294-360, from the GPU's run statistics
-  void build(const SectionRuns& in) {
+  // WaveletTree(const byte*, size_t), :294-360, from the GPU's run statistics: the two code
+  // sets and the symbol tree
+  void buildCodes(const SectionRuns& in) {
     std::vector<LenSym> lengths;
     for (uint32_t c = 0; c < 256; ++c) if (in.run_freqs[c]) lengths.push_back(LenSym(in.run_freqs[c], c));
     calculateCodeLengths(lengths, false);
@@ -252,7 +253,19 @@ class Tree {
     Bits path;
     SymbolSink sink = {codes};
     collectCodes(nodes, root, path, sink);
+  }
 
+  // the code of a run length: its own prefix code, or the escape code + the fixed code
+  Bits lengthCodeOf(uint32_t len) {
+    std::map<uint32_t, Bits>::const_iterator it = integerCodes.find(len);
+    if (it != integerCodes.end()) return it->second;
+    Bits code = integerCodes[0];
+    fixedIntegerCode(code, len, W);
+    return code;
+  }
+
+  void build(const SectionRuns& in) {
+    buildCodes(in);
     // pushMessage / pushRun, :1484-1494, :1251-1275.  Every run appends its symbol's code bits
     // to the nodes on the root->leaf path and its length code to the leaf's integer subtree.
     // Both paths are resolved once per symbol / per (symbol, small length) and then replayed.
@@ -284,13 +297,7 @@ class Tree {
         for (uint32_t i = 0; i < slot->second; ++i) nodes[q[i].first].bits.push(q[i].second);
         continue;
       }
-      std::map<uint32_t, Bits>::const_iterator it = integerCodes.find(len);
-      if (it == integerCodes.end()) {
-        lengthCode = integerCodes[0];
-        fixedIntegerCode(lengthCode, len, W);
-      } else {
-        lengthCode = it->second;
-      }
+      lengthCode = lengthCodeOf(len);
       scratch.clear();
       pushBelow(leafOf[c], lengthCode, len, scratch);
       if (slot) {
@@ -443,33 +450,144 @@ inline uint32_t nextState(uint32_t states, uint32_t cur, bool bit) {  // FSM.hpp
   return cur < states / 2 ? (cur ? cur - 1 : 0) : (states - 1) / 2;
 }
 
-struct Predictor {                                                    // UnbiasedPredictor, BitPredictors.hpp:37-65
-  uint16_t p, lo, initial; unsigned delay;
-  void set(uint16_t lo_, unsigned delay_, uint16_t initial_) { lo = lo_; delay = delay_; initial = initial_; p = initial_; }
-  void update(bool bit) {
-    const uint16_t top = static_cast<uint16_t>(4096 - lo);
-    if (bit) p = static_cast<uint16_t>(p + ((top - p) >> delay));
-    else p = static_cast<uint16_t>(p - ((p - lo) >> delay));
+// The three models of the 'B' coder (probmodels/ProbabilityModel.cpp:38-75) and the range
+// coder (BitEncoder, BitCoders.cpp:59-113) in one flat state: 15 predictors
+// (UnbiasedPredictor, BitPredictors.hpp:37-65: p moves 1/2^delay of the way to its bound)
+// selected by three small state machines (FSM.hpp:42-67).  Written without data-dependent
+// branches, the coded bits are close to random.
+//   main     FSM8: 8 predictors, delay 4 for the two outer states, 5 otherwise; the upper four
+//            predict the inverted bit (InversePredictor); reset keeps the state (FSM.hpp:196-205)
+//   gaps     FSM<4>, delay 5;  integers  FSM<3>, delay 5, probabilities kept within [100, 3996]
+// FSM.hpp:42-67 as tables: [state][bit] -> state
+const uint8_t kNext8[8][2] = {{0, 4}, {0, 4}, {1, 4}, {2, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 7}};
+const uint8_t kNext4[4][2] = {{0, 2}, {0, 2}, {1, 3}, {1, 3}};
+const uint8_t kNext3[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+
+struct Coder {
+  enum { kMain = 0, kGaps = 8, kInts = 12 };
+  uint16_t p[16];
+  uint8_t next8[8][2], next4[4][2], next3[3][2];
+  uint32_t mcur, gcur, icur;
+  uint32_t low, high;
+  std::vector<uint8_t>* out;
+  size_t used;                                                         // bytes of *out that are final
+
+  Coder(uint32_t startState, std::vector<uint8_t>* o) : mcur(startState), gcur(2), icur(1), low(0), high(0xFFFFFFFFu), out(o), used(o->size()), w(0) {
+    for (uint32_t c = 0; c < 8; ++c) for (uint32_t b = 0; b < 2; ++b) next8[c][b] = static_cast<uint8_t>(nextState(8, c, b));
+    for (uint32_t c = 0; c < 4; ++c) for (uint32_t b = 0; b < 2; ++b) next4[c][b] = static_cast<uint8_t>(nextState(4, c, b));
+    for (uint32_t c = 0; c < 3; ++c) for (uint32_t b = 0; b < 2; ++b) next3[c][b] = static_cast<uint8_t>(nextState(3, c, b));
+    resetMain(); resetGaps(); resetInts();
   }
-};
+  void resetMain() {
+    static const uint16_t init[8] = {2400, 2300, 2200, 2100, 2100, 2200, 2300, 2400};
+    for (int i = 0; i < 8; ++i) p[kMain + i] = init[i];
+  }
+  void resetGaps() { for (int i = 0; i < 4; ++i) p[kGaps + i] = 2048; gcur = 2; }
+  void resetInts() { for (int i = 0; i < 3; ++i) p[kInts + i] = 2048; icur = 1; }
 
-struct Fsm {                                                          // FSM<N,...> and FSM8
-  bool fsm8; uint32_t n, cur; Predictor st[8];
-  void reset() { for (uint32_t i = 0; i < n; ++i) st[i].p = st[i].initial; if (!fsm8) cur = n / 2; }
-  uint16_t probabilityOfOne() const { return (fsm8 && cur >= 4) ? static_cast<uint16_t>(4096 - st[cur].p) : st[cur].p; }
-  void updateState(bool bit) { cur = nextState(n, cur, bit); }
-  void update(bool bit) { st[cur].update((fsm8 && cur >= 4) ? !bit : bit); updateState(bit); }
-};
+  // room for `elements` more coded bits (at most four bytes leave the coder per bit)
+  void ensure(size_t elements) { if (out->size() - used < 4 * elements + 8) out->resize(used + 4 * elements + 8 + out->size() / 2); }
 
-struct RangeCoder {                                                   // BitEncoder, BitCoders.cpp:59-113
-  uint32_t low, high; std::vector<uint8_t>* out;
-  void encode(bool bit, uint16_t p1) {
+  uint8_t* w;                                                          // write position (hot loops only)
+  inline void encode(uint32_t bit, uint32_t p1) {
     const uint32_t size = high - low - 1;
     const uint32_t split = low + (size >> 12) * p1 + (((size & 4095u) * p1 + 2048u) >> 12);
-    if (bit) high = split; else low = split + 1;
-    while (((low ^ high) & 0xFF000000u) == 0) { out->push_back(static_cast<uint8_t>(low >> 24)); low <<= 8; high = (high << 8) + 255; }
+    high = bit ? split : high;
+    low = bit ? low : split + 1;
+    while (((low ^ high) & 0xFF000000u) == 0) { *w++ = static_cast<uint8_t>(low >> 24); low <<= 8; high = (high << 8) + 255; }
   }
-  void finish() { out->push_back(static_cast<uint8_t>(low >> 24)); out->insert(out->end(), 3, 255); low = 0; high = 0xFFFFFFFFu; }
+  // Codes elements [b, e) of one group.  All state lives in locals for the loop: the byte
+  // stores could alias the members otherwise and every field would stay in memory.
+  template <int TYPE>
+  void run(const uint8_t* codes, uint64_t b, uint64_t e) {
+    const uint64_t kChunk = 8192;
+    uint32_t lo = low, hi = high, mc = mcur, gc = gcur, ic = icur;
+    uint32_t q[16];
+    for (int i = 0; i < 16; ++i) q[i] = p[i];
+    for (; b < e; b += kChunk) {
+      const uint64_t ce = std::min(e, b + kChunk);
+      ensure(kChunk);
+      uint8_t* o = out->data() + used;
+      for (uint64_t i = b; i < ce; ++i) {
+        const uint32_t v = (codes[i >> 2] >> ((i & 3) * 2)) & 3u;
+        const uint32_t bit = v & 1u;
+        uint32_t slot, inv = 0, delay = 5, floor = 2;
+        if (TYPE == kRoot) { slot = kMain + mc; inv = mc >> 2; delay = (mc == 0 || mc == 7) ? 4 : 5; }
+        else if (TYPE == kBothLeaves) { slot = kGaps + gc; }
+        else if (TYPE == kInteger) { slot = kInts + ic; floor = 100; }
+        else {
+          const uint32_t gap = v >> 1;
+          slot = gap ? kGaps + gc : kMain + mc;
+          inv = gap ? 0u : mc >> 2;
+          delay = (!gap && (mc == 0 || mc == 7)) ? 4 : 5;
+        }
+        const uint32_t pr = q[slot];
+        const uint32_t p1 = inv ? 4096u - pr : pr;
+        const uint32_t size = hi - lo - 1;
+        const uint32_t split = lo + (size >> 12) * p1 + (((size & 4095u) * p1 + 2048u) >> 12);
+        hi = bit ? split : hi;
+        lo = bit ? lo : split + 1;
+        while (((lo ^ hi) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; hi = (hi << 8) + 255; }
+        const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
+        q[slot] = (bit ^ inv) ? up : down;
+        if (TYPE == kRoot) mc = kNext8[mc][bit];
+        else if (TYPE == kBothLeaves) gc = kNext4[gc][bit];
+        else if (TYPE == kInteger) ic = kNext3[ic][bit];
+        else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
+      }
+      used = static_cast<size_t>(o - out->data());
+    }
+    low = lo; high = hi; mcur = mc; gcur = gc; icur = ic;
+    for (int i = 0; i < 16; ++i) p[i] = static_cast<uint16_t>(q[i]);
+  }
+  static inline uint16_t moved(uint32_t q, uint32_t toward_one, uint32_t lo, uint32_t delay) {
+    const uint32_t up = q + (((4096u - lo) - q) >> delay), down = q - ((q - lo) >> delay);
+    return static_cast<uint16_t>(toward_one ? up : down);
+  }
+  inline void pmFast(uint32_t bit) {
+    const uint32_t inv = mcur >> 2, q = p[kMain + mcur];
+    encode(bit, inv ? 4096u - q : q);
+    p[kMain + mcur] = moved(q, bit ^ inv, 2, (mcur == 0 || mcur == 7) ? 4 : 5);
+    mcur = next8[mcur][bit];
+  }
+  inline void gapFast(uint32_t bit, bool state) {
+    const uint32_t q = p[kGaps + gcur];
+    encode(bit, q);
+    p[kGaps + gcur] = moved(q, bit, 2, 5);
+    gcur = next4[gcur][bit];
+    if (state) mcur = next8[mcur][bit];
+  }
+  inline void integerFast(uint32_t bit) {
+    const uint32_t q = p[kInts + icur];
+    encode(bit, q);
+    p[kInts + icur] = moved(q, bit, 100, 5);
+    icur = next3[icur][bit];
+  }
+  // either of pm / gap(state = true), chosen by `gap` without a branch
+  inline void pmOrGapFast(uint32_t bit, uint32_t gap) {
+    const uint32_t slot = gap ? kGaps + gcur : kMain + mcur;
+    const uint32_t inv = gap ? 0u : mcur >> 2;
+    const uint32_t delay = (!gap && (mcur == 0 || mcur == 7)) ? 4 : 5;
+    const uint32_t q = p[slot];
+    encode(bit, inv ? 4096u - q : q);
+    p[slot] = moved(q, bit ^ inv, 2, delay);
+    gcur = gap ? next4[gcur][bit] : gcur;
+    mcur = next8[mcur][bit];
+  }
+  // visitor interface of Tree::walk
+  void pm(bool bit) { ensure(1); w = out->data() + used; pmFast(bit); used = static_cast<size_t>(w - out->data()); }
+  void gap(bool bit, bool state) { ensure(1); w = out->data() + used; gapFast(bit, state); used = static_cast<size_t>(w - out->data()); }
+  void integer(bool bit) { ensure(1); w = out->data() + used; integerFast(bit); used = static_cast<size_t>(w - out->data()); }
+  void resetInternal() { resetMain(); resetGaps(); }
+  void resetIntegerLevel() { resetInts(); }
+  void finish() {                                                      // BitEncoder::finish, :100-113
+    ensure(1);
+    uint8_t* o = out->data();
+    o[used++] = static_cast<uint8_t>(low >> 24);
+    o[used++] = 255; o[used++] = 255; o[used++] = 255;
+    out->resize(used);
+    low = 0; high = 0xFFFFFFFFu;
+  }
 };
 
 // visitor 1: only the main model's state, as a function of the (unknown) starting state.  The
@@ -491,26 +609,6 @@ struct StateTracker {
   void integer(bool) {}
   void resetInternal() {}
   void resetIntegerLevel() {}
-};
-
-// visitor 2: the real coder
-struct Coder {
-  Fsm main, ints, gaps; RangeCoder rc;
-  explicit Coder(uint32_t startState, std::vector<uint8_t>* out) {
-    main.fsm8 = true; main.n = 8; main.cur = startState;              // ProbabilityModel.cpp:63-75
-    main.st[0].set(2, 4, 2400); main.st[1].set(2, 5, 2300); main.st[2].set(2, 5, 2200); main.st[3].set(2, 5, 2100);
-    main.st[4].set(2, 5, 2100); main.st[5].set(2, 5, 2200); main.st[6].set(2, 5, 2300); main.st[7].set(2, 4, 2400);
-    ints.fsm8 = false; ints.n = 3; ints.cur = 1;                       // :38-41
-    for (int i = 0; i < 3; ++i) ints.st[i].set(100, 5, 2048);
-    gaps.fsm8 = false; gaps.n = 4; gaps.cur = 2;                       // :43-45
-    for (int i = 0; i < 4; ++i) gaps.st[i].set(2, 5, 2048);
-    rc.low = 0; rc.high = 0xFFFFFFFFu; rc.out = out;
-  }
-  void pm(bool bit) { rc.encode(bit, main.probabilityOfOne()); main.update(bit); }
-  void gap(bool bit, bool state) { rc.encode(bit, gaps.probabilityOfOne()); gaps.update(bit); if (state) main.updateState(bit); }
-  void integer(bool bit) { rc.encode(bit, ints.probabilityOfOne()); ints.update(bit); }
-  void resetInternal() { main.reset(); gaps.reset(); }
-  void resetIntegerLevel() { ints.reset(); }
 };
 
 // runs f(i) for every i on a small thread pool, heaviest items first
@@ -567,7 +665,7 @@ void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, 
     if (sections[s].n_runs == 0) return;
     Coder coder(start[s], &(*out)[s].bytes);
     trees[s].walk(coder);
-    coder.rc.finish();                                                // endContextBlock, WaveletCoders.cpp:62-68
+    coder.finish();                                                   // endContextBlock, WaveletCoders.cpp:62-68
     Tree().nodes.swap(trees[s].nodes);
   });
   if (debug) {
@@ -576,6 +674,284 @@ void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, 
                  std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
                  threads, n);
   }
+}
+
+
+// ---- device-built streams -------------------------------------------------------------------
+namespace {
+
+// union of the length codes of one section as a binary trie
+struct LengthTrie {
+  struct N { int child[2]; bool terminal; uint32_t group; N() : terminal(false), group(0) { child[0] = child[1] = -1; } };
+  std::vector<N> n;
+  LengthTrie() : n(1) {}
+  // false: the code is not prefix free against the ones already inserted
+  bool insert(const Bits& code) {
+    int nd = 0;
+    for (size_t i = 0; i < code.size(); ++i) {
+      if (n[nd].terminal) return false;
+      int next = n[nd].child[code[i]];
+      if (next < 0) { n.push_back(N()); next = static_cast<int>(n.size()) - 1; n[nd].child[code[i]] = next; }
+      nd = next;
+    }
+    if (n[nd].child[0] >= 0 || n[nd].child[1] >= 0) return false;
+    n[nd].terminal = true;
+    return true;
+  }
+};
+
+inline uint32_t codeAt(const uint8_t* codes, uint64_t i) { return (codes[i >> 2] >> ((i & 3) * 2)) & 3u; }
+
+}  // namespace
+
+bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
+  const size_t nsec = sections.size();
+  plan->sections.assign(nsec, StreamPlan::Section());
+  plan->group_type.clear();
+  plan->symtab.assign(nsec * 512, 0);
+  plan->lendense.assign(nsec * 2 * static_cast<size_t>(kLenDense), 0);
+  plan->over_first.assign(nsec + 1, 0);
+  plan->over.clear();
+  plan->pool.clear();
+  plan->max_elements = 0;
+  for (size_t s = 0; s < nsec; ++s) {
+    const SectionRuns& in = sections[s];
+    StreamPlan::Section& sec = plan->sections[s];
+    sec.group_base = static_cast<uint32_t>(plan->group_type.size());
+    sec.n_nodes = 0;
+    plan->over_first[s] = static_cast<uint32_t>(plan->over.size() / 4);
+    if (in.n_runs == 0) { sec.level_first.assign(1, 0); continue; }
+    Tree tree;
+    tree.buildCodes(in);
+    utils::packInteger(in.n_runs, sec.prefix);                       // bitsInRoot: one bit per run
+    tree.shape(sec.prefix);
+
+    // the nodes encodeTreeBF visits, in its order, and the order the symbol leaves are met in
+    std::vector<int> groupOf(tree.nodes.size(), -1);
+    std::vector<int> leafRank(tree.nodes.size(), -1);
+    std::vector<uint8_t> types;
+    int leaves = 0;
+    {
+      std::deque<int> queue;
+      const Node& r = tree.nodes[tree.root];
+      groupOf[tree.root] = 0; types.push_back(kRoot);
+      if (r.left >= 0) { if (tree.nodes[r.left].hasSymbol) leafRank[r.left] = leaves++; else queue.push_back(r.left); }
+      if (r.right >= 0) { if (tree.nodes[r.right].hasSymbol) leafRank[r.right] = leaves++; else queue.push_back(r.right); }
+      while (!queue.empty()) {
+        const int id = queue.front();
+        queue.pop_front();
+        const Node& nd = tree.nodes[id];
+        if (nd.left < 0 || nd.right < 0) return false;               // the reference would read out of bounds
+        const bool leftSym = tree.nodes[nd.left].hasSymbol, rightSym = tree.nodes[nd.right].hasSymbol;
+        if (leftSym && rightSym) {
+          groupOf[id] = static_cast<int>(types.size()); types.push_back(kBothLeaves);
+          leafRank[nd.left] = leaves++; leafRank[nd.right] = leaves++;
+        } else if (leftSym) {
+          groupOf[id] = static_cast<int>(types.size()); types.push_back(kLeftLeaf);
+          queue.push_back(nd.right);
+          leafRank[nd.left] = leaves++;
+        } else if (!rightSym) {
+          groupOf[id] = static_cast<int>(types.size()); types.push_back(kInner);
+          queue.push_back(nd.left); queue.push_back(nd.right);
+        }                                                            // right leaf only: dropped with its subtree (sic)
+      }
+    }
+    if (leaves > 256) return false;
+    sec.n_nodes = static_cast<uint32_t>(types.size());
+
+    // the integer levels: union trie of the section's length codes
+    LengthTrie trie;
+    std::vector<Bits> lengthCodes(in.n_dist);
+    for (size_t i = 0; i < in.n_dist; ++i) {
+      lengthCodes[i] = tree.lengthCodeOf(in.dist[i].first);
+      if (lengthCodes[i].empty() || !trie.insert(lengthCodes[i])) return false;
+    }
+    uint32_t nextGroup = sec.n_nodes;
+    {
+      std::vector<int> level(1, 0), lefts, rights;                   // next level = all lefts, then all rights
+      while (!level.empty()) {
+        sec.level_first.push_back(nextGroup);
+        lefts.clear(); rights.clear();
+        for (size_t i = 0; i < level.size(); ++i) {
+          LengthTrie::N& t = trie.n[level[i]];
+          t.group = nextGroup++;
+          if (t.child[0] >= 0 && !trie.n[t.child[0]].terminal) lefts.push_back(t.child[0]);
+          if (t.child[1] >= 0 && !trie.n[t.child[1]].terminal) rights.push_back(t.child[1]);
+        }
+        level = lefts;
+        level.insert(level.end(), rights.begin(), rights.end());
+      }
+      sec.level_first.push_back(nextGroup);
+    }
+    if (static_cast<uint64_t>(sec.group_base) + nextGroup >= kMaxGroups) return false;
+    for (uint32_t g = 0; g < nextGroup; ++g) plan->group_type.push_back(g < sec.n_nodes ? types[g] : static_cast<uint8_t>(kInteger));
+
+    // steps of every symbol: the visited nodes on its path
+    for (uint32_t c = 0; c < 256; ++c) {
+      if (tree.codes[c].empty()) continue;
+      const uint32_t off = static_cast<uint32_t>(plan->pool.size());
+      int nd = tree.root;
+      for (size_t i = 0; i < tree.codes[c].size(); ++i) {
+        const uint32_t bit = tree.codes[c][i];
+        if (groupOf[nd] >= 0)
+          plan->pool.push_back(((sec.group_base + static_cast<uint32_t>(groupOf[nd])) << kStepGroupShift) | bit);
+        nd = bit ? tree.nodes[nd].right : tree.nodes[nd].left;
+      }
+      const uint32_t steps = static_cast<uint32_t>(plan->pool.size()) - off;
+      const bool live = leafRank[nd] >= 0;
+      plan->symtab[(s * 256 + c) * 2] = off;
+      plan->symtab[(s * 256 + c) * 2 + 1] = steps | (live ? static_cast<uint32_t>(leafRank[nd]) << 8 : 0u) | (live ? 1u << 16 : 0u);
+      plan->max_elements += static_cast<uint64_t>(steps) * in.run_freqs[c];
+    }
+    // steps of every run length
+    for (size_t i = 0; i < in.n_dist; ++i) {
+      const uint32_t len = in.dist[i].first;
+      const uint32_t off = static_cast<uint32_t>(plan->pool.size());
+      int nd = 0;
+      for (size_t k = 0; k < lengthCodes[i].size(); ++k) {
+        const uint32_t bit = lengthCodes[i][k];
+        plan->pool.push_back(((sec.group_base + trie.n[nd].group) << kStepGroupShift) | bit);
+        nd = trie.n[nd].child[bit];
+      }
+      const uint32_t steps = static_cast<uint32_t>(lengthCodes[i].size());
+      if (len < kLenDense) {
+        plan->lendense[(s * kLenDense + len) * 2] = off;
+        plan->lendense[(s * kLenDense + len) * 2 + 1] = steps;
+      } else {                                                       // dist is ascending by length
+        plan->over.push_back(len); plan->over.push_back(off); plan->over.push_back(steps); plan->over.push_back(0);
+      }
+      plan->max_elements += static_cast<uint64_t>(steps) * in.dist[i].second;
+    }
+  }
+  plan->over_first[nsec] = static_cast<uint32_t>(plan->over.size() / 4);
+  return true;
+}
+
+void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, unsigned threads,
+                 uint32_t* fsm8_state, std::vector<SectionOutput>* out) {
+  const size_t nsec = plan.sections.size();
+  out->assign(nsec, SectionOutput());
+  // The main model's state is the one value carried from section to section.  It is a
+  // function of the last few bits that advanced it: two different bits in a row, or four
+  // equal ones, fix the state whatever it was before.
+  std::vector<StateTracker> trans(nsec);
+  std::vector<uint64_t> weight(nsec, 0);
+  for (size_t s = 0; s < nsec; ++s) {
+    const StreamPlan::Section& sec = plan.sections[s];
+    if (sec.level_first.size() < 2) continue;
+    weight[s] = coded_pos[sec.group_base + sec.level_first.back()] - coded_pos[sec.group_base];
+    uint8_t tail[8];
+    int have = 0;
+    for (uint32_t g = sec.n_nodes; g-- > 0 && have < 8;) {
+      if (plan.group_type[sec.group_base + g] == kBothLeaves) continue;
+      const uint64_t b = coded_pos[sec.group_base + g], e = coded_pos[sec.group_base + g + 1];
+      for (uint64_t i = e; i-- > b && have < 8;) tail[have++] = codeAt(codes, i) & 1u;
+    }
+    while (have > 0) trans[s].step(tail[--have]);
+  }
+  std::vector<uint32_t> start(nsec);
+  uint32_t state = *fsm8_state;
+  for (size_t s = 0; s < nsec; ++s) { start[s] = state; if (weight[s]) state = trans[s].image(state); }
+  *fsm8_state = state;
+
+  const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
+  std::vector<double> took(nsec, 0.0);
+  parallelFor(nsec, threads, weight.data(), [&](size_t s) {
+    const StreamPlan::Section& sec = plan.sections[s];
+    if (sec.level_first.size() < 2) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t>& bytes = (*out)[s].bytes;
+    bytes = sec.prefix;
+    Coder coder(start[s], &bytes);
+    const uint32_t* pos = coded_pos + sec.group_base;
+    for (uint32_t g = 0; g < sec.n_nodes; ++g) {
+      const uint8_t type = plan.group_type[sec.group_base + g];
+      if (type == kRoot) { coder.run<kRoot>(codes, pos[g], pos[g + 1]); continue; }
+      coder.resetInternal();
+      if (type == kBothLeaves) coder.run<kBothLeaves>(codes, pos[g], pos[g + 1]);
+      else coder.run<kInner>(codes, pos[g], pos[g + 1]);
+    }
+    for (size_t l = 0; l + 1 < sec.level_first.size(); ++l) {
+      coder.resetIntegerLevel();
+      coder.run<kInteger>(codes, pos[sec.level_first[l]], pos[sec.level_first[l + 1]]);
+    }
+    coder.finish();
+    took[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  });
+  if (debug) {
+    size_t big = 0;
+    double sum = 0;
+    for (size_t s = 0; s < nsec; ++s) { sum += took[s]; if (weight[s] > weight[big]) big = s; }
+    std::fprintf(stderr, "wavelet coder: %zu sections, %.3f s of coding in total; largest section %llu elements in %.3f s (%.2f ns each)\n",
+                 nsec, sum, (unsigned long long)weight[big], took[big], weight[big] ? took[big] * 1e9 / weight[big] : 0.0);
+  }
+}
+
+bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>& sections,
+                         std::vector<uint32_t>* coded_pos, std::vector<uint8_t>* codes) {
+  const size_t nsec = sections.size();
+  std::vector<uint32_t> key;                                         // expand
+  std::vector<uint32_t> runOff, runSymSteps;
+  for (size_t s = 0; s < nsec; ++s) {
+    for (uint64_t r = 0; r < sections[s].n_runs; ++r) {
+      const uint32_t c = sections[s].symbols[r], len = sections[s].starts[r + 1] - sections[s].starts[r];
+      const uint32_t off = plan.symtab[(s * 256 + c) * 2], meta = plan.symtab[(s * 256 + c) * 2 + 1];
+      runOff.push_back(static_cast<uint32_t>(key.size()));
+      runSymSteps.push_back(meta & 255u);
+      for (uint32_t i = 0; i < (meta & 255u); ++i) key.push_back(plan.pool[off + i]);
+      if (!(meta >> 16)) continue;
+      uint32_t loff = 0, lsteps = 0;
+      if (len < kLenDense) {
+        loff = plan.lendense[(s * kLenDense + len) * 2]; lsteps = plan.lendense[(s * kLenDense + len) * 2 + 1];
+      } else {
+        for (uint32_t i = plan.over_first[s]; i < plan.over_first[s + 1]; ++i)
+          if (plan.over[i * 4] == len) { loff = plan.over[i * 4 + 1]; lsteps = plan.over[i * 4 + 2]; }
+      }
+      if (lsteps == 0) return false;
+      for (uint32_t i = 0; i < lsteps; ++i) key.push_back(plan.pool[loff + i] | (((meta >> 8) & 255u) << kStepLeafShift));
+    }
+  }
+  const size_t n = key.size();
+  std::vector<uint32_t> order(n);                                    // sort
+  for (size_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (key[a] >> 1) < (key[b] >> 1); });
+  const size_t groups = plan.group_type.size();
+  std::vector<uint8_t> flag(n, 0);                                   // gaps
+  std::vector<uint32_t> groupStart(groups + 1, 0xFFFFFFFFu);
+  for (size_t j = 0; j < n; ++j) {
+    const uint32_t k = key[order[j]], g = k >> kStepGroupShift;
+    const bool first = j == 0 || (key[order[j - 1]] >> kStepGroupShift) != g;
+    if (first) groupStart[g] = static_cast<uint32_t>(j);
+    if (plan.group_type[g] != kInteger) flag[order[j]] = first || ((k ^ key[order[j - 1]]) & 1u);
+  }
+  for (size_t r = 0; r < runOff.size(); ++r) {
+    uint8_t g = 0;
+    for (uint32_t i = 0; i < runSymSteps[r]; ++i) { const uint8_t c = flag[runOff[r] + i]; flag[runOff[r] + i] = g; g |= c; }
+  }
+  coded_pos->assign(groups + 1, 0);                                   // select + pack
+  codes->clear();
+  uint64_t coded = 0;
+  for (size_t j = 0; j < n; ++j) {
+    const uint32_t k = key[order[j]], g = k >> kStepGroupShift, bit = k & 1u;
+    const bool first = j == 0 || (key[order[j - 1]] >> kStepGroupShift) != g;
+    if (first) (*coded_pos)[g] = static_cast<uint32_t>(coded);
+    const uint8_t type = plan.group_type[g];
+    uint32_t gap = 0;
+    bool keep = true;
+    if (type != kRoot && type != kInteger) {
+      gap = flag[order[j]];
+      const uint32_t prev = first ? (bit ^ 1u) : (key[order[j - 1]] & 1u);
+      if (type == kBothLeaves) keep = gap != 0;
+      else if (type == kLeftLeaf) keep = (prev | gap) != 0;
+    }
+    if (!keep) continue;
+    if ((coded & 3) == 0) codes->push_back(0);
+    codes->back() |= static_cast<uint8_t>((bit | (gap << 1)) << ((coded & 3) * 2));
+    ++coded;
+  }
+  (*coded_pos)[groups] = static_cast<uint32_t>(coded);
+  for (size_t g = groups; g-- > 0;) if (groupStart[g] == 0xFFFFFFFFu) (*coded_pos)[g] = (*coded_pos)[g + 1];
+  return true;
 }
 
 }  // namespace wavelet

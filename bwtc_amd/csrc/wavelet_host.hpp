@@ -38,5 +38,56 @@ struct SectionOutput {
 void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads,
                     uint32_t* fsm8_state, std::vector<SectionOutput>* out);
 
+// ---- device-built streams -------------------------------------------------------------------
+// With the tree shapes known (they follow from the run statistics alone) every coded bit has a
+// fixed place: the bits of one tree node are the bits its runs contribute, in run order, and
+// the nodes are coded in the breadth-first order of encodeTreeBF (WaveletTree.hpp:637-809),
+// the integer subtrees level by level after the symbol tree.  planStreams() numbers those
+// places ("groups") and emits lookup tables from which the GPU (wavelet_tree.hip) expands every
+// run into (group, bit) steps, sorts them into coding order, derives the gap flags and drops
+// the bits encodeTreeBF skips.  codeStreams() then only runs the adaptive models and the range
+// coder over the finished streams.
+constexpr uint32_t kStepBitShift = 0;      // step word: bit 0 = the bit,
+constexpr uint32_t kStepLeafShift = 1;     //   bits 1..8 = rank of the symbol leaf (integer steps),
+constexpr uint32_t kStepGroupShift = 9;    //   bits 9..  = group number (block-wide)
+constexpr uint32_t kMaxGroups = 1u << 23;
+constexpr uint32_t kLenDense = 4096;       // run lengths below this are looked up in a dense table
+
+enum GroupType { kRoot = 0, kBothLeaves = 1, kLeftLeaf = 2, kInner = 3, kInteger = 4 };
+
+struct StreamPlan {
+  struct Section {
+    std::vector<uint8_t> prefix;           // packed bitsInRoot + tree shape
+    uint32_t group_base;                   // first group of the section
+    uint32_t n_nodes;                      // symbol-tree nodes that are coded (groups 0..n_nodes-1)
+    std::vector<uint32_t> level_first;     // integer levels: first group of each level, then the end
+  };
+  std::vector<Section> sections;
+  std::vector<uint8_t> group_type;         // per block-wide group
+  // device tables
+  std::vector<uint32_t> symtab;            // [section][256] x {pool offset, steps | leaf rank << 8 | live << 16}
+  std::vector<uint32_t> lendense;          // [section][kLenDense] x {pool offset, steps}
+  std::vector<uint32_t> over_first;        // [section + 1] ranges into `over`
+  std::vector<uint32_t> over;              // x {length, pool offset, steps, 0}, ascending by length
+  std::vector<uint32_t> pool;              // step words
+  uint64_t max_elements;                   // upper bound of the number of steps of the block
+};
+
+// false: the shapes need something the device path does not do (too many groups, a length code
+// that is a prefix of another); the caller then uses encodeSections().
+bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan);
+
+// coded_pos[g] = index of group g's first coded element in `codes` (2 bits per element, bit 0 =
+// the bit, bit 1 = the gap flag), coded_pos[groups] = total.
+void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes,
+                 unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out);
+
+// What wavelet_tree.hip computes, stated with plain host loops (expand, stable sort, gap flags,
+// select, pack).  Only the host-only test hook bwtc_hip_host_wavelet_streams calls it, so that
+// planStreams/codeStreams can be checked where there is no GPU; false = the plan's tables do
+// not cover a run of the input.
+bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>& sections,
+                         std::vector<uint32_t>* coded_pos, std::vector<uint8_t>* codes);
+
 }  // namespace wavelet
 }  // namespace bwtc

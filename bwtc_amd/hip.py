@@ -38,7 +38,7 @@ EXPORTS = [
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
-    "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -96,6 +96,7 @@ def load():
     L.bwtc_hip_wavelet_reset.argtypes = [_vp]
     L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64,
                                                  ctypes.POINTER(_u64)]
+    L.bwtc_hip_host_wavelet_streams.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
     L.bwtc_hip_host_huffman_lengths.restype = None
     L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
     L.bwtc_hip_host_huffman_codes.restype = None

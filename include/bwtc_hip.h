@@ -185,6 +185,19 @@ int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_ru
                                    uint32_t threads, uint32_t* state, uint8_t* out,
                                    uint64_t out_cap, uint64_t* out_bytes);
 
+/* Same arguments and same bytes as bwtc_hip_host_wavelet_sections, computed the way the device
+ * path does it: the tree shapes are planned from the statistics alone, every run is expanded
+ * into (tree node, bit) steps that are sorted into coding order, and the coder only sees the
+ * finished streams.  The expansion is done with plain host loops here (no device work), so
+ * the planning and stream-coding halves can be checked without a GPU.  -5: a shape the
+ * stream path does not take (the library then uses the tree builder of ..._sections). */
+int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run,
+                                  const uint8_t* run_sym, const uint32_t* run_start,
+                                  const uint32_t* run_freqs, const uint32_t* dist_offset,
+                                  const uint32_t* dist_len, const uint32_t* dist_cnt,
+                                  uint32_t threads, uint32_t* state, uint8_t* out,
+                                  uint64_t out_cap, uint64_t* out_bytes);
+
 /* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the
  * small-table steps the encoder runs between its device passes, exported so the host logic
  * can be checked on its own:

@@ -144,3 +144,36 @@ def test_wavelet_B_golden_and_multi_block_state(hip_ctx, oracle):
         out += _packed(blk.size) + _packed(1) + b"\x00" + rec.tobytes()
     out += b"\x00"
     assert out == oracle.oracle_compress_B(d, bs, 8).tobytes()
+
+
+def test_wavelet_B_host_tree_path_gives_the_same_bytes(hip_ctx, oracle):
+    """BWTC_HIP_WAVELET=host builds the trees with the library's host builder instead of the
+    device stream kernels (the route taken for shapes the stream path declines); both routes
+    must produce the reference's bytes."""
+    from bwtc_amd import hip
+    os.environ["BWTC_HIP_WAVELET"] = "host"
+    try:
+        ctx = hip.Context(device=0, max_block_size=(4 << 20) + 1024)
+    finally:
+        del os.environ["BWTC_HIP_WAVELET"]
+    try:
+        for name, data, sp in _inputs():
+            if data.size > (4 << 20):
+                continue
+            ctx.wavelet_reset()
+            hip_ctx.wavelet_reset()
+            rec_host, _ = ctx.transform_and_encode_wavelet(data, sp)
+            rec_dev, _ = hip_ctx.transform_and_encode_wavelet(data, sp)
+            assert rec_host.tobytes() == rec_dev.tobytes(), name
+    finally:
+        ctx.close()
+
+
+def test_wavelet_B_large_text_block(hip_ctx, oracle):
+    """32 MiB of text: tens of millions of steps through the stream kernels; whole record
+    against the oracle (a few seconds of CPU)."""
+    data = synth.gen_text(32 << 20, 5)
+    hip_ctx.wavelet_reset()
+    rec, bwt = hip_ctx.transform_and_encode_wavelet(data, 8)
+    want = oracle.oracle_compress_B(data, data.size, 8).tobytes()
+    assert _frame(b"B", rec.tobytes(), data.size) == want

@@ -106,7 +106,7 @@ def _runs_of(section):
     return s[heads], np.concatenate([heads, [s.size]]).astype(np.uint32)
 
 
-def _host_wavelet_payload(H, bwt, sections, state=4, threads=2):
+def _host_wavelet_payload(H, bwt, sections, state=4, threads=2, entry="bwtc_hip_host_wavelet_sections"):
     import ctypes
     first = [0]
     syms, starts, rfs, doff, dl, dc = [], [], [], [0], [], []
@@ -128,9 +128,8 @@ def _host_wavelet_payload(H, bwt, sections, state=4, threads=2):
     out = np.zeros(2 * bwt.size + 65536 * len(sections), np.uint8)
     n = ctypes.c_uint64(0)
     st = ctypes.c_uint32(state)
-    rc = H.bwtc_hip_host_wavelet_sections(len(sections), _p(first), _p(run_sym), _p(run_start), _p(rf), _p(doff),
-                                          _p(dl), _p(dc), threads, ctypes.byref(st), _p(out), out.size,
-                                          ctypes.byref(n))
+    rc = getattr(H, entry)(len(sections), _p(first), _p(run_sym), _p(run_start), _p(rf), _p(doff),
+                           _p(dl), _p(dc), threads, ctypes.byref(st), _p(out), out.size, ctypes.byref(n))
     assert rc == 0
     return out[:n.value].tobytes(), st.value
 
@@ -159,8 +158,12 @@ def test_wavelet_host_half_matches_oracle(oracle):
         k = oracle.lib().orc_write_bwtblock_header(_p(lfa), lfa.size, _p(hdr))
         skip = 6 + k + 1 + sum(len(_packed(int(x))) for x in sections)
         for threads in (1, 3):
-            got, _ = _host_wavelet_payload(H, bwt, sections, 4, threads)
+            got, end_state = _host_wavelet_payload(H, bwt, sections, 4, threads)
             assert got == want[skip:], (d.size, threads)
+            # the stream path: shapes planned from the statistics, runs expanded and sorted
+            got2, end_state2 = _host_wavelet_payload(H, bwt, sections, 4, threads, "bwtc_hip_host_wavelet_streams")
+            assert got2 == want[skip:], ("streams", d.size, threads)
+            assert end_state2 == end_state
 
 
 def _packed(v):
