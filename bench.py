@@ -93,7 +93,7 @@ def main():
     d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev)
     h_comp = np.empty(ctx.compress_bound(size), np.uint8)      # the 'B' coder runs on host threads
     cores = os.cpu_count() or 1
-    threads = max(1, cores // max(world, 1))
+    threads = max(1, min(64, cores // max(world, 1)))
     torch.cuda.synchronize()
     comp = [0]
 
@@ -148,8 +148,10 @@ def main():
                                    "(splitmix64 token generator, seed %s), 8 starting points"
                                    % (args.size_mib, "3" if world == 1 else "30+rank"),
                        "stages": "BWT (suffix sort + BWT + LFpowers + freqs) on the GPU + " +
-                                 ("'B' wavelet coder: run scanner on the GPU, tree + range coder on %d host "
-                                  "threads (bit-serial by the format)" % threads if args.coder == "B" else
+                                 ("'B' wavelet coder: run scanner, tree bit vectors, traversal order and gap "
+                                  "flags on the GPU; adaptive models (parallel over tree nodes) and the range "
+                                  "coder (one serial chain per section, by the format) on %d host threads"
+                                  % min(threads, 64) if args.coder == "B" else
                                   "'H' run-length/Huffman coder on the GPU"),
                        "coder": args.coder,
                        "blocks_per_gpu": 1, "parallelism": "block farm, no collective"},

@@ -62,6 +62,7 @@ struct BwtEngine {
   u64 wt_bytes = 0;
   u8* h_wt = nullptr;      // pinned: tables up, packed streams down
   u64 h_wt_bytes = 0;
+  std::vector<uint16_t> wt_prob;       // host: probability of every coded element (codeStreams)
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
 

@@ -675,7 +675,7 @@ int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
       rc = wavelet_streams_device(e, n_runs, st.first_run, plan, &coded_pos, &codes);
       if (rc) return rc;
       const auto t2 = std::chrono::steady_clock::now();
-      bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes, threads, fsm8_state, &outs);
+      bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes, threads, fsm8_state, &outs, &e.wt_prob);
       if (debug) {
         const auto t3 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; plan %.1f ms, device streams %.1f ms, "

@@ -496,50 +496,6 @@ struct Coder {
     low = bit ? low : split + 1;
     while (((low ^ high) & 0xFF000000u) == 0) { *w++ = static_cast<uint8_t>(low >> 24); low <<= 8; high = (high << 8) + 255; }
   }
-  // Codes elements [b, e) of one group.  All state lives in locals for the loop: the byte
-  // stores could alias the members otherwise and every field would stay in memory.
-  template <int TYPE>
-  void run(const uint8_t* codes, uint64_t b, uint64_t e) {
-    const uint64_t kChunk = 8192;
-    uint32_t lo = low, hi = high, mc = mcur, gc = gcur, ic = icur;
-    uint32_t q[16];
-    for (int i = 0; i < 16; ++i) q[i] = p[i];
-    for (; b < e; b += kChunk) {
-      const uint64_t ce = std::min(e, b + kChunk);
-      ensure(kChunk);
-      uint8_t* o = out->data() + used;
-      for (uint64_t i = b; i < ce; ++i) {
-        const uint32_t v = (codes[i >> 2] >> ((i & 3) * 2)) & 3u;
-        const uint32_t bit = v & 1u;
-        uint32_t slot, inv = 0, delay = 5, floor = 2;
-        if (TYPE == kRoot) { slot = kMain + mc; inv = mc >> 2; delay = (mc == 0 || mc == 7) ? 4 : 5; }
-        else if (TYPE == kBothLeaves) { slot = kGaps + gc; }
-        else if (TYPE == kInteger) { slot = kInts + ic; floor = 100; }
-        else {
-          const uint32_t gap = v >> 1;
-          slot = gap ? kGaps + gc : kMain + mc;
-          inv = gap ? 0u : mc >> 2;
-          delay = (!gap && (mc == 0 || mc == 7)) ? 4 : 5;
-        }
-        const uint32_t pr = q[slot];
-        const uint32_t p1 = inv ? 4096u - pr : pr;
-        const uint32_t size = hi - lo - 1;
-        const uint32_t split = lo + (size >> 12) * p1 + (((size & 4095u) * p1 + 2048u) >> 12);
-        hi = bit ? split : hi;
-        lo = bit ? lo : split + 1;
-        while (((lo ^ hi) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; hi = (hi << 8) + 255; }
-        const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
-        q[slot] = (bit ^ inv) ? up : down;
-        if (TYPE == kRoot) mc = kNext8[mc][bit];
-        else if (TYPE == kBothLeaves) gc = kNext4[gc][bit];
-        else if (TYPE == kInteger) ic = kNext3[ic][bit];
-        else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
-      }
-      used = static_cast<size_t>(o - out->data());
-    }
-    low = lo; high = hi; mcur = mc; gcur = gc; icur = ic;
-    for (int i = 0; i < 16; ++i) p[i] = static_cast<uint16_t>(q[i]);
-  }
   static inline uint16_t moved(uint32_t q, uint32_t toward_one, uint32_t lo, uint32_t delay) {
     const uint32_t up = q + (((4096u - lo) - q) >> delay), down = q - ((q - lo) >> delay);
     return static_cast<uint16_t>(toward_one ? up : down);
@@ -702,6 +658,66 @@ struct LengthTrie {
 
 inline uint32_t codeAt(const uint8_t* codes, uint64_t i) { return (codes[i >> 2] >> ((i & 3) * 2)) & 3u; }
 
+// Stage 1 of the stream coder: the probability every coded bit of one group is coded with.
+// A group starts with fresh predictors (resetModel before every inner node and every integer
+// level, a new encoder for the root; WaveletTree.hpp:651-653, :707, :792-797), so groups are
+// independent once the main model's state `mc` at the group's start is known.
+template <int TYPE>
+void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
+  enum { kMain = 0, kGaps = 8, kInts = 12 };
+  uint32_t q[16] = {2400, 2300, 2200, 2100, 2100, 2200, 2300, 2400, 2048, 2048, 2048, 2048, 2048, 2048, 2048, 0};
+  uint32_t gc = 2, ic = 1;
+  for (uint64_t i = b; i < e; ++i) {
+    const uint32_t v = codeAt(codes, i), bit = v & 1u;
+    uint32_t slot, inv = 0, delay = 5, floor = 2;
+    if (TYPE == kRoot) { slot = kMain + mc; inv = mc >> 2; delay = (mc == 0 || mc == 7) ? 4 : 5; }
+    else if (TYPE == kBothLeaves) { slot = kGaps + gc; }
+    else if (TYPE == kInteger) { slot = kInts + ic; floor = 100; }
+    else {
+      const uint32_t gap = v >> 1;
+      slot = gap ? kGaps + gc : kMain + mc;
+      inv = gap ? 0u : mc >> 2;
+      delay = (!gap && (mc == 0 || mc == 7)) ? 4 : 5;
+    }
+    const uint32_t pr = q[slot];
+    prob[i] = static_cast<uint16_t>(inv ? 4096u - pr : pr);
+    const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
+    q[slot] = (bit ^ inv) ? up : down;
+    if (TYPE == kRoot) mc = kNext8[mc][bit];
+    else if (TYPE == kBothLeaves) gc = kNext4[gc][bit];
+    else if (TYPE == kInteger) ic = kNext3[ic][bit];
+    else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
+  }
+}
+
+// Stage 2: BitEncoder (BitCoders.cpp:59-113) over elements [b, e) with their probabilities;
+// the one chain of the coder that cannot be split.
+void rangeCode(const uint8_t* codes, const uint16_t* prob, uint64_t b, uint64_t e, std::vector<uint8_t>* out) {
+  // The coder's interval is kept as (low, size = high - low - 1), all modulo 2^32 like the
+  // reference's high/low: with t = (size * p + 2048) >> 12 (the reference's two-part product,
+  // exact in 64 bits) a one bit gives size = t - 1 and a zero bit low += t + 1, size -= t + 1,
+  // so the loop-carried chain is one multiply and a subtraction.
+  const uint64_t kChunk = 16384;
+  uint32_t lo = 0, size = 0xFFFFFFFEu;
+  size_t used = out->size();
+  for (; b < e; b += kChunk) {
+    const uint64_t ce = std::min(e, b + kChunk);
+    if (out->size() - used < 4 * kChunk + 8) out->resize(used + 4 * kChunk + 8 + out->size() / 2);
+    uint8_t* o = out->data() + used;
+    for (uint64_t i = b; i < ce; ++i) {
+      const uint32_t bit = codeAt(codes, i) & 1u;
+      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * prob[i] + 2048u) >> 12);
+      lo = bit ? lo : lo + t + 1;
+      size = bit ? t - 1 : size - t - 1;
+      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
+    }
+    used = static_cast<size_t>(o - out->data());
+  }
+  out->resize(used + 4);
+  uint8_t* o = out->data() + used;                                    // BitEncoder::finish
+  o[0] = static_cast<uint8_t>(lo >> 24); o[1] = 255; o[2] = 255; o[3] = 255;
+}
+
 }  // namespace
 
 bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
@@ -828,7 +844,7 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
 }
 
 void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, unsigned threads,
-                 uint32_t* fsm8_state, std::vector<SectionOutput>* out) {
+                 uint32_t* fsm8_state, std::vector<SectionOutput>* out, std::vector<uint16_t>* scratch) {
   const size_t nsec = plan.sections.size();
   out->assign(nsec, SectionOutput());
   // The main model's state is the one value carried from section to section.  It is a
@@ -854,36 +870,71 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
   for (size_t s = 0; s < nsec; ++s) { start[s] = state; if (weight[s]) state = trans[s].image(state); }
   *fsm8_state = state;
 
+  // stage 1, parallel over groups: probabilities.  The main model's state at the start of a
+  // group follows from the (at most eight) bits that advanced it last, as above.
+  struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };
+  std::vector<Task> tasks;
+  std::vector<uint64_t> taskWeight;
+  for (size_t s = 0; s < nsec; ++s) {
+    const StreamPlan::Section& sec = plan.sections[s];
+    if (sec.level_first.size() < 2) continue;
+    const uint32_t* pos = coded_pos + sec.group_base;
+    for (uint32_t g = 0; g < sec.n_nodes; ++g) {
+      const Task t = {static_cast<uint32_t>(s), g, pos[g], pos[g + 1], plan.group_type[sec.group_base + g]};
+      if (t.end > t.begin) { tasks.push_back(t); taskWeight.push_back(t.end - t.begin); }
+    }
+    for (size_t l = 0; l + 1 < sec.level_first.size(); ++l) {
+      const Task t = {static_cast<uint32_t>(s), sec.level_first[l], pos[sec.level_first[l]], pos[sec.level_first[l + 1]], kInteger};
+      if (t.end > t.begin) { tasks.push_back(t); taskWeight.push_back(t.end - t.begin); }
+    }
+  }
+  const uint64_t total = coded_pos[plan.group_type.size()];
+  std::vector<uint16_t> local;
+  std::vector<uint16_t>& prob = scratch ? *scratch : local;
+  if (prob.size() < total) { std::vector<uint16_t>().swap(prob); prob.resize(total + total / 8); }
   const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  parallelFor(tasks.size(), threads, taskWeight.data(), [&](size_t k) {
+    const Task& t = tasks[k];
+    const StreamPlan::Section& sec = plan.sections[t.section];
+    if (t.type == kInteger) { modelGroup<kInteger>(codes, t.begin, t.end, 0, prob.data()); return; }
+    if (t.type == kBothLeaves) { modelGroup<kBothLeaves>(codes, t.begin, t.end, 0, prob.data()); return; }
+    uint8_t tail[8];
+    int have = 0;
+    for (uint32_t g = t.group; g-- > 0 && have < 8;) {
+      if (plan.group_type[sec.group_base + g] == kBothLeaves) continue;
+      const uint64_t b = coded_pos[sec.group_base + g], e = coded_pos[sec.group_base + g + 1];
+      for (uint64_t i = e; i-- > b && have < 8;) tail[have++] = codeAt(codes, i) & 1u;
+    }
+    StateTracker before;
+    while (have > 0) before.step(tail[--have]);
+    const uint32_t mc = before.image(start[t.section]);
+    if (t.type == kRoot) modelGroup<kRoot>(codes, t.begin, t.end, mc, prob.data());
+    else modelGroup<kInner>(codes, t.begin, t.end, mc, prob.data());
+  });
+  // stage 2, parallel over sections: the range coder
+  const auto t1 = std::chrono::steady_clock::now();
   std::vector<double> took(nsec, 0.0);
   parallelFor(nsec, threads, weight.data(), [&](size_t s) {
     const StreamPlan::Section& sec = plan.sections[s];
     if (sec.level_first.size() < 2) return;
-    const auto t0 = std::chrono::steady_clock::now();
+    const auto b0 = std::chrono::steady_clock::now();
     std::vector<uint8_t>& bytes = (*out)[s].bytes;
     bytes = sec.prefix;
-    Coder coder(start[s], &bytes);
     const uint32_t* pos = coded_pos + sec.group_base;
-    for (uint32_t g = 0; g < sec.n_nodes; ++g) {
-      const uint8_t type = plan.group_type[sec.group_base + g];
-      if (type == kRoot) { coder.run<kRoot>(codes, pos[g], pos[g + 1]); continue; }
-      coder.resetInternal();
-      if (type == kBothLeaves) coder.run<kBothLeaves>(codes, pos[g], pos[g + 1]);
-      else coder.run<kInner>(codes, pos[g], pos[g + 1]);
-    }
-    for (size_t l = 0; l + 1 < sec.level_first.size(); ++l) {
-      coder.resetIntegerLevel();
-      coder.run<kInteger>(codes, pos[sec.level_first[l]], pos[sec.level_first[l + 1]]);
-    }
-    coder.finish();
-    took[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    rangeCode(codes, prob.data(), pos[0], pos[sec.level_first.back()], &bytes);   // endContextBlock, WaveletCoders.cpp:62-68
+    took[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
   });
   if (debug) {
-    size_t big = 0;
-    double sum = 0;
-    for (size_t s = 0; s < nsec; ++s) { sum += took[s]; if (weight[s] > weight[big]) big = s; }
-    std::fprintf(stderr, "wavelet coder: %zu sections, %.3f s of coding in total; largest section %llu elements in %.3f s (%.2f ns each)\n",
-                 nsec, sum, (unsigned long long)weight[big], took[big], weight[big] ? took[big] * 1e9 / weight[big] : 0.0);
+    const auto t2 = std::chrono::steady_clock::now();
+    size_t big = 0, bigTask = 0;
+    for (size_t s = 0; s < nsec; ++s) if (weight[s] > weight[big]) big = s;
+    for (size_t k = 0; k < tasks.size(); ++k) if (taskWeight[k] > taskWeight[bigTask]) bigTask = k;
+    std::fprintf(stderr, "wavelet coder: %zu groups modelled in %.3f s (largest %llu elements), %zu sections range coded in %.3f s; "
+                 "largest section %llu elements in %.3f s (%.2f ns each)\n", tasks.size(),
+                 std::chrono::duration<double>(t1 - t0).count(), (unsigned long long)(tasks.empty() ? 0 : taskWeight[bigTask]), nsec,
+                 std::chrono::duration<double>(t2 - t1).count(), (unsigned long long)weight[big], took[big],
+                 weight[big] ? took[big] * 1e9 / weight[big] : 0.0);
   }
 }
 

@@ -78,9 +78,13 @@ struct StreamPlan {
 bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan);
 
 // coded_pos[g] = index of group g's first coded element in `codes` (2 bits per element, bit 0 =
-// the bit, bit 1 = the gap flag), coded_pos[groups] = total.
+// the bit, bit 1 = the gap flag), coded_pos[groups] = total.  Two stages: the probability of
+// every element (adaptive models; groups are independent, all in parallel), then the range
+// coder (one serial chain per section, sections in parallel).  `scratch` (optional) keeps the
+// probability buffer between calls.
 void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes,
-                 unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out);
+                 unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out,
+                 std::vector<uint16_t>* scratch = nullptr);
 
 // What wavelet_tree.hip computes, stated with plain host loops (expand, stable sort, gap flags,
 // select, pack).  Only the host-only test hook bwtc_hip_host_wavelet_streams calls it, so that

@@ -337,7 +337,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   // sort by (group, leaf rank); bit 0 rides along
   u32* ks = nullptr; u32* vs = nullptr;
   radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), ptr32(o_v0), ptr32(o_v1), n, key_bits,
-                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, &e.probe, (int)kStepLeafShift);
+                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift);
   // gaps
   u8* d_flag = base + o_flag;
   u32* d_gstart = ptr32(o_gstart);
