@@ -25,6 +25,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cpus():
+    """CPUs this job may keep busy: affinity mask, cut down to the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(size_mib_sample, seed, coder):
     """Times the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
     BWT = the reference's own divbwtf when oracle/_ref was built ("reference"), else the
@@ -61,11 +73,13 @@ def cpu_baseline(size_mib_sample, seed, coder):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--coder", choices=["B", "H"], default="B",
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
+    ap.add_argument("--depth", type=int, default=12,
+                    help="'B': blocks under way at once (device half of block i+1 overlaps the host half of block i)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -89,30 +103,63 @@ def main():
     host = synth.gen_text(size, seed)
     d_in = torch.from_numpy(host).to(dev)
     d_out = torch.empty_like(d_in)
+    os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(max(1, args.depth)))
     ctx = hip.Context(gpu, size)
     d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev)
     h_comp = np.empty(ctx.compress_bound(size), np.uint8)      # the 'B' coder runs on host threads
-    cores = os.cpu_count() or 1
-    threads = max(1, min(64, cores // max(world, 1)))
+    cores = usable_cpus()
+    threads = max(1, min(64, cores // max(world, 1) - 1))   # one CPU per rank feeds the GPU
     torch.cuda.synchronize()
     comp = [0]
+
+    # 'B': the device work of a block takes a tenth of the time its range coder needs on the
+    # host, so the steps overlap -- a step does the device half of its block and queues the
+    # host half on the context's worker threads (bwtc_hip_wavelet_encode_device_begin); every
+    # block is finished (..._end) inside the timed region, at the latest by drain().
+    depth = max(1, args.depth)
+    ring = [np.empty(ctx.compress_bound(size), np.uint8) for _ in range(depth)] if args.coder == "B" else []
+    pending = []
+
+    def collect():
+        comp[0] = ctx.wavelet_encode_end(pending.pop(0))
+
+    def drain():
+        while pending:
+            collect()
+
+    issued = [0]
 
     def step_for(coder):
         def step():
             lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
             if coder == "H":
                 comp[0] = ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
-            else:
+            elif not ring:
                 ctx.wavelet_reset()
                 comp[0] = ctx.wavelet_encode_device(d_out.data_ptr(), size, lf, freqs, h_comp, threads)
+            else:
+                if len(pending) >= depth:
+                    collect()
+                ctx.wavelet_reset()
+                pending.append(ctx.wavelet_encode_device_begin(d_out.data_ptr(), size, lf, freqs,
+                                                               ring[issued[0] % depth], threads))
+                issued[0] += 1
         return step
 
     step = step_for(args.coder)
 
+    # one block alone, start to finish (untimed): the latency a single block sees
+    single_ms = None
+    if args.coder == "B":
+        step(); drain()
+        t1 = time.perf_counter()
+        step(); drain()
+        single_ms = 1e3 * (time.perf_counter() - t1)
     for _ in range(args.warmup):
         step()
+    drain()
     ctx.reset_kernel_timers()
-    elapsed = farm.timed(step, args.steps, 0)
+    elapsed = farm.timed(step, args.steps, 0, drain)
     comp_bytes = comp[0]
 
     if rank == 0:
@@ -151,13 +198,15 @@ def main():
                                  ("'B' wavelet coder: run scanner, tree bit vectors, traversal order and gap "
                                   "flags on the GPU; adaptive models (parallel over tree nodes) and the range "
                                   "coder (one serial chain per section, by the format) on %d host threads"
-                                  % min(threads, 64) if args.coder == "B" else
+                                  % threads if args.coder == "B" else
                                   "'H' run-length/Huffman coder on the GPU"),
                        "coder": args.coder,
-                       "blocks_per_gpu": 1, "parallelism": "block farm, no collective"},
+                       "blocks_per_gpu": 1, "parallelism": "block farm, no collective",
+                       "blocks_under_way": depth if args.coder == "B" else 1},
             "device_ms_bwt": round(st.ms_total, 3), "rounds": st.rounds,
             "R_eff": round(st.active_sum / max(st.n, 1), 3),
             "compressed_bytes": int(comp_bytes),
+            "single_block_ms": round(single_ms, 1) if single_ms else None,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -165,9 +214,9 @@ def main():
         # the other coder on the same block, two untimed-region steps, for orientation
         other = "H" if args.coder == "B" else "B"
         ostep = step_for(other)
-        ostep()
+        ostep(); drain()
         t1 = time.perf_counter()
-        ostep()
+        ostep(); drain()
         out["other_coder"] = {"coder": other, "MBps": round(size / 1e6 / (time.perf_counter() - t1), 2),
                               "compressed_bytes": int(comp[0])}
         print(json.dumps(out), flush=True)

@@ -483,6 +483,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     use_sweep = e && std::strcmp(e, "sweep") == 0;
     const char* w = std::getenv("BWTC_HIP_WAVELET");
     wavelet_on_host = w && std::strcmp(w, "host") == 0;
+    const char* d = std::getenv("BWTC_HIP_WAVELET_DEPTH");
+    if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
   }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
@@ -493,6 +495,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
 }
 
 void BwtEngine::release() {
+  wavelet_pipeline_release(*this);
   if (stream) (void)hipStreamSynchronize(stream);
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);

@@ -19,6 +19,9 @@
 #include "bwtc_hip.h"
 #include "radix_sort.hpp"
 #include "wavelet_host.hpp"
+#include "wavelet_pipeline.hpp"
+#include <map>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -62,7 +65,13 @@ struct BwtEngine {
   u64 wt_bytes = 0;
   u8* h_wt = nullptr;      // pinned: tables up, packed streams down
   u64 h_wt_bytes = 0;
-  std::vector<uint16_t> wt_prob;       // host: probability of every coded element (codeStreams)
+  // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
+  WorkerPool* pool = nullptr;
+  std::map<u64, std::shared_ptr<WaveletJob> > jobs;
+  u64 next_ticket = 1;
+  unsigned max_inflight = 12;          // BWTC_HIP_WAVELET_DEPTH
+  std::vector<std::unique_ptr<RawBuffer<uint8_t> > > codes_free;     // recycled: no fresh pages per block
+  std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
 
@@ -114,19 +123,22 @@ struct WaveletSectionStats {
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
                                  WaveletSectionStats* out);
 
-// WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
-// 112-157, 159-163) for a device-resident transformed block.  Run scanning on the GPU, tree
-// building and range coding on `threads` host threads (wavelet_host.cpp); *fsm8_state is the
-// probability model's carried state (4 for a fresh encoder).  The record goes to host memory.
 // Steps of all runs of the block sorted into coding order, gap flags derived, skipped bits
 // dropped (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
 int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
                            const u8** codes);
 
-int wavelet_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
-                          const u32* freqs, unsigned threads, u32* fsm8_state,
-                          std::vector<u8>* record);
+// WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
+// 112-157, 159-163) for a device-resident transformed block, in two halves so that blocks
+// overlap (wavelet_pipeline.hpp): _begin does the device work (run scanner, stream kernels),
+// advances the encoder's carried model state and queues the block's models and range coders
+// on the engine's worker threads (created with `threads` threads by the first call); _end waits
+// for that block and reports the record's size (the bytes are in `out` given to _begin).
+int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                         const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket);
+int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes);
+void wavelet_pipeline_release(BwtEngine& e);
 
 // Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).
 // Returns -4 when an LF power does not lie on the LF walk (corrupt header or data).

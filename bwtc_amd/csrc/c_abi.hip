@@ -4,6 +4,7 @@
 #include "bwtc_hip.h"
 #include "entropy_host.hpp"
 #include "wavelet_host.hpp"
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -278,30 +279,55 @@ int bwtc_hip_wavelet_section_stats(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32
   return 0;
 }
 
+// CPUs this process may keep busy: the hardware threads, cut down to the cgroup's CPU quota
+// (a container with a quota is throttled as a whole, the GPU-feeding thread included, when
+// more threads than that run).
+static unsigned usable_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    unsigned long period = 0;
+    if (std::fscanf(f, "%31s %lu", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+      const unsigned long q = std::strtoul(quota, nullptr, 10);
+      if (q > 0) n = std::min<unsigned long>(n, std::max<unsigned long>(1, q / period));
+    }
+    std::fclose(f);
+  }
+  return n;
+}
+
 static unsigned pick_threads(uint32_t threads) {
   if (threads) return threads;
-  const unsigned hc = std::thread::hardware_concurrency();
-  return hc ? (hc < 64 ? hc : 64) : 1;      // sections are at most 256 and very unequal
+  const unsigned n = usable_cpus();
+  return n > 1 ? std::min(n - 1, 64u) : 1;   // one is left to the thread that feeds the GPU
 }
 
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { if (ctx) ctx->eng.wavelet_state = 4; }
+
+int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                         const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                         uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                         uint64_t* ticket) {
+  if (!ctx || (!d_bwt && size) || !lf || !freqs || !out || !ticket) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  return wavelet_encode_begin(e, d_bwt, size, lf, n_lf, freqs, pick_threads(threads), out, out_cap, ticket);
+}
+
+int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes) {
+  if (!ctx || !out_bytes) return -1;
+  return wavelet_encode_end(ctx->eng, ticket, out_bytes);
+}
 
 int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                    const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
                                    uint32_t threads, uint8_t* out, uint64_t out_cap,
                                    uint64_t* out_bytes) {
-  if (!ctx || (!d_bwt && size) || !lf || !freqs || !out || !out_bytes) return -1;
-  BwtEngine& e = ctx->eng;
-  if (size > e.max_block) return -1;
-  std::vector<u8> rec;
-  u32 state = e.wavelet_state;
-  int rc = wavelet_encode_device(e, d_bwt, size, lf, n_lf, freqs, pick_threads(threads), &state, &rec);
+  uint64_t ticket = 0;
+  int rc = bwtc_hip_wavelet_encode_device_begin(ctx, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, &ticket);
   if (rc) return rc;
-  if (rec.size() > out_cap) return -1;
-  e.wavelet_state = state;
-  std::memcpy(out, rec.data(), rec.size());
-  *out_bytes = rec.size();
-  return 0;
+  return bwtc_hip_wavelet_encode_end(ctx, ticket, out_bytes);
 }
 
 int bwtc_hip_wavelet_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size,

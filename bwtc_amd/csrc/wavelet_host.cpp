@@ -636,6 +636,37 @@ void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, 
 // ---- device-built streams -------------------------------------------------------------------
 namespace {
 
+inline uint32_t codeAt(const uint8_t* codes, uint64_t i) { return (codes[i >> 2] >> ((i & 3) * 2)) & 3u; }
+
+// Stage 2 of the stream coder: BitEncoder (BitCoders.cpp:59-113) over elements [b, e) with their
+// probabilities; the one chain of the coder that cannot be split.  The interval is kept as
+// (low, size = high - low - 1), all modulo 2^32 like the reference's high/low: with
+// t = (size * p + 2048) >> 12 (the reference's two-part product, exact in 64 bits) a one bit
+// gives size = t - 1 and a zero bit low += t + 1, size -= t + 1, so the loop-carried chain is
+// one multiply and a subtraction.  (Stepping several sections' chains in lockstep in one
+// thread was measured slower, here and on the GPU box's EPYC: the loop is not latency bound.)
+void rangeCode(const uint8_t* codes, const uint16_t* prob, uint64_t b, uint64_t e, std::vector<uint8_t>* out) {
+  const uint64_t kChunk = 16384;
+  uint32_t lo = 0, size = 0xFFFFFFFEu;
+  size_t used = out->size();
+  for (; b < e; b += kChunk) {
+    const uint64_t ce = std::min(e, b + kChunk);
+    if (out->size() - used < 4 * kChunk + 8) out->resize(used + 4 * kChunk + 8 + out->size() / 2);
+    uint8_t* o = out->data() + used;
+    for (uint64_t i = b; i < ce; ++i) {
+      const uint32_t bit = codeAt(codes, i) & 1u;
+      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * prob[i] + 2048u) >> 12);
+      lo = bit ? lo : lo + t + 1;
+      size = bit ? t - 1 : size - t - 1;
+      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
+    }
+    used = static_cast<size_t>(o - out->data());
+  }
+  out->resize(used + 4);
+  uint8_t* o = out->data() + used;                                    // BitEncoder::finish
+  o[0] = static_cast<uint8_t>(lo >> 24); o[1] = 255; o[2] = 255; o[3] = 255;
+}
+
 // union of the length codes of one section as a binary trie
 struct LengthTrie {
   struct N { int child[2]; bool terminal; uint32_t group; N() : terminal(false), group(0) { child[0] = child[1] = -1; } };
@@ -656,7 +687,6 @@ struct LengthTrie {
   }
 };
 
-inline uint32_t codeAt(const uint8_t* codes, uint64_t i) { return (codes[i >> 2] >> ((i & 3) * 2)) & 3u; }
 
 // Stage 1 of the stream coder: the probability every coded bit of one group is coded with.
 // A group starts with fresh predictors (resetModel before every inner node and every integer
@@ -688,34 +718,6 @@ void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint1
     else if (TYPE == kInteger) ic = kNext3[ic][bit];
     else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
   }
-}
-
-// Stage 2: BitEncoder (BitCoders.cpp:59-113) over elements [b, e) with their probabilities;
-// the one chain of the coder that cannot be split.
-void rangeCode(const uint8_t* codes, const uint16_t* prob, uint64_t b, uint64_t e, std::vector<uint8_t>* out) {
-  // The coder's interval is kept as (low, size = high - low - 1), all modulo 2^32 like the
-  // reference's high/low: with t = (size * p + 2048) >> 12 (the reference's two-part product,
-  // exact in 64 bits) a one bit gives size = t - 1 and a zero bit low += t + 1, size -= t + 1,
-  // so the loop-carried chain is one multiply and a subtraction.
-  const uint64_t kChunk = 16384;
-  uint32_t lo = 0, size = 0xFFFFFFFEu;
-  size_t used = out->size();
-  for (; b < e; b += kChunk) {
-    const uint64_t ce = std::min(e, b + kChunk);
-    if (out->size() - used < 4 * kChunk + 8) out->resize(used + 4 * kChunk + 8 + out->size() / 2);
-    uint8_t* o = out->data() + used;
-    for (uint64_t i = b; i < ce; ++i) {
-      const uint32_t bit = codeAt(codes, i) & 1u;
-      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * prob[i] + 2048u) >> 12);
-      lo = bit ? lo : lo + t + 1;
-      size = bit ? t - 1 : size - t - 1;
-      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
-    }
-    used = static_cast<size_t>(o - out->data());
-  }
-  out->resize(used + 4);
-  uint8_t* o = out->data() + used;                                    // BitEncoder::finish
-  o[0] = static_cast<uint8_t>(lo >> 24); o[1] = 255; o[2] = 255; o[3] = 255;
 }
 
 }  // namespace
@@ -843,98 +845,93 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   return true;
 }
 
-void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, unsigned threads,
-                 uint32_t* fsm8_state, std::vector<SectionOutput>* out, std::vector<uint16_t>* scratch) {
+StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state)
+    : plan_(plan), pos_(coded_pos), codes_(codes), end_state_(fsm8_state) {
   const size_t nsec = plan.sections.size();
-  out->assign(nsec, SectionOutput());
   // The main model's state is the one value carried from section to section.  It is a
   // function of the last few bits that advanced it: two different bits in a row, or four
   // equal ones, fix the state whatever it was before.
-  std::vector<StateTracker> trans(nsec);
+  start_.assign(nsec, 0);
   std::vector<uint64_t> weight(nsec, 0);
   for (size_t s = 0; s < nsec; ++s) {
     const StreamPlan::Section& sec = plan.sections[s];
+    start_[s] = end_state_;
     if (sec.level_first.size() < 2) continue;
     weight[s] = coded_pos[sec.group_base + sec.level_first.back()] - coded_pos[sec.group_base];
-    uint8_t tail[8];
-    int have = 0;
-    for (uint32_t g = sec.n_nodes; g-- > 0 && have < 8;) {
-      if (plan.group_type[sec.group_base + g] == kBothLeaves) continue;
-      const uint64_t b = coded_pos[sec.group_base + g], e = coded_pos[sec.group_base + g + 1];
-      for (uint64_t i = e; i-- > b && have < 8;) tail[have++] = codeAt(codes, i) & 1u;
-    }
-    while (have > 0) trans[s].step(tail[--have]);
+    if (weight[s]) end_state_ = stateBefore(s, sec.n_nodes);
   }
-  std::vector<uint32_t> start(nsec);
-  uint32_t state = *fsm8_state;
-  for (size_t s = 0; s < nsec; ++s) { start[s] = state; if (weight[s]) state = trans[s].image(state); }
-  *fsm8_state = state;
-
-  // stage 1, parallel over groups: probabilities.  The main model's state at the start of a
-  // group follows from the (at most eight) bits that advanced it last, as above.
-  struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };
-  std::vector<Task> tasks;
-  std::vector<uint64_t> taskWeight;
   for (size_t s = 0; s < nsec; ++s) {
     const StreamPlan::Section& sec = plan.sections[s];
     if (sec.level_first.size() < 2) continue;
+    sections_.push_back(static_cast<uint32_t>(s));
     const uint32_t* pos = coded_pos + sec.group_base;
     for (uint32_t g = 0; g < sec.n_nodes; ++g) {
       const Task t = {static_cast<uint32_t>(s), g, pos[g], pos[g + 1], plan.group_type[sec.group_base + g]};
-      if (t.end > t.begin) { tasks.push_back(t); taskWeight.push_back(t.end - t.begin); }
+      if (t.end > t.begin) tasks_.push_back(t);
     }
     for (size_t l = 0; l + 1 < sec.level_first.size(); ++l) {
       const Task t = {static_cast<uint32_t>(s), sec.level_first[l], pos[sec.level_first[l]], pos[sec.level_first[l + 1]], kInteger};
-      if (t.end > t.begin) { tasks.push_back(t); taskWeight.push_back(t.end - t.begin); }
+      if (t.end > t.begin) tasks_.push_back(t);
     }
   }
-  const uint64_t total = coded_pos[plan.group_type.size()];
+  std::stable_sort(tasks_.begin(), tasks_.end(), [](const Task& x, const Task& y) { return x.end - x.begin > y.end - y.begin; });
+  std::stable_sort(sections_.begin(), sections_.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+}
+
+// state of the main model before group `group` of section s (group = n_nodes: after the section)
+uint32_t StreamCoder::stateBefore(size_t s, uint32_t group) const {
+  const StreamPlan::Section& sec = plan_.sections[s];
+  uint8_t tail[8];
+  int have = 0;
+  for (uint32_t g = group; g-- > 0 && have < 8;) {
+    if (plan_.group_type[sec.group_base + g] == kBothLeaves) continue;   // gaps that leave the main model alone
+    const uint64_t b = pos_[sec.group_base + g], e = pos_[sec.group_base + g + 1];
+    for (uint64_t i = e; i-- > b && have < 8;) tail[have++] = codeAt(codes_, i) & 1u;
+  }
+  StateTracker t;
+  while (have > 0) t.step(tail[--have]);
+  return t.image(start_[s]);
+}
+
+uint64_t StreamCoder::elements() const { return pos_[plan_.group_type.size()]; }
+
+void StreamCoder::model(size_t k, uint16_t* prob) const {
+  const Task& t = tasks_[k];
+  if (t.type == kInteger) { modelGroup<kInteger>(codes_, t.begin, t.end, 0, prob); return; }
+  if (t.type == kBothLeaves) { modelGroup<kBothLeaves>(codes_, t.begin, t.end, 0, prob); return; }
+  const uint32_t mc = stateBefore(t.section, t.group);
+  if (t.type == kRoot) modelGroup<kRoot>(codes_, t.begin, t.end, mc, prob);
+  else modelGroup<kInner>(codes_, t.begin, t.end, mc, prob);
+}
+
+void StreamCoder::codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const {
+  const size_t s = sections_[k];
+  const StreamPlan::Section& sec = plan_.sections[s];
+  std::vector<uint8_t>& bytes = (*out)[s].bytes;
+  bytes = sec.prefix;
+  const uint32_t* pos = pos_ + sec.group_base;
+  rangeCode(codes_, prob, pos[0], pos[sec.level_first.back()], &bytes);   // endContextBlock, WaveletCoders.cpp:62-68
+}
+
+void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, unsigned threads,
+                 uint32_t* fsm8_state, std::vector<SectionOutput>* out, std::vector<uint16_t>* scratch) {
+  out->assign(plan.sections.size(), SectionOutput());
+  StreamCoder coder(plan, coded_pos, codes, *fsm8_state);
+  *fsm8_state = coder.endState();
+  const uint64_t total = coder.elements();
   std::vector<uint16_t> local;
   std::vector<uint16_t>& prob = scratch ? *scratch : local;
   if (prob.size() < total) { std::vector<uint16_t>().swap(prob); prob.resize(total + total / 8); }
   const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
   const auto t0 = std::chrono::steady_clock::now();
-  parallelFor(tasks.size(), threads, taskWeight.data(), [&](size_t k) {
-    const Task& t = tasks[k];
-    const StreamPlan::Section& sec = plan.sections[t.section];
-    if (t.type == kInteger) { modelGroup<kInteger>(codes, t.begin, t.end, 0, prob.data()); return; }
-    if (t.type == kBothLeaves) { modelGroup<kBothLeaves>(codes, t.begin, t.end, 0, prob.data()); return; }
-    uint8_t tail[8];
-    int have = 0;
-    for (uint32_t g = t.group; g-- > 0 && have < 8;) {
-      if (plan.group_type[sec.group_base + g] == kBothLeaves) continue;
-      const uint64_t b = coded_pos[sec.group_base + g], e = coded_pos[sec.group_base + g + 1];
-      for (uint64_t i = e; i-- > b && have < 8;) tail[have++] = codeAt(codes, i) & 1u;
-    }
-    StateTracker before;
-    while (have > 0) before.step(tail[--have]);
-    const uint32_t mc = before.image(start[t.section]);
-    if (t.type == kRoot) modelGroup<kRoot>(codes, t.begin, t.end, mc, prob.data());
-    else modelGroup<kInner>(codes, t.begin, t.end, mc, prob.data());
-  });
-  // stage 2, parallel over sections: the range coder
+  parallelFor(coder.modelTasks(), threads, 0, [&](size_t k) { coder.model(k, prob.data()); });
   const auto t1 = std::chrono::steady_clock::now();
-  std::vector<double> took(nsec, 0.0);
-  parallelFor(nsec, threads, weight.data(), [&](size_t s) {
-    const StreamPlan::Section& sec = plan.sections[s];
-    if (sec.level_first.size() < 2) return;
-    const auto b0 = std::chrono::steady_clock::now();
-    std::vector<uint8_t>& bytes = (*out)[s].bytes;
-    bytes = sec.prefix;
-    const uint32_t* pos = coded_pos + sec.group_base;
-    rangeCode(codes, prob.data(), pos[0], pos[sec.level_first.back()], &bytes);   // endContextBlock, WaveletCoders.cpp:62-68
-    took[s] = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
-  });
+  parallelFor(coder.sectionTasks(), threads, 0, [&](size_t k) { coder.codeSection(k, prob.data(), out); });
   if (debug) {
     const auto t2 = std::chrono::steady_clock::now();
-    size_t big = 0, bigTask = 0;
-    for (size_t s = 0; s < nsec; ++s) if (weight[s] > weight[big]) big = s;
-    for (size_t k = 0; k < tasks.size(); ++k) if (taskWeight[k] > taskWeight[bigTask]) bigTask = k;
-    std::fprintf(stderr, "wavelet coder: %zu groups modelled in %.3f s (largest %llu elements), %zu sections range coded in %.3f s; "
-                 "largest section %llu elements in %.3f s (%.2f ns each)\n", tasks.size(),
-                 std::chrono::duration<double>(t1 - t0).count(), (unsigned long long)(tasks.empty() ? 0 : taskWeight[bigTask]), nsec,
-                 std::chrono::duration<double>(t2 - t1).count(), (unsigned long long)weight[big], took[big],
-                 weight[big] ? took[big] * 1e9 / weight[big] : 0.0);
+    std::fprintf(stderr, "wavelet coder: %llu elements; %zu groups modelled in %.3f s, %zu sections range coded in %.3f s\n",
+                 (unsigned long long)total, coder.modelTasks(), std::chrono::duration<double>(t1 - t0).count(),
+                 coder.sectionTasks(), std::chrono::duration<double>(t2 - t1).count());
   }
 }
 

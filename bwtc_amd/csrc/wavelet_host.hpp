@@ -77,11 +77,38 @@ struct StreamPlan {
 // that is a prefix of another); the caller then uses encodeSections().
 bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan);
 
-// coded_pos[g] = index of group g's first coded element in `codes` (2 bits per element, bit 0 =
-// the bit, bit 1 = the gap flag), coded_pos[groups] = total.  Two stages: the probability of
-// every element (adaptive models; groups are independent, all in parallel), then the range
-// coder (one serial chain per section, sections in parallel).  `scratch` (optional) keeps the
-// probability buffer between calls.
+// The coder over finished streams.  coded_pos[g] = index of group g's first coded element in
+// `codes` (2 bits per element, bit 0 = the bit, bit 1 = the gap flag), coded_pos[groups] =
+// total.  Two kinds of independent tasks, both ordered largest first:
+//   model(k)        the probability of every element of one group (adaptive models; a group
+//                   starts with fresh predictors, the main model's state at its start follows
+//                   from the few bits before it)
+//   codeSection(k)  the range coder over one section -- the one serial chain of the format --
+//                   once all of the section's groups are modelled
+// plan, coded_pos and codes must outlive the object.
+class StreamCoder {
+ public:
+  StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state);
+  uint32_t endState() const { return end_state_; }        // the carried state after the block
+  uint64_t elements() const;                              // size of the probability buffer
+  size_t modelTasks() const { return tasks_.size(); }
+  void model(size_t k, uint16_t* prob) const;
+  size_t sectionTasks() const { return sections_.size(); }
+  void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
+
+ private:
+  struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };
+  uint32_t stateBefore(size_t s, uint32_t group) const;
+  const StreamPlan& plan_;
+  const uint32_t* pos_;
+  const uint8_t* codes_;
+  uint32_t end_state_;
+  std::vector<uint32_t> start_;
+  std::vector<Task> tasks_;
+  std::vector<uint32_t> sections_;
+};
+
+// All of it on `threads` threads; `scratch` (optional) keeps the probability buffer between calls.
 void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes,
                  unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out,
                  std::vector<uint16_t>* scratch = nullptr);

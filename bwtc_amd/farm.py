@@ -59,15 +59,21 @@ class Farm:
         return float(t.item())
 
     # ---- timing contract of bench.py -----------------------------------------------------
-    def timed(self, step, steps, warmup):
+    def timed(self, step, steps, warmup, drain=None):
         """warmup untimed steps, then `steps` steps bracketed by barrier+synchronize on both
-        sides; returns the MAX over ranks of the elapsed seconds."""
+        sides; returns the MAX over ranks of the elapsed seconds.  `drain` (optional) completes
+        work the steps left under way; it runs after the warmup and, inside the timed region,
+        after the last step."""
         for _ in range(warmup):
             step()
+        if drain:
+            drain()
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        if drain:
+            drain()
         self.barrier()
         return self.max(time.perf_counter() - t0)
 

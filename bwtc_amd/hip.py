@@ -38,7 +38,8 @@ EXPORTS = [
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
-    "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
+    "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -92,6 +93,8 @@ def load():
     L.bwtc_hip_transform_and_encode_wavelet.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_encode.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_encode_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode_device_begin.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode_end.argtypes = [_vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_reset.restype = None
     L.bwtc_hip_wavelet_reset.argtypes = [_vp]
     L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64,
@@ -294,6 +297,25 @@ class Context:
                                                        _ptr(freqs), threads, _ptr(out), out.size,
                                                        ctypes.byref(n)),
                "bwtc_hip_wavelet_encode_device")
+        return int(n.value)
+
+    def wavelet_encode_device_begin(self, d_bwt_ptr, size, lf, freqs, out, threads=0):
+        """First half: device work now, models + range coder queued on the worker threads.
+        `out` must stay alive until wavelet_encode_end(ticket); returns the ticket."""
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        t = _u64(0)
+        _check(self.lib.bwtc_hip_wavelet_encode_device_begin(self.handle, _vp(d_bwt_ptr), size, _ptr(lf), lf.size,
+                                                             _ptr(freqs), threads, _ptr(out), out.size,
+                                                             ctypes.byref(t)),
+               "bwtc_hip_wavelet_encode_device_begin")
+        return int(t.value)
+
+    def wavelet_encode_end(self, ticket):
+        """Second half: waits for the block, returns the record's size."""
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_wavelet_encode_end(self.handle, _u64(ticket), ctypes.byref(n)),
+               "bwtc_hip_wavelet_encode_end")
         return int(n.value)
 
     def transform_and_encode_wavelet(self, data, starting_points=8, threads=0):

@@ -170,6 +170,22 @@ int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint
                                    const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
                                    uint32_t threads, uint8_t* out, uint64_t out_cap,
                                    uint64_t* out_bytes);
+/* The same in two halves, so that a caller with several blocks overlaps them (the
+ * reference's Compressor::compress loop, Compressor.cpp:103-137, made a pipeline): _begin does
+ * the device work of the block (run scanner, tree bit vectors, traversal order, gap flags),
+ * advances the encoder's carried model state and queues the block's adaptive models and range
+ * coders on the context's worker threads (created by the first call, `threads` of them, 0 =
+ * all cores up to 64); it returns as soon as the GPU is free for the next block.  _end waits
+ * for that block; the record is then in the `out` given to _begin, *out_bytes long.  Records
+ * are those of a strictly sequential encoder whatever the overlap.  At most
+ * BWTC_HIP_WAVELET_DEPTH (default 12) blocks are under way; a further _begin waits for the
+ * oldest, and returns -6 if that one is finished but not collected.  `out` must stay valid
+ * until _end; _begin/_end of one context are called from one thread. */
+int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                         const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                         uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                         uint64_t* ticket);
+int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 
 /* Host half of the 'B' coder alone (no device work): the sections' runs as the GPU scanner

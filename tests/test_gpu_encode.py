@@ -177,3 +177,30 @@ def test_wavelet_B_large_text_block(hip_ctx, oracle):
     rec, bwt = hip_ctx.transform_and_encode_wavelet(data, 8)
     want = oracle.oracle_compress_B(data, data.size, 8).tobytes()
     assert _frame(b"B", rec.tobytes(), data.size) == want
+
+
+def test_wavelet_B_overlapped_blocks_equal_the_sequential_stream(hip_ctx, oracle):
+    """Several blocks through _begin/_end with all of them under way at once: the carried model
+    state is handed on at _begin, so the records are those of the sequential encoder."""
+    d = synth.gen_text(6 << 20, 9)
+    bs = 1 << 20
+    hip_ctx.wavelet_reset()
+    bufs, tickets, sizes = [], [], []
+    for off in range(0, d.size, bs):
+        blk = d[off:off + bs]
+        d_in = hip_ctx.dmalloc(blk.size + 16)
+        try:
+            hip_ctx.to_device(d_in, blk)
+            lf, freqs = hip_ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+            out = np.zeros(hip_ctx.compress_bound(blk.size), np.uint8)
+            tickets.append(hip_ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=4))
+        finally:
+            hip_ctx.dfree(d_in)         # the block's streams have left the device by now
+        bufs.append(out)
+        sizes.append(blk.size)
+    stream = b"B"
+    for t, out, n in zip(tickets, bufs, sizes):
+        m = hip_ctx.wavelet_encode_end(t)
+        stream += _packed(n) + _packed(1) + b"\x00" + out[:m].tobytes()
+    stream += b"\x00"
+    assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes()
