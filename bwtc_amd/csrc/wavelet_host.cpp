@@ -653,13 +653,25 @@ void rangeCode(const uint8_t* codes, const uint16_t* prob, uint64_t b, uint64_t 
     const uint64_t ce = std::min(e, b + kChunk);
     if (out->size() - used < 4 * kChunk + 8) out->resize(used + 4 * kChunk + 8 + out->size() / 2);
     uint8_t* o = out->data() + used;
-    for (uint64_t i = b; i < ce; ++i) {
-      const uint32_t bit = codeAt(codes, i) & 1u;
-      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * prob[i] + 2048u) >> 12);
-      lo = bit ? lo : lo + t + 1;
-      size = bit ? t - 1 : size - t - 1;
-      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
+#define BWTC_RC_STEP(bit_, p_)                                                                          \
+    {                                                                                                    \
+      const uint32_t bit = (bit_);                                                                       \
+      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * (p_) + 2048u) >> 12);      \
+      lo = bit ? lo : lo + t + 1;                                                                        \
+      size = bit ? t - 1 : size - t - 1;                                                                 \
+      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; } \
     }
+    uint64_t i = b;
+    for (; i < ce && (i & 3); ++i) BWTC_RC_STEP(codeAt(codes, i) & 1u, prob[i]);
+    for (; i + 4 <= ce; i += 4) {
+      const uint32_t four = codes[i >> 2];
+      BWTC_RC_STEP(four & 1u, prob[i]);
+      BWTC_RC_STEP((four >> 2) & 1u, prob[i + 1]);
+      BWTC_RC_STEP((four >> 4) & 1u, prob[i + 2]);
+      BWTC_RC_STEP((four >> 6) & 1u, prob[i + 3]);
+    }
+    for (; i < ce; ++i) BWTC_RC_STEP(codeAt(codes, i) & 1u, prob[i]);
+#undef BWTC_RC_STEP
     used = static_cast<size_t>(o - out->data());
   }
   out->resize(used + 4);
@@ -692,32 +704,51 @@ struct LengthTrie {
 // A group starts with fresh predictors (resetModel before every inner node and every integer
 // level, a new encoder for the root; WaveletTree.hpp:651-653, :707, :792-797), so groups are
 // independent once the main model's state `mc` at the group's start is known.
+// The upper four predictors of the main model predict the inverted bit (InversePredictor):
+// the probability of a one is 4096 - p and the predictor moves the other way.  Kept as
+// p' = 4096 - p they follow the same rule as the others (4094 - p = p' - 2), so all fifteen
+// are handled alike: probability of a one = q[slot], moved towards the coded bit.
 template <int TYPE>
-void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
-  enum { kMain = 0, kGaps = 8, kInts = 12 };
-  uint32_t q[16] = {2400, 2300, 2200, 2100, 2100, 2200, 2300, 2400, 2048, 2048, 2048, 2048, 2048, 2048, 2048, 0};
-  uint32_t gc = 2, ic = 1;
-  for (uint64_t i = b; i < e; ++i) {
-    const uint32_t v = codeAt(codes, i), bit = v & 1u;
-    uint32_t slot, inv = 0, delay = 5, floor = 2;
-    if (TYPE == kRoot) { slot = kMain + mc; inv = mc >> 2; delay = (mc == 0 || mc == 7) ? 4 : 5; }
-    else if (TYPE == kBothLeaves) { slot = kGaps + gc; }
-    else if (TYPE == kInteger) { slot = kInts + ic; floor = 100; }
-    else {
-      const uint32_t gap = v >> 1;
-      slot = gap ? kGaps + gc : kMain + mc;
-      inv = gap ? 0u : mc >> 2;
-      delay = (!gap && (mc == 0 || mc == 7)) ? 4 : 5;
-    }
-    const uint32_t pr = q[slot];
-    prob[i] = static_cast<uint16_t>(inv ? 4096u - pr : pr);
+struct GroupModel {
+  uint32_t q[16];
+  uint32_t mc, gc, ic;
+  explicit GroupModel(uint32_t mainState) : mc(mainState), gc(2), ic(1) {
+    static const uint32_t init[16] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400,
+                                      2048, 2048, 2048, 2048, 2048, 2048, 2048, 0};
+    for (int k = 0; k < 16; ++k) q[k] = init[k];
+  }
+  inline uint16_t step(uint32_t v) {
+    static const uint8_t kDelay[16] = {4, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 5, 5, 5, 5};
+    const uint32_t bit = v & 1u;
+    uint32_t slot, floor = 2;
+    if (TYPE == kRoot) slot = mc;
+    else if (TYPE == kBothLeaves) slot = 8 + gc;
+    else if (TYPE == kInteger) { slot = 12 + ic; floor = 100; }
+    else slot = (v >> 1) ? 8 + gc : mc;
+    const uint32_t pr = q[slot], delay = kDelay[slot];
     const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
-    q[slot] = (bit ^ inv) ? up : down;
+    q[slot] = bit ? up : down;
     if (TYPE == kRoot) mc = kNext8[mc][bit];
     else if (TYPE == kBothLeaves) gc = kNext4[gc][bit];
     else if (TYPE == kInteger) ic = kNext3[ic][bit];
     else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
+    return static_cast<uint16_t>(pr);
   }
+};
+
+template <int TYPE>
+void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
+  GroupModel<TYPE> m(mc);
+  uint64_t i = b;
+  for (; i < e && (i & 3); ++i) prob[i] = m.step(codeAt(codes, i));
+  for (; i + 4 <= e; i += 4) {                                         // four elements per byte of codes
+    const uint32_t four = codes[i >> 2];
+    prob[i] = m.step(four & 3u);
+    prob[i + 1] = m.step((four >> 2) & 3u);
+    prob[i + 2] = m.step((four >> 4) & 3u);
+    prob[i + 3] = m.step(four >> 6);
+  }
+  for (; i < e; ++i) prob[i] = m.step(codeAt(codes, i));
 }
 
 }  // namespace
