@@ -444,12 +444,16 @@ static ArenaPlan plan_arena(u64 cap) {
   return a;
 }
 
-u64 BwtEngine::workspace_bytes(u32 max_block) { return plan_arena((u64)max_block + 1).total; }
+// Contexts for tiny blocks still get room for the entropy front-ends' per-section tables
+// (256 sections x 4096 run lengths).
+static u64 arena_items(u32 max_block) { return std::max<u64>((u64)max_block + 1, 1u << 20); }
+
+u64 BwtEngine::workspace_bytes(u32 max_block) { return plan_arena(arena_items(max_block)).total; }
 
 int BwtEngine::init(int dev, u32 max_block_size) {
   device = dev;
   max_block = max_block_size;
-  cap = (u64)max_block_size + 1;
+  cap = arena_items(max_block_size);
   std::memset(&stats, 0, sizeof stats);
   BWTC_HIP_TRY(hipSetDevice(dev));
   BWTC_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));

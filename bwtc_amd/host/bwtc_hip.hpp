@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -311,6 +312,15 @@ class EntropyEncoder {
  public:
   virtual ~EntropyEncoder() {}
   virtual size_t transformAndEncode(BWTBlock& block, BWTManager& bwtm, OutStream* out) = 0;
+  // Overlapped form for coders whose host half outlasts their device half: begin() returns
+  // when the device is free for the next block, finishOldest() writes the oldest block's
+  // record (waiting for it if need be).  Coders without a host half keep the defaults and
+  // Compressor::compress calls transformAndEncode block by block.
+  virtual bool overlapsBlocks() const { return false; }
+  virtual void begin(BWTBlock&, BWTManager&) {}
+  virtual size_t pending() const { return 0; }
+  virtual size_t depth() const { return 1; }
+  virtual size_t finishOldest(OutStream*) { return 0; }
 };
 
 class HuffmanEncoder : public EntropyEncoder {
@@ -333,9 +343,99 @@ class HuffmanEncoder : public EntropyEncoder {
   std::vector<byte> m_record;
 };
 
+// WaveletCoders.hpp:48-77, the 'B' models.  The encoder object carries the main model's
+// state from block to block (m_probModel; FSM8::resetModel keeps its state): that state
+// lives in the context and a new encoder starts a new stream there.
+class WaveletEncoder : public EntropyEncoder {
+ public:
+  explicit WaveletEncoder(char encoder = 'B') : m_fresh(true), m_ctx(0), m_dev(0), m_devBytes(0), m_next(0) { (void)encoder; }
+  ~WaveletEncoder() {
+    if (m_ctx && m_dev) bwtc_hip_free(m_ctx, m_dev);
+    for (size_t i = 0; i < m_slots.size(); ++i) std::free(m_slots[i].rec);
+  }
+  // WaveletCoders.cpp:70-86: transform, writeBlockHeader, encodeData, finishBlock
+  size_t transformAndEncode(BWTBlock& block, BWTManager& bwtm, OutStream* out) {
+    assert(!block.isTransformed());
+    start(bwtm);
+    m_record.resize(bwtc_hip_compress_bound((uint32)block.size()));
+    uint64_t n = 0;
+    hipFatal(bwtc_hip_transform_and_encode_wavelet(m_ctx, block.begin(), (uint32)block.size(),
+                                                   bwtm.getStartingPoints(), 0, &m_record[0],
+                                                   m_record.size(), &n),
+             "bwtc_hip_transform_and_encode_wavelet");
+    block.setTransformed(true);
+    out->writeBlock(&m_record[0], &m_record[0] + n);
+    return (size_t)n;
+  }
+  bool overlapsBlocks() const { return true; }
+  size_t depth() const { return kDepth; }
+  size_t pending() const { return m_order.size(); }
+  // device half: upload, transform on the device, run scanner + stream kernels; the models and
+  // range coders of the block are queued on the context's worker threads.  The block's bytes
+  // in host memory are left as they were.
+  void begin(BWTBlock& block, BWTManager& bwtm) {
+    assert(!block.isTransformed() && m_order.size() < kDepth);
+    start(bwtm);
+    const uint32 size = (uint32)block.size();
+    if (m_devBytes < (uint64)size + 64) {
+      if (m_dev) bwtc_hip_free(m_ctx, m_dev);
+      m_dev = bwtc_hip_malloc(m_ctx, (uint64)size + 64);
+      if (!m_dev) hipFatal(-2, "bwtc_hip_malloc");
+      m_devBytes = (uint64)size + 64;
+    }
+    if (m_slots.size() < kDepth) m_slots.resize(kDepth);
+    Slot& slot = m_slots[m_next % kDepth];
+    const uint64 cap = bwtc_hip_compress_bound(size);
+    if (slot.cap < cap) {                                         // not zero-filled: only the record's bytes get touched
+      std::free(slot.rec);
+      slot.rec = static_cast<byte*>(std::malloc(cap));
+      if (!slot.rec) hipFatal(-2, "malloc");
+      slot.cap = cap;
+    }
+    block.prepareLFpowers(bwtm.getStartingPoints());
+    uint32 freqs[256];
+    std::memset(freqs, 0, sizeof freqs);                          // WaveletCoders.cpp:78-79
+    hipFatal(bwtc_hip_memcpy_to_device(m_ctx, m_dev, block.begin(), size), "bwtc_hip_memcpy_to_device");
+    hipFatal(bwtc_hip_bwt_block_device(m_ctx, static_cast<const uint8_t*>(m_dev), static_cast<uint8_t*>(m_dev), size,
+                                       &block.LFpowers()[0], (uint32)block.LFpowers().size(), freqs),
+             "bwtc_hip_bwt_block_device");
+    hipFatal(bwtc_hip_wavelet_encode_device_begin(m_ctx, static_cast<const uint8_t*>(m_dev), size,
+                                                  &block.LFpowers()[0], (uint32)block.LFpowers().size(),
+                                                  freqs, 0, slot.rec, slot.cap, &slot.ticket),
+             "bwtc_hip_wavelet_encode_device_begin");
+    m_order.push_back(m_next % kDepth);
+    ++m_next;
+  }
+  size_t finishOldest(OutStream* out) {
+    assert(!m_order.empty());
+    Slot& slot = m_slots[m_order.front()];
+    m_order.erase(m_order.begin());
+    uint64_t n = 0;
+    hipFatal(bwtc_hip_wavelet_encode_end(m_ctx, slot.ticket, &n), "bwtc_hip_wavelet_encode_end");
+    out->writeBlock(slot.rec, slot.rec + n);
+    return (size_t)n;
+  }
+ private:
+  enum { kDepth = 8 };
+  struct Slot { byte* rec; uint64 cap; uint64_t ticket; Slot() : rec(0), cap(0), ticket(0) {} };
+  void start(BWTManager& bwtm) {
+    m_ctx = bwtm.hipContext();
+    if (m_fresh) { bwtc_hip_wavelet_reset(m_ctx); m_fresh = false; }
+  }
+  bool m_fresh;
+  bwtc_hip_ctx* m_ctx;
+  void* m_dev;
+  uint64 m_devBytes;
+  size_t m_next;
+  std::vector<Slot> m_slots;
+  std::vector<size_t> m_order;
+  std::vector<byte> m_record;
+};
+
 inline EntropyEncoder* giveEntropyEncoder(char encoder) {        // EntropyCoders.cpp:38-51
   if (encoder == 'H') return new HuffmanEncoder();
-  std::fprintf(stderr, "bwtc-hip: entropy coder '%c' is not built yet (only 'H')\n", encoder);
+  if (encoder == 'B') return new WaveletEncoder(encoder);
+  std::fprintf(stderr, "bwtc-hip: entropy coder '%c' is not built (this build offers H and B)\n", encoder);
   std::exit(1);
 }
 
@@ -381,21 +481,39 @@ class Compressor {
     size_t compressedSize = writeGlobalHeader();
     const size_t bs = bwtBlockSize();
     std::vector<byte> buf(bs + 1);
+    std::vector<size_t> sizes;                                    // blocks under way (overlapping coders)
     for (;;) {
       const size_t got = m_in->readBlock(&buf[0], bs);
       if (got == 0) break;
-      compressedSize += detail::writePacked(got, m_out);          // PrecompressorBlock.cpp:64-90
-      compressedSize += detail::writePacked(1, m_out);
-      m_out->writeByte(0); ++compressedSize;                      // empty grammar
       BWTBlock block(&buf[0], (uint32)got, false);
+      if (m_coder->overlapsBlocks()) {
+        // the device half of this block runs while worker threads still code earlier blocks;
+        // headers and records reach the stream in block order
+        if (m_coder->pending() >= m_coder->depth()) { compressedSize += writeFinished(sizes.front()); sizes.erase(sizes.begin()); }
+        m_coder->begin(block, m_bwtmanager);
+        sizes.push_back(got);
+        continue;
+      }
+      compressedSize += writeBlockPrefix(got);
       compressedSize += m_coder->transformAndEncode(block, m_bwtmanager, m_out);
     }
+    while (!sizes.empty()) { compressedSize += writeFinished(sizes.front()); sizes.erase(sizes.begin()); }
     m_out->writeByte(0); ++compressedSize;                        // writeEmptyHeader, :115
     m_out->flush();
     return compressedSize;
   }
   OutStream* out() { return m_out; }
  private:
+  size_t writeBlockPrefix(size_t got) {                           // PrecompressorBlock.cpp:64-90
+    size_t n = detail::writePacked(got, m_out);
+    n += detail::writePacked(1, m_out);
+    m_out->writeByte(0);                                          // empty grammar
+    return n + 1;
+  }
+  size_t writeFinished(size_t got) {
+    const size_t n = writeBlockPrefix(got);
+    return n + m_coder->finishOldest(m_out);
+  }
   InStream* m_in;
   OutStream* m_out;
   EntropyEncoder* m_coder;

@@ -116,6 +116,52 @@ static void testCompressorRoundTrip(std::mt19937& rng) {
   }
 }
 
+// The 'B' coder through the mirror: WaveletEncoder block by block (transformAndEncode) and
+// through Compressor::compress, which overlaps the blocks; many small blocks so that the
+// model state is carried across a dozen block borders while up to eight blocks are under way.
+static void testWaveletCompressor(std::mt19937& rng) {
+  struct Case { size_t size, mem; unsigned sp; bool rep; };
+  const Case cases[] = {{11, 1000, 1, false},        {1000, 2000, 3, true},      {100000, 1000000, 8, false},
+                        {2000000, 800000, 8, true},  {3000000, 100000000, 16, false}, {5000000, 1500000, 4, true}};
+  for (const Case& c : cases) {
+    std::vector<byte> data = c.rep ? repetitiveData(rng, c.size) : randomData(rng, c.size, 200);
+    MemoryOutStream* out = new MemoryOutStream();
+    Compressor compressor(new MemoryInStream(&data[0], data.size()), out, c.mem, 'B');
+    compressor.initializeBwtAlgorithm('g', c.sp);
+    const size_t reported = compressor.compress(1);
+    CHECK(reported == out->data.size(), "'B' compress() returned %zu, stream holds %zu", reported, out->data.size());
+    std::vector<byte> want(orc_compress_bound(data.size()) + 100000 * 8);
+    const size_t wn = orc_compress_B(&data[0], data.size(), compressor.bwtBlockSize(), c.sp, &want[0], want.size());
+    CHECK(wn == out->data.size() && std::memcmp(&want[0], &out->data[0], wn) == 0,
+          "'B' stream differs from the oracle's (size %zu mem %zu: %zu vs %zu bytes)", c.size, c.mem, out->data.size(), wn);
+  }
+  // block by block through the encoder object, as the reference's compress loop calls it
+  {
+    std::vector<byte> data = repetitiveData(rng, 900000);
+    const size_t bs = 250000;
+    BWTManager manager(8);
+    manager.setMaxBlockSize((uint32)bs);
+    manager.initialize('g');
+    MemoryOutStream out;
+    out.writeByte('B');
+    EntropyEncoder* enc = giveEntropyEncoder('B');
+    std::vector<byte> buf(bs + 1);
+    for (size_t off = 0; off < data.size(); off += bs) {
+      const size_t n = std::min(bs, data.size() - off);
+      std::memcpy(&buf[0], &data[off], n);
+      detail::writePacked(n, &out); detail::writePacked(1, &out); out.writeByte(0);
+      BWTBlock block(&buf[0], (uint32)n, false);
+      enc->transformAndEncode(block, manager, &out);
+      CHECK(block.isTransformed(), "block not marked transformed");
+    }
+    out.writeByte(0);
+    delete enc;
+    std::vector<byte> want(orc_compress_bound(data.size()) + 100000);
+    const size_t wn = orc_compress_B(&data[0], data.size(), bs, 8, &want[0], want.size());
+    CHECK(wn == out.data.size() && std::memcmp(&want[0], &out.data[0], wn) == 0, "'B' block-by-block stream differs");
+  }
+}
+
 // Compressor -> Decompressor entirely through this framework (GPU forward + inverse, host
 // entropy coder), and Decompressor on streams produced by the oracle's restatement of the
 // reference's Compressor, including the golden stream recorded from the reference itself.
@@ -161,6 +207,7 @@ int main() {
   testBlockTransformViaManager(rng);
   testInverseTransformer(rng);
   testCompressorRoundTrip(rng);
+  testWaveletCompressor(rng);
   testDecompressor(rng);
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all tests passed\n", failures);
   return failures ? 1 : 0;

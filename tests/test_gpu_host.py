@@ -45,6 +45,14 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     r = subprocess.run([unexe, "-v", "1", str(dst), str(out)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert out.read_bytes() == data.tobytes()
+    # the reference's default coder 'B' (no -e): five blocks, overlapped by the Compressor loop
+    dstb = tmp_path / "input.B.bwtc"
+    r = subprocess.run([exe, "-m", "4", "-s", "8", "-v", "1", str(src), str(dstb)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    sb = dstb.read_bytes()
+    assert sb[:1] == b"B"
+    assert sb == oracle.oracle_compress_B(data, int(4 * 1000000 * 0.185), 8).tobytes()
     # rejected choices, as the reference's validators do (compress.cpp:86-96)
     r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
     assert r.returncode != 0
