@@ -2,9 +2,13 @@
 // BWTBlock::readHeader (BWTBlock.cpp:88-102), Decompressor (Decompressor.cpp:45-94).  The
 // entropy decoder is serial host code (a section's streams have no length fields, so
 // nothing in a block can be decoded ahead); the inverse transform runs on the GPU
-// (HipInverseBWTransform).  Only coder 'H' and streams without precompression are accepted.
+// (HipInverseBWTransform).  WaveletDecoder ('B'; WaveletCoders.cpp:232-291, WaveletTree.hpp
+// readShape :403-500, decodeTreeBF :857-1174, message :1277-1378, BitDecoder BitCoders.cpp:115-148)
+// is serial host code for the same reason plus the adaptive models.  Coders 'H' and 'B' and
+// streams without precompression are accepted.
 #pragma once
 #include <cstring>
+#include <deque>
 
 #include "bwtc_hip.hpp"
 
@@ -145,9 +149,386 @@ class HuffmanDecoder : public EntropyDecoder {
   }
 };
 
+// ---- 'B' ------------------------------------------------------------------------------------
+namespace detail {
+
+// the three models of coder 'B' (probmodels/ProbabilityModel.cpp:38-75) as one table of
+// fifteen predictors: main FSM8 0..7, gaps FSM<4> 8..11, integers FSM<3> 12..14.  A predictor
+// moves 1/2^delay of the way towards its bound (BitPredictors.hpp:37-65); the upper four of
+// the main model predict the inverted bit and are kept as 4096 - p.
+struct WaveletModels {
+  uint32 q[15];
+  uint32 mc, gc, ic;
+  WaveletModels() : mc(4), gc(2), ic(1) { resetMain(); resetGaps(); resetInts(); }
+  void resetMain() {                                   // FSM8::resetModel keeps the state, FSM.hpp:196-205
+    static const uint32 init[8] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400};
+    for (int i = 0; i < 8; ++i) q[i] = init[i];
+  }
+  void resetGaps() { for (int i = 8; i < 12; ++i) q[i] = 2048; gc = 2; }
+  void resetInts() { for (int i = 12; i < 15; ++i) q[i] = 2048; ic = 1; }
+  static uint32 next(uint32 states, uint32 cur, bool bit) {          // FSM.hpp:42-67
+    if (states == 3) {
+      if (cur == 1) return bit ? 2 : 0;
+      if (cur == 2 && bit) return 2;
+      if (cur == 0 && !bit) return 0;
+      return 1;
+    }
+    if (bit) return cur >= states / 2 ? std::min(cur + 1, states - 1) : states / 2;
+    return cur < states / 2 ? (cur ? cur - 1 : 0) : (states - 1) / 2;
+  }
+  void move(uint32 slot, bool bit, uint32 floor, uint32 delay) {
+    q[slot] = bit ? q[slot] + (((4096 - floor) - q[slot]) >> delay) : q[slot] - ((q[slot] - floor) >> delay);
+  }
+  uint32 mainP() const { return q[mc]; }
+  void mainUpdate(bool bit) { move(mc, bit, 2, (mc == 0 || mc == 7) ? 4 : 5); mc = next(8, mc, bit); }
+  void mainState(bool bit) { mc = next(8, mc, bit); }
+  uint32 gapP() const { return q[8 + gc]; }
+  void gapUpdate(bool bit) { move(8 + gc, bit, 2, 5); gc = next(4, gc, bit); }
+  uint32 intP() const { return q[12 + ic]; }
+  void intUpdate(bool bit) { move(12 + ic, bit, 100, 5); ic = next(3, ic, bit); }
+};
+
+// BitDecoder, BitCoders.cpp:115-148
+struct RangeDecoder {
+  uint32 low, high, next;
+  MemoryBitReader* in;
+  void start(MemoryBitReader* r) {
+    in = r; low = 0; high = 0xFFFFFFFFu; next = 0;
+    for (int i = 0; i < 4; ++i) next = (next << 8) + in->readByte();
+  }
+  bool decode(uint32 p1) {
+    const uint32 size = high - low - 1;
+    const uint32 split = low + (size >> 12) * p1 + (((size & 4095u) * p1 + 2048u) >> 12);
+    const bool bit = next <= split;
+    if (bit) high = split; else low = split + 1;
+    while (((low ^ high) & 0xFF000000u) == 0) { low <<= 8; high = (high << 8) + 255; next = (next << 8) + in->readByte(); }
+    return bit;
+  }
+};
+
+struct BitQueue {                                       // bits of one tree node, read back in order
+  std::vector<uint64> w; size_t n, at;
+  BitQueue() : n(0), at(0) {}
+  void push(bool b) { if ((n & 63) == 0) w.push_back(0); w.back() |= (uint64)b << (n & 63); ++n; }
+  bool operator[](size_t i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+  bool take() { const bool b = (*this)[at]; ++at; return b; }
+};
+
+struct WtNode {
+  int left, right;
+  bool hasSymbol; uint32 symbol;
+  BitQueue bits;
+  WtNode() : left(-1), right(-1), hasSymbol(false), symbol(0) {}
+};
+
+typedef std::pair<uint64, uint32> LenSym;
+
+// WaveletTree::assignPrefixCodes(lengths, node, elem, bits), WaveletTree.hpp:1446-1482
+inline size_t assignPrefixCodes(std::vector<WtNode>& pool, const std::vector<LenSym>& lengths, int nd, size_t elem, size_t depth) {
+  if (elem >= lengths.size()) return elem;
+  if (depth == lengths[elem].first - 1) {
+    WtNode leaf; leaf.hasSymbol = true; leaf.symbol = lengths[elem].second;
+    pool.push_back(leaf);
+    const int c = (int)pool.size() - 1;
+    if (pool[nd].left < 0) { pool[nd].left = c; return assignPrefixCodes(pool, lengths, nd, elem + 1, depth); }
+    pool[nd].right = c;
+    return elem + 1;
+  }
+  if (pool[nd].left < 0) {
+    pool.push_back(WtNode());
+    const int c = (int)pool.size() - 1;
+    pool[nd].left = c;
+    elem = assignPrefixCodes(pool, lengths, c, elem, depth + 1);
+  }
+  if (elem < lengths.size()) {
+    pool.push_back(WtNode());
+    const int c = (int)pool.size() - 1;
+    pool[nd].right = c;
+    elem = assignPrefixCodes(pool, lengths, c, elem, depth + 1);
+  }
+  return elem;
+}
+
+inline uint64 readPackedIntegerRev(MemoryBitReader& in) {           // utils::readPackedIntegerRev: bytes LSB first
+  uint64 result = 0; unsigned shift = 0; uint32 byte_;
+  do {
+    byte_ = 0;
+    for (int i = 0; i < 8; ++i) byte_ |= (in.readBit() ? 1u : 0u) << i;
+    result |= (uint64)(byte_ & 0x7F) << shift;
+    shift += 7;
+  } while (byte_ & 0x80);
+  return result;
+}
+
+}  // namespace detail
+
+class WaveletDecoder : public EntropyDecoder {
+ public:
+  explicit WaveletDecoder(char decoder = 'B') { (void)decoder; }
+  void decodeBlock(BWTBlock& block, MemoryBitReader& in, size_t capacity) {
+    const uint64 compressed = in.readBits(48);                       // readBlockHeader, WaveletCoders.cpp:232-244
+    const size_t start = in.position();
+    const uint32 nLF = (uint32)in.readByte() + 1;
+    block.LFpowers().resize(nLF);
+    for (uint32 i = 0; i < nLF; ++i) block.LFpowers()[i] = (uint32)in.readBits(31);
+    in.flushBuffer();
+    size_t sections = in.readByte();
+    if (sections == 0) sections = 256;
+    std::vector<uint64> lengths(sections);
+    uint64 total = 0;
+    for (size_t i = 0; i < sections; ++i) { lengths[i] = in.readPackedInteger(); total += lengths[i]; }
+    if (total > capacity) MemoryBitReader::fail("block larger than announced");
+    byte* dst = block.begin();
+    for (size_t s = 0; s < sections; ++s) {                          // decodeBlock, :246-291
+      if (lengths[s] == 0) continue;
+      const size_t rootSize = (size_t)in.readPackedInteger();
+      Tree tree;
+      tree.readShape(in);
+      in.flushBuffer();
+      m_rc.start(&in);
+      tree.decodeTreeBF(rootSize, m_rc, m_models);
+      const size_t got = tree.message(dst, lengths[s]);
+      if (got != lengths[s]) MemoryBitReader::fail("section length");
+      dst += got;
+      m_models.resetMain(); m_models.resetInts(); m_models.resetGaps();   // endContextBlock, :70-76
+    }
+    if (in.position() - start != compressed) MemoryBitReader::fail("block length field");
+    block.setSize((uint32)total);
+  }
+
+ private:
+  struct Tree {
+    std::vector<detail::WtNode> nodes;      // [0] = root of the symbol tree; integer data nodes hang below its leaves
+    std::vector<detail::WtNode> codeTree;   // prefix code of the run lengths; [0] = root
+    uint32 W;
+    bool plainFixed;                        // no length has a code of its own: every run is escape coded
+    Tree() : nodes(1), codeTree(1), W(0), plainFixed(false) {}
+
+    void readShape(MemoryBitReader& in) {                            // WaveletTree.hpp:403-500
+      const size_t maxSym = in.readByte();
+      size_t symbols = in.readByte();
+      if (symbols == 0) symbols = 256;
+      size_t maxLen = (size_t)detail::readPackedIntegerRev(in);
+      std::vector<uint32> alphabet;
+      detail::interpolativeDecode(in, alphabet, 0, maxSym, symbols);
+      std::vector<detail::LenSym> lengths;
+      for (size_t i = 0; i < symbols; ++i) {
+        size_t n = 1; while (!in.readBit()) ++n;                     // utils::unaryDecode
+        if (n > maxLen) MemoryBitReader::fail("symbol code length");
+        lengths.push_back(detail::LenSym(maxLen - n + 1, alphabet[i]));
+      }
+      std::sort(lengths.begin(), lengths.end());                     // assignPrefixCodes(lengths), :1440-1444
+      detail::assignPrefixCodes(nodes, lengths, 0, 0, 0);
+      symbolNodes = (int)nodes.size();                               // what follows are run-length nodes
+      const size_t longestRun = (size_t)detail::readPackedIntegerRev(in);
+      if (longestRun > 0) {
+        symbols = (size_t)detail::readPackedIntegerRev(in);
+        maxLen = (size_t)detail::readPackedIntegerRev(in);
+        std::vector<uint32> integers;
+        detail::interpolativeDecode(in, integers, 0, longestRun, symbols);
+        std::vector<detail::LenSym> integerLengths;
+        for (size_t i = 0; i < symbols; ++i) {
+          size_t n = 1; while (!in.readBit()) ++n;
+          if (n > maxLen) MemoryBitReader::fail("integer code length");
+          integerLengths.push_back(detail::LenSym(maxLen + 1 - n, integers[i]));
+        }
+        std::sort(integerLengths.begin(), integerLengths.end());
+        detail::assignPrefixCodes(codeTree, integerLengths, 0, 0, 0);
+      } else {
+        codeTree[0].hasSymbol = true;                                // TreeNode(0): the escape code is the empty word
+        codeTree[0].symbol = 0;
+        plainFixed = true;
+      }
+      W = (uint32)in.readBits(4);
+    }
+
+    // a node of an integer level on its way through the level-synchronised decoding, :837-853
+    struct IntegerNode {
+      int node, code;                       // data node; node of the length code tree or -1 once in the fixed part
+      size_t bits; uint32 leadingOnes; int status;
+    };
+
+    int child(int nd, bool right) {
+      int& c = right ? nodes[nd].right : nodes[nd].left;
+      if (c < 0) { nodes.push_back(detail::WtNode()); const int id = (int)nodes.size() - 1; (right ? nodes[nd].right : nodes[nd].left) = id; return id; }
+      return c;
+    }
+
+    void decodeTreeBF(size_t rootSize, detail::RangeDecoder& dec, detail::WaveletModels& m) {   // :857-1174
+      typedef std::pair<int, detail::BitQueue> Inner;                // node, its gap vector
+      std::deque<Inner> queue;
+      std::deque<IntegerNode> level;
+      if (rootSize == 0) MemoryBitReader::fail("empty wavelet tree");
+      {
+        detail::BitQueue left, right;
+        bool prev = dec.decode(m.mainP());
+        m.mainUpdate(prev);
+        nodes[0].bits.push(prev);
+        (prev ? right : left).push(true);
+        for (size_t i = 1; i < rootSize; ++i) {
+          const bool bit = dec.decode(m.mainP());
+          m.mainUpdate(bit);
+          nodes[0].bits.push(bit);
+          (bit ? right : left).push(prev != bit);
+          prev = bit;
+        }
+        if (nodes[0].left < 0) MemoryBitReader::fail("tree without symbols");
+        if (nodes[nodes[0].left].hasSymbol) level.push_back(IntegerNode{nodes[0].left, 0, left.n, 0, 0});
+        else queue.push_back(Inner(nodes[0].left, left));
+        if (right.n > 0) {
+          if (nodes[0].right < 0) MemoryBitReader::fail("bits for a missing subtree");
+          if (nodes[nodes[0].right].hasSymbol) level.push_back(IntegerNode{nodes[0].right, 0, right.n, 0, 0});
+          else queue.push_back(Inner(nodes[0].right, right));
+        }
+      }
+      while (!queue.empty()) {
+        m.resetMain();
+        m.resetGaps();
+        const int id = queue.front().first;
+        detail::BitQueue gaps;
+        std::swap(gaps, queue.front().second);
+        queue.pop_front();
+        if (nodes[id].left < 0 || nodes[id].right < 0) MemoryBitReader::fail("inner node with one child");
+        const int l = nodes[id].left, r = nodes[id].right;
+        detail::BitQueue left, right;
+        bool prev = true;
+        if (nodes[l].hasSymbol && nodes[r].hasSymbol) {
+          size_t ones = 0;
+          for (size_t i = 0; i < gaps.n; ++i) {
+            if (!gaps[i]) prev = !prev;
+            else { prev = dec.decode(m.gapP()); m.gapUpdate(prev); }
+            nodes[id].bits.push(prev);
+            ones += prev;
+          }
+          level.push_back(IntegerNode{l, 0, gaps.n - ones, 0, 0});
+          level.push_back(IntegerNode{r, 0, ones, 0, 0});
+        } else if (nodes[l].hasSymbol) {
+          for (size_t i = 0; i < gaps.n; ++i) {
+            bool bit;
+            if (!gaps[i] && !prev) bit = true;
+            else if (gaps[i]) { bit = dec.decode(m.gapP()); m.gapUpdate(bit); m.mainState(bit); }
+            else { bit = dec.decode(m.mainP()); m.mainUpdate(bit); }
+            nodes[id].bits.push(bit);
+            if (bit) right.push(prev != bit || gaps[i]);
+            prev = bit;
+          }
+          level.push_back(IntegerNode{l, 0, gaps.n - right.n, 0, 0});
+          queue.push_back(Inner(r, right));
+        } else if (!nodes[r].hasSymbol) {
+          for (size_t i = 0; i < gaps.n; ++i) {
+            bool bit;
+            if (gaps[i]) { bit = dec.decode(m.gapP()); m.gapUpdate(bit); m.mainState(bit); }
+            else { bit = dec.decode(m.mainP()); m.mainUpdate(bit); }
+            nodes[id].bits.push(bit);
+            (bit ? right : left).push(prev != bit || gaps[i]);
+            prev = bit;
+          }
+          queue.push_back(Inner(l, left));
+          queue.push_back(Inner(r, right));
+        } else {
+          MemoryBitReader::fail("tree shape the encoder cannot produce");
+        }
+      }
+      // integer levels: all nodes of a level, then its left children, then its right children
+      std::deque<IntegerNode> lefts, rights;
+      while (!level.empty()) {
+        m.resetInts();
+        lefts.clear(); rights.clear();
+        while (!level.empty()) {
+          IntegerNode nd = level.front();
+          level.pop_front();
+          if (nd.code >= 0 && codeTree[nd.code].hasSymbol) {
+            nodes[nd.node].hasSymbol = true;
+            if (!plainFixed) nodes[nd.node].symbol = codeTree[nd.code].symbol;   // :1041-1044
+            if (codeTree[nd.code].symbol != 0) continue;
+          }
+          size_t ones = 0;
+          for (size_t i = 0; i < nd.bits; ++i) {
+            const bool bit = dec.decode(m.intP());
+            m.intUpdate(bit);
+            ones += bit;
+            nodes[nd.node].bits.push(bit);
+          }
+          const bool inCode = nd.code >= 0 && !codeTree[nd.code].hasSymbol;
+          if (nd.bits > ones) {
+            IntegerNode c = {child(nd.node, false), inCode ? codeTree[nd.code].left : -1, nd.bits - ones, nd.leadingOnes, nd.status};
+            if (c.code < 0) {
+              if (nd.status == 0) { c.status = 2; c.leadingOnes = W; }
+              else if (nd.status == 1) { c.status = 2; c.leadingOnes += W; }
+              else --c.leadingOnes;
+            }
+            if (c.status != 2 || c.leadingOnes > 0) lefts.push_back(c);
+          }
+          if (ones > 0) {
+            IntegerNode c = {child(nd.node, true), inCode ? codeTree[nd.code].right : -1, ones, nd.leadingOnes, nd.status};
+            if (c.code < 0) {
+              if (nd.status == 0) { c.status = 1; ++c.leadingOnes; }
+              else if (nd.status == 1) ++c.leadingOnes;
+              else --c.leadingOnes;
+            }
+            if (c.status != 2 || c.leadingOnes > 0) rights.push_back(c);
+          }
+        }
+        level.insert(level.end(), lefts.begin(), lefts.end());
+        level.insert(level.end(), rights.begin(), rights.end());
+      }
+    }
+
+    // message, :1277-1378: every node's bits are used in order, so a read cursor per node
+    // stands in for the reference's rank bookkeeping
+    size_t message(byte* out, uint64 room) {
+      size_t len = 0;
+      const size_t runs = nodes[0].bits.n;
+      for (size_t j = 0; j < runs; ++j) {
+        int nd = 0;
+        do { const bool bit = take(nd); nd = bit ? nodes[nd].right : nodes[nd].left; if (nd < 0) MemoryBitReader::fail("symbol path"); }
+        while (!isSymbolLeaf(nd));
+        const byte symbol = (byte)nodes[nd].symbol;
+        uint64 runLength = 0;
+        int code = 0;
+        if (!plainFixed) {
+          do {
+            const bool bit = take(nd);
+            nd = bit ? nodes[nd].right : nodes[nd].left;
+            code = bit ? codeTree[code].right : codeTree[code].left;
+            if (nd < 0 || code < 0) MemoryBitReader::fail("length code path");
+          } while (!codeTree[code].hasSymbol);
+          runLength = codeTree[code].symbol;
+        }
+        if (runLength == 0) {                                        // escape: the fixed code, :514-533
+          uint32 leadingOnes = 0;
+          bool bit = take(nd);
+          while (bit) { ++leadingOnes; nd = nodes[nd].right; if (nd < 0) MemoryBitReader::fail("fixed code"); bit = take(nd); }
+          for (uint32 k = 0; k < leadingOnes + W; ++k) {
+            runLength <<= 1;
+            nd = bit ? nodes[nd].right : nodes[nd].left;
+            if (nd < 0) MemoryBitReader::fail("fixed code");
+            bit = take(nd);
+            runLength |= bit ? 1u : 0u;
+          }
+          runLength += 1 + (((uint64(1) << leadingOnes) - 1) << W);
+        }
+        if (runLength > room - len) MemoryBitReader::fail("run length");
+        std::memset(out + len, symbol, runLength);
+        len += runLength;
+      }
+      return len;
+    }
+    bool take(int nd) {
+      if (nodes[nd].bits.at >= nodes[nd].bits.n) MemoryBitReader::fail("node out of bits");
+      return nodes[nd].bits.take();
+    }
+    bool isSymbolLeaf(int nd) const { return nd < symbolNodes && nodes[nd].hasSymbol; }
+    int symbolNodes = 0;
+  };
+  detail::WaveletModels m_models;
+  detail::RangeDecoder m_rc;
+};
+
 inline EntropyDecoder* giveEntropyDecoder(char decoder) {            // EntropyCoders.cpp:53-65
   if (decoder == 'H') return new HuffmanDecoder();
-  std::fprintf(stderr, "bwtc-hip: entropy decoder '%c' is not built (only 'H')\n", decoder);
+  if (decoder == 'B') return new WaveletDecoder(decoder);
+  std::fprintf(stderr, "bwtc-hip: entropy decoder '%c' is not built (this build offers H and B)\n", decoder);
   std::exit(1);
 }
 

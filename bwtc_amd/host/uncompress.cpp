@@ -1,5 +1,5 @@
 // uncompress -- command-line front end with the reference's flag surface
-// (uncompress.cpp:53-65): Huffman ('H') streams, inverse BWT on the MI355X.
+// (uncompress.cpp:53-65): wavelet ('B') and Huffman ('H') streams, inverse BWT on the MI355X.
 //   uncompress [-i] [-c] [-d device] [-v N] [input] [output]
 #include <getopt.h>
 #include <chrono>

@@ -162,6 +162,51 @@ static void testWaveletCompressor(std::mt19937& rng) {
   }
 }
 
+// WaveletDecoder: streams written by the oracle's restatement of the reference's 'B' encoder
+// (golden stream included) and by this framework's own compressor decode back to the input --
+// single symbols, one-run blocks, long runs (escape codes), 256 sections, several blocks.
+static void testWaveletDecompressor(std::mt19937& rng) {
+  std::vector<std::vector<byte> > inputs;
+  const char* golden = "abracadabra";
+  inputs.push_back(std::vector<byte>(golden, golden + 11));
+  inputs.push_back(std::vector<byte>(1, 'x'));
+  inputs.push_back(std::vector<byte>(70001, 7));
+  inputs.push_back(randomData(rng, 300000, 256));
+  inputs.push_back(randomData(rng, 200000, 3));
+  inputs.push_back(repetitiveData(rng, 1500000));
+  { std::vector<byte> runs;                                           // long runs: lengths up to 5000
+    while (runs.size() < 2000000) runs.insert(runs.end(), 1 + rng() % 5000, (byte)(rng() % 5));
+    inputs.push_back(runs); }
+  { std::vector<byte> skew(800000);                                  // geometric symbols, short runs
+    for (size_t i = 0; i < skew.size(); ++i) { unsigned v = 0; while ((rng() & 3) && v < 200) ++v; skew[i] = (byte)v; }
+    inputs.push_back(skew); }
+  const size_t blockSizes[] = {1u << 30, 400000};
+  for (size_t k = 0; k < inputs.size(); ++k) {
+    const std::vector<byte>& data = inputs[k];
+    for (size_t b = 0; b < 2; ++b) {
+      const size_t bs = std::min(blockSizes[b], std::max<size_t>(data.size(), 1));
+      std::vector<byte> stream(orc_compress_bound(data.size()) + 100000 * 8);
+      const size_t sn = orc_compress_B(&data[0], data.size(), bs, 8, &stream[0], stream.size());
+      MemoryOutStream* plain = new MemoryOutStream();
+      Decompressor d(new MemoryInStream(&stream[0], sn), plain);
+      const size_t n = d.decompress(1);
+      CHECK(n == data.size() && plain->data == data, "'B' oracle stream -> Decompressor (input %zu, block %zu)", k, bs);
+    }
+  }
+  {                                                                   // own compressor -> own decompressor
+    std::vector<byte> data = repetitiveData(rng, 3000000);
+    MemoryOutStream* packed = new MemoryOutStream();
+    Compressor compressor(new MemoryInStream(&data[0], data.size()), packed, 3000000, 'B');
+    compressor.initializeBwtAlgorithm('g', 8);
+    compressor.compress(1);
+    std::vector<byte> stream = packed->data;
+    MemoryOutStream* plain = new MemoryOutStream();
+    Decompressor d(new MemoryInStream(&stream[0], stream.size()), plain);
+    const size_t n = d.decompress(1);
+    CHECK(n == data.size() && plain->data == data, "'B' Compressor -> Decompressor round trip");
+  }
+}
+
 // Compressor -> Decompressor entirely through this framework (GPU forward + inverse, host
 // entropy coder), and Decompressor on streams produced by the oracle's restatement of the
 // reference's Compressor, including the golden stream recorded from the reference itself.
@@ -208,6 +253,7 @@ int main() {
   testInverseTransformer(rng);
   testCompressorRoundTrip(rng);
   testWaveletCompressor(rng);
+  testWaveletDecompressor(rng);
   testDecompressor(rng);
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all tests passed\n", failures);
   return failures ? 1 : 0;

@@ -53,6 +53,10 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     sb = dstb.read_bytes()
     assert sb[:1] == b"B"
     assert sb == oracle.oracle_compress_B(data, int(4 * 1000000 * 0.185), 8).tobytes()
+    outb = tmp_path / "roundtrip.B.bin"
+    r = subprocess.run([unexe, "-v", "1", str(dstb), str(outb)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert outb.read_bytes() == data.tobytes()
     # rejected choices, as the reference's validators do (compress.cpp:86-96)
     r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
     assert r.returncode != 0

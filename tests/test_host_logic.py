@@ -186,3 +186,16 @@ def test_wavelet_golden_stream_from_reference(oracle):
     bwt, lf, freqs = oracle.oracle_bwt_block(d, c["sp"])
     got, _ = _host_wavelet_payload(H, bwt, oracle.oracle_sections(freqs))
     assert bytes.fromhex(c["stream_hex"])[17:-1] == got
+
+
+def test_wavelet_decoder_program(oracle):
+    """The host mirror's WaveletDecoder ('B') on streams written by the oracle's
+    restatement of the reference encoder: tests/cpp/wavelet_decoder_test.cpp (no device calls)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "wavelet_decoder_test")
+    r = subprocess.run(["make", "-C", os.path.join(root, "bwtc_amd", "host"), "../../tests/cpp/wavelet_decoder_test"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all tests passed" in r.stdout, r.stdout + r.stderr
