@@ -60,3 +60,26 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     # rejected choices, as the reference's validators do (compress.cpp:86-96)
     r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_cli_roundtrip_full_size_block_default_coder(tmp_path):
+    """BASELINE's configuration end to end: one 256 MiB text block, the default 'B' coder,
+    compress -> uncompress (host wavelet decoder + GPU inverse BWT) gives the input back.
+    Size-independent property; no oracle involved."""
+    exe = os.path.join(ROOT, "bwtc_amd", "host", "compress")
+    unexe = os.path.join(ROOT, "bwtc_amd", "host", "uncompress")
+    data = synth.gen_text(256 << 20, 3)
+    src = tmp_path / "text256.bin"
+    dst = tmp_path / "text256.bwtc"
+    out = tmp_path / "text256.out"
+    src.write_bytes(data.tobytes())
+    # --mem 1452 -> BWT block 0.185 * 1452e6 = 268.6 MB >= 256 MiB: one block
+    r = subprocess.run([exe, "-m", "1452", "-s", "8", "-v", "1", str(src), str(dst)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    packed = dst.stat().st_size
+    assert 40_000_000 < packed < 60_000_000, packed
+    r = subprocess.run([unexe, "-v", "1", str(dst), str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    back = np.fromfile(out, np.uint8)
+    assert back.size == data.size and (back == data).all()
