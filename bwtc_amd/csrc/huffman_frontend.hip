@@ -9,16 +9,14 @@
 //             of the code lengths -> absolute bit position -> MSB-first bits OR-ed into the
 //             output
 // The small-table work in between (code lengths, canonical codes, shape, headers) is host
-// code in entropy_host.cpp.
+// code in entropy_host.cpp.  The run scanner and the per-section run statistics are shared
+// with the 'B' coder (wavelet_section_stats_device below; the rest of 'B' is in
+// wavelet_tree.hip / wavelet_encoder.hip).
 #include "bwt_engine.hpp"
 #include "entropy_host.hpp"
 #include "wavelet_host.hpp"
-#include "wavelet_pipeline.hpp"
 #include "scan.hpp"
 #include <algorithm>
-#include <chrono>
-#include <map>
-#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -634,178 +632,5 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   return 0;
 }
 
-
-// Appends the finished sections to the record and closes it (finishBlock,
-// WaveletCoders.cpp:159-163); the worker that finishes a block's last section runs this.
-static void finish_wavelet_job(WaveletJob& job) {
-  std::vector<uint8_t>& rec = job.record;
-  size_t total = rec.size();
-  for (size_t s = 0; s < job.outs.size(); ++s) total += job.outs[s].bytes.size();
-  rec.reserve(total);
-  for (size_t s = 0; s < job.outs.size(); ++s) rec.insert(rec.end(), job.outs[s].bytes.begin(), job.outs[s].bytes.end());
-  const u64 len = rec.size() - 6;
-  for (int i = 0; i < 6; ++i) rec[i] = (uint8_t)(len >> (8 * (5 - i)));
-  if (job.user_out && rec.size() <= job.user_cap) std::memcpy(job.user_out, rec.data(), rec.size());
-  { std::lock_guard<std::mutex> g(job.mu); job.done = true; }
-  job.cv.notify_all();
-}
-
-int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
-                         const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
-  if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
-  // bounded number of blocks under way: wait for the oldest one (its result stays collectable)
-  while (e.jobs.size() >= e.max_inflight) {
-    WaveletJob& oldest = *e.jobs.begin()->second;
-    std::unique_lock<std::mutex> g(oldest.mu);
-    if (oldest.done) return -6;                     // finished blocks must be collected with ..._end first
-    oldest.cv.wait(g, [&] { return oldest.done; });
-  }
-  std::shared_ptr<WaveletJob> jobp(new WaveletJob());
-  WaveletJob& job = *jobp;
-  job.user_out = out;
-  job.user_cap = out_cap;
-  // header: WaveletEncoder::writeBlockHeader, WaveletCoders.cpp:173-219
-  std::vector<uint8_t>& rec = job.record;
-  rec.assign(6, 0);
-  bwtc::writeBWTBlockHeader(lf, n_lf, rec);
-  WaveletSectionStats st;
-  const auto t_begin = std::chrono::steady_clock::now();
-  int rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st);
-  if (rc) return rc;
-  const u32 nsec = (u32)st.sections.size();
-  rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
-  for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
-  bool queued = false;
-  if (size && nsec) {
-    const u32 n_runs = st.first_run[nsec];
-    std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
-    for (u32 s = 0; s < nsec; ++s) {
-      bwtc::wavelet::SectionRuns& r = secs[s];
-      r.symbols = nullptr;
-      r.starts = nullptr;
-      r.n_runs = st.first_run[s + 1] - st.first_run[s];
-      r.run_freqs = &st.run_freqs[(size_t)s * 256];
-      r.dist = st.dist[s].data();
-      r.n_dist = st.dist[s].size();
-    }
-    // Tree bit vectors and traversal on the GPU (wavelet_tree.hip), models + range coder on the
-    // host.  Shapes the device path does not take (planStreams) and BWTC_HIP_WAVELET=host go
-    // through the host's own tree builder instead; both are this library's code and give the
-    // same bytes.
-    const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const bool on_device = !e.wavelet_on_host && bwtc::wavelet::planStreams(secs, &job.plan) &&
-                           job.plan.max_elements + (1u << 16) < (1ull << 32);
-    if (on_device) {
-      const auto t1 = std::chrono::steady_clock::now();
-      const u8* codes = nullptr;
-      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &codes);
-      if (rc) return rc;
-      const auto t2 = std::chrono::steady_clock::now();
-      // the streams leave the engine's pinned buffer, the next block will overwrite it
-      const u64 code_bytes = (e.wt_coded + 3) / 4 + 8;
-      if (!e.codes_free.empty()) { job.codes.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-      if (!job.codes.reserve(code_bytes)) return -2;
-      std::memcpy(job.codes.data(), codes, (e.wt_coded + 3) / 4);
-      job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state));
-      e.wavelet_state = job.coder->endState();
-      if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
-      if (!job.prob.reserve(job.coder->elements() + 8)) return -2;
-      job.outs.assign(nsec, bwtc::wavelet::SectionOutput());
-      job.models_left = job.coder->modelTasks();
-      job.sections_left = job.coder->sectionTasks();
-      if (!e.pool) e.pool = new WorkerPool(threads);
-      const auto t3 = std::chrono::steady_clock::now();
-      if (job.models_left == 0 || job.sections_left == 0) {
-        finish_wavelet_job(job);
-      } else {
-        WorkerPool* pool = e.pool;
-        for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
-          pool->submit([jobp, pool, k] {
-            WaveletJob& j = *jobp;
-            j.coder->model(k, j.prob.data());
-            bool last;
-            { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
-            if (!last) return;
-            // every group is modelled: the sections' range coders, ahead of newer blocks' work
-            std::vector<std::function<void()> > next;
-            for (size_t q = 0; q < j.coder->sectionTasks(); ++q) {
-              next.push_back([jobp, q] {
-                WaveletJob& jj = *jobp;
-                jj.coder->codeSection(q, jj.prob.data(), &jj.outs);
-                bool fin;
-                { std::lock_guard<std::mutex> g(jj.mu); fin = --jj.sections_left == 0; }
-                if (fin) finish_wavelet_job(jj);
-              });
-            }
-            pool->submitFront(next);
-          });
-        }
-      }
-      if (debug) {
-        const auto t4 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; run scanner %.1f ms, plan %.1f ms, "
-                     "device streams %.1f ms, hand-over %.1f ms, queueing %.1f ms on %u threads\n", n_runs,
-                     (unsigned long long)e.wt_elements, (unsigned long long)e.wt_coded, job.plan.group_type.size(),
-                     std::chrono::duration<double, std::milli>(t0 - t_begin).count(),
-                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                     std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                     std::chrono::duration<double, std::milli>(t3 - t2).count(),
-                     std::chrono::duration<double, std::milli>(t4 - t3).count(), e.pool->size());
-      }
-      queued = true;
-    } else {
-      // the runs themselves: symbols and start offsets, left in the workspace by the scanner
-      std::vector<u8> run_sym(n_runs);
-      std::vector<u32> run_start((size_t)n_runs + 1);
-      BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
-      for (u32 s = 0; s < nsec; ++s) {
-        secs[s].symbols = run_sym.data() + st.first_run[s];
-        secs[s].starts = run_start.data() + st.first_run[s];
-      }
-      bwtc::wavelet::encodeSections(secs, threads, &e.wavelet_state, &job.outs);
-    }
-  }
-  if (!queued) finish_wavelet_job(job);
-  *ticket = e.next_ticket++;
-  e.jobs[*ticket] = jobp;
-  return 0;
-}
-
-int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
-  std::map<u64, std::shared_ptr<WaveletJob> >::iterator it = e.jobs.find(ticket);
-  if (it == e.jobs.end() || !out_bytes) return -1;
-  std::shared_ptr<WaveletJob> jobp = it->second;
-  WaveletJob& job = *jobp;
-  { std::unique_lock<std::mutex> g(job.mu); job.cv.wait(g, [&] { return job.done; }); }
-  e.jobs.erase(it);
-  // keep the two big buffers: fresh ones would be paged in again for every block
-  if (job.codes.size() && e.codes_free.size() < e.max_inflight) {
-    e.codes_free.push_back(std::unique_ptr<RawBuffer<uint8_t> >(new RawBuffer<uint8_t>()));
-    e.codes_free.back()->swap(job.codes);
-  }
-  if (job.prob.size() && e.prob_free.size() < e.max_inflight) {
-    e.prob_free.push_back(std::unique_ptr<RawBuffer<uint16_t> >(new RawBuffer<uint16_t>()));
-    e.prob_free.back()->swap(job.prob);
-  }
-  *out_bytes = job.record.size();
-  return job.record.size() <= job.user_cap ? 0 : -1;
-}
-
-void wavelet_pipeline_release(BwtEngine& e) {
-  for (std::map<u64, std::shared_ptr<WaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it) {
-    WaveletJob& job = *it->second;
-    job.user_out = nullptr;
-    std::unique_lock<std::mutex> g(job.mu);
-    job.cv.wait(g, [&] { return job.done; });
-  }
-  e.jobs.clear();
-  delete e.pool;
-  e.pool = nullptr;
-  e.codes_free.clear();
-  e.prob_free.clear();
-}
 
 }  // namespace bwtc_hip

@@ -204,3 +204,51 @@ def test_wavelet_B_overlapped_blocks_equal_the_sequential_stream(hip_ctx, oracle
         stream += _packed(n) + _packed(1) + b"\x00" + out[:m].tobytes()
     stream += b"\x00"
     assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes()
+
+
+def test_wavelet_B_pipeline_limits_and_misuse(oracle):
+    """Depth limit and ticket handling of _begin/_end: an unknown ticket is refused, a finished
+    but uncollected oldest block makes a further _begin return -6 instead of waiting forever,
+    and collecting in any order still gives every block's own record."""
+    from bwtc_amd import hip
+    os.environ["BWTC_HIP_WAVELET_DEPTH"] = "2"
+    try:
+        ctx = hip.Context(device=0, max_block_size=(1 << 20) + 1024)
+    finally:
+        del os.environ["BWTC_HIP_WAVELET_DEPTH"]
+    try:
+        blocks = [synth.gen_text(300000, 40 + i) for i in range(3)]
+        outs, tickets, metas = [], [], []
+        d_in = ctx.dmalloc((1 << 20) + 64)
+        ctx.wavelet_reset()
+        for blk in blocks[:2]:
+            ctx.to_device(d_in, blk)
+            lf, freqs = ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+            out = np.zeros(ctx.compress_bound(blk.size), np.uint8)
+            tickets.append(ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=2))
+            outs.append(out)
+        with pytest.raises(hip.BwtcHipError):
+            ctx.wavelet_encode_end(987654)                       # never issued
+        # wait until the oldest is done without collecting it, then a third _begin must say -6
+        import time
+        time.sleep(2.0)
+        ctx.to_device(d_in, blocks[2])
+        lf, freqs = ctx.bwt_block_device(d_in, d_in, blocks[2].size, 8)
+        out3 = np.zeros(ctx.compress_bound(blocks[2].size), np.uint8)
+        with pytest.raises(hip.BwtcHipError) as err:
+            ctx.wavelet_encode_device_begin(d_in, blocks[2].size, lf, freqs, out3, threads=2)
+        assert "-6" in str(err.value)
+        # collect newest first
+        n1 = ctx.wavelet_encode_end(tickets[1])
+        n0 = ctx.wavelet_encode_end(tickets[0])
+        with pytest.raises(hip.BwtcHipError):
+            ctx.wavelet_encode_end(tickets[0])                   # already collected
+        stream = b"B"
+        for blk, out, n in zip(blocks[:2], outs, (n0, n1)):
+            stream += _packed(blk.size) + _packed(1) + b"\x00" + out[:n].tobytes()
+        stream += b"\x00"
+        want = oracle.oracle_compress_B(np.concatenate(blocks[:2]), 300000, 8).tobytes()
+        assert stream == want
+        ctx.dfree(d_in)
+    finally:
+        ctx.close()
