@@ -82,6 +82,7 @@ struct BwtEngine {
 
   bwtc_hip_stats stats;
   u32 wavelet_state = 4;   // FSM8 state carried from block to block by one WaveletEncoder
+  char wavelet_model = 'B'; // coder letter = main probability model ('B', 'b' or 'u')
   ScatterProbe probe;
 
   static u64 workspace_bytes(u32 max_block);

@@ -303,7 +303,13 @@ static unsigned pick_threads(uint32_t threads) {
   return n > 1 ? std::min(n - 1, 64u) : 1;   // one is left to the thread that feeds the GPU
 }
 
-void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { if (ctx) ctx->eng.wavelet_state = 4; }
+int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
+  if (!ctx || !bwtc::wavelet::isWaveletModel(coder)) return -1;
+  ctx->eng.wavelet_state = 4;
+  ctx->eng.wavelet_model = coder;
+  return 0;
+}
+void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }
 
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                          const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
@@ -366,10 +372,10 @@ int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_ru
                                    const uint8_t* run_sym, const uint32_t* run_start,
                                    const uint32_t* run_freqs, const uint32_t* dist_offset,
                                    const uint32_t* dist_len, const uint32_t* dist_cnt,
-                                   uint32_t threads, uint32_t* state, uint8_t* out,
+                                   uint32_t threads, char coder, uint32_t* state, uint8_t* out,
                                    uint64_t out_cap, uint64_t* out_bytes) {
   if (!first_run || !run_sym || !run_start || !run_freqs || !dist_offset || !dist_len || !dist_cnt ||
-      !state || !out || !out_bytes || n_sections > 256) return -1;
+      !state || !out || !out_bytes || n_sections > 256 || !bwtc::wavelet::isWaveletModel(coder)) return -1;
   std::vector<std::vector<std::pair<uint32_t, uint32_t> > > dist(n_sections);
   std::vector<bwtc::wavelet::SectionRuns> secs(n_sections);
   for (uint32_t s = 0; s < n_sections; ++s) {
@@ -382,7 +388,7 @@ int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_ru
     secs[s].n_dist = dist[s].size();
   }
   std::vector<bwtc::wavelet::SectionOutput> outs;
-  bwtc::wavelet::encodeSections(secs, pick_threads(threads), state, &outs);
+  bwtc::wavelet::encodeSections(secs, pick_threads(threads), state, &outs, coder);
   uint64_t n = 0;
   for (uint32_t s = 0; s < n_sections; ++s) {
     if (n + outs[s].bytes.size() > out_cap) return -1;
@@ -397,10 +403,10 @@ int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run
                                   const uint8_t* run_sym, const uint32_t* run_start,
                                   const uint32_t* run_freqs, const uint32_t* dist_offset,
                                   const uint32_t* dist_len, const uint32_t* dist_cnt,
-                                  uint32_t threads, uint32_t* state, uint8_t* out,
+                                  uint32_t threads, char coder, uint32_t* state, uint8_t* out,
                                   uint64_t out_cap, uint64_t* out_bytes) {
   if (!first_run || !run_sym || !run_start || !run_freqs || !dist_offset || !dist_len || !dist_cnt ||
-      !state || !out || !out_bytes || n_sections > 256) return -1;
+      !state || !out || !out_bytes || n_sections > 256 || !bwtc::wavelet::isWaveletModel(coder)) return -1;
   std::vector<std::vector<std::pair<uint32_t, uint32_t> > > dist(n_sections);
   std::vector<bwtc::wavelet::SectionRuns> secs(n_sections);
   for (uint32_t s = 0; s < n_sections; ++s) {
@@ -419,7 +425,7 @@ int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run
   if (!bwtc::wavelet::expandStreamsOnHost(plan, secs, &coded_pos, &codes)) return -3;
   codes.push_back(0);
   std::vector<bwtc::wavelet::SectionOutput> outs;
-  bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes.data(), pick_threads(threads), state, &outs);
+  bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes.data(), pick_threads(threads), state, &outs, nullptr, coder);
   uint64_t n = 0;
   for (uint32_t s = 0; s < n_sections; ++s) {
     if (n + outs[s].bytes.size() > out_cap) return -1;

@@ -93,7 +93,8 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       if (!e.codes_free.empty()) { job.codes.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
       if (!job.codes.reserve(code_bytes)) return -2;
       std::memcpy(job.codes.data(), codes, (e.wt_coded + 3) / 4);
-      job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state));
+      job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state,
+                                                      e.wavelet_model));
       e.wavelet_state = job.coder->endState();
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(job.coder->elements() + 8)) return -2;
@@ -151,7 +152,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
         secs[s].symbols = run_sym.data() + st.first_run[s];
         secs[s].starts = run_start.data() + st.first_run[s];
       }
-      bwtc::wavelet::encodeSections(secs, threads, &e.wavelet_state, &job.outs);
+      bwtc::wavelet::encodeSections(secs, threads, &e.wavelet_state, &job.outs, e.wavelet_model);
     }
   }
   if (!queued) finish_wavelet_job(job);

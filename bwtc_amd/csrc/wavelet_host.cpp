@@ -463,8 +463,18 @@ const uint8_t kNext8[8][2] = {{0, 4}, {0, 4}, {1, 4}, {2, 4}, {3, 5}, {3, 6}, {3
 const uint8_t kNext4[4][2] = {{0, 2}, {0, 2}, {1, 3}, {1, 3}};
 const uint8_t kNext3[3][2] = {{0, 1}, {0, 2}, {1, 2}};
 
+// FSM<6, ...> of coder 'b' (generic nextState<6>, FSM.hpp:42-54)
+const uint8_t kNext6[6][2] = {{0, 3}, {0, 3}, {1, 3}, {2, 4}, {2, 5}, {2, 5}};
+
+// EvenIntervalPredictor<4> (BitPredictors.hpp:95-125): steps of 1024, never 0 or 4096
+inline uint32_t evenMoved(uint32_t q, uint32_t bit) {
+  const uint32_t up = q + 1024u < 4096u ? q + 1024u : q, down = q > 1024u ? q - 1024u : q;
+  return bit ? up : down;
+}
+
 struct Coder {
   enum { kMain = 0, kGaps = 8, kInts = 12 };
+  char model;                                                          // 'B', 'b' or 'u': the main model
   uint16_t p[16];
   uint8_t next8[8][2], next4[4][2], next3[3][2];
   uint32_t mcur, gcur, icur;
@@ -472,15 +482,18 @@ struct Coder {
   std::vector<uint8_t>* out;
   size_t used;                                                         // bytes of *out that are final
 
-  Coder(uint32_t startState, std::vector<uint8_t>* o) : mcur(startState), gcur(2), icur(1), low(0), high(0xFFFFFFFFu), out(o), used(o->size()), w(0) {
+  Coder(char model_, uint32_t startState, std::vector<uint8_t>* o)
+      : model(model_), mcur(startState), gcur(2), icur(1), low(0), high(0xFFFFFFFFu), out(o), used(o->size()), w(0) {
     for (uint32_t c = 0; c < 8; ++c) for (uint32_t b = 0; b < 2; ++b) next8[c][b] = static_cast<uint8_t>(nextState(8, c, b));
     for (uint32_t c = 0; c < 4; ++c) for (uint32_t b = 0; b < 2; ++b) next4[c][b] = static_cast<uint8_t>(nextState(4, c, b));
     for (uint32_t c = 0; c < 3; ++c) for (uint32_t b = 0; b < 2; ++b) next3[c][b] = static_cast<uint8_t>(nextState(3, c, b));
     resetMain(); resetGaps(); resetInts();
   }
-  void resetMain() {
+  void resetMain() {                                                   // resetModel of the main model
     static const uint16_t init[8] = {2400, 2300, 2200, 2100, 2100, 2200, 2300, 2400};
-    for (int i = 0; i < 8; ++i) p[kMain + i] = init[i];
+    if (model == 'B') { for (int i = 0; i < 8; ++i) p[kMain + i] = init[i]; return; }   // FSM8 keeps its state
+    for (int i = 0; i < 8; ++i) p[kMain + i] = 2048;
+    mcur = model == 'b' ? 3 : 0;
   }
   void resetGaps() { for (int i = 0; i < 4; ++i) p[kGaps + i] = 2048; gcur = 2; }
   void resetInts() { for (int i = 0; i < 3; ++i) p[kInts + i] = 2048; icur = 1; }
@@ -500,35 +513,34 @@ struct Coder {
     const uint32_t up = q + (((4096u - lo) - q) >> delay), down = q - ((q - lo) >> delay);
     return static_cast<uint16_t>(toward_one ? up : down);
   }
+  inline void mainState(uint32_t bit) {
+    if (model == 'B') mcur = next8[mcur][bit];
+    else if (model == 'b') mcur = kNext6[mcur][bit];
+  }
   inline void pmFast(uint32_t bit) {
-    const uint32_t inv = mcur >> 2, q = p[kMain + mcur];
-    encode(bit, inv ? 4096u - q : q);
-    p[kMain + mcur] = moved(q, bit ^ inv, 2, (mcur == 0 || mcur == 7) ? 4 : 5);
-    mcur = next8[mcur][bit];
+    const uint32_t q = p[kMain + mcur];
+    if (model == 'B') {
+      const uint32_t inv = mcur >> 2;
+      encode(bit, inv ? 4096u - q : q);
+      p[kMain + mcur] = moved(q, bit ^ inv, 2, (mcur == 0 || mcur == 7) ? 4 : 5);
+    } else {
+      encode(bit, q);
+      p[kMain + mcur] = static_cast<uint16_t>(evenMoved(q, bit));
+    }
+    mainState(bit);
   }
   inline void gapFast(uint32_t bit, bool state) {
     const uint32_t q = p[kGaps + gcur];
     encode(bit, q);
     p[kGaps + gcur] = moved(q, bit, 2, 5);
     gcur = next4[gcur][bit];
-    if (state) mcur = next8[mcur][bit];
+    if (state) mainState(bit);
   }
   inline void integerFast(uint32_t bit) {
     const uint32_t q = p[kInts + icur];
     encode(bit, q);
     p[kInts + icur] = moved(q, bit, 100, 5);
     icur = next3[icur][bit];
-  }
-  // either of pm / gap(state = true), chosen by `gap` without a branch
-  inline void pmOrGapFast(uint32_t bit, uint32_t gap) {
-    const uint32_t slot = gap ? kGaps + gcur : kMain + mcur;
-    const uint32_t inv = gap ? 0u : mcur >> 2;
-    const uint32_t delay = (!gap && (mcur == 0 || mcur == 7)) ? 4 : 5;
-    const uint32_t q = p[slot];
-    encode(bit, inv ? 4096u - q : q);
-    p[slot] = moved(q, bit ^ inv, 2, delay);
-    gcur = gap ? next4[gcur][bit] : gcur;
-    mcur = next8[mcur][bit];
   }
   // visitor interface of Tree::walk
   void pm(bool bit) { ensure(1); w = out->data() + used; pmFast(bit); used = static_cast<size_t>(w - out->data()); }
@@ -592,7 +604,7 @@ void parallelFor(size_t count, unsigned threads, const uint64_t* weight, F f) {
 }  // namespace
 
 void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, uint32_t* fsm8_state,
-                    std::vector<SectionOutput>* out) {
+                    std::vector<SectionOutput>* out, char model) {
   const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
   const auto t0 = std::chrono::steady_clock::now();
   const size_t n = sections.size();
@@ -619,7 +631,7 @@ void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads, 
   // pass 2 (parallel): range coding
   parallelFor(n, threads, weight.data(), [&](size_t s) {
     if (sections[s].n_runs == 0) return;
-    Coder coder(start[s], &(*out)[s].bytes);
+    Coder coder(model, model == 'B' ? start[s] : 0u, &(*out)[s].bytes);
     trees[s].walk(coder);
     coder.finish();                                                   // endContextBlock, WaveletCoders.cpp:62-68
     Tree().nodes.swap(trees[s].nodes);
@@ -708,14 +720,16 @@ struct LengthTrie {
 // the probability of a one is 4096 - p and the predictor moves the other way.  Kept as
 // p' = 4096 - p they follow the same rule as the others (4094 - p = p' - 2), so all fifteen
 // are handled alike: probability of a one = q[slot], moved towards the coded bit.
-template <int TYPE>
+// MODEL = the main model's letter: 'B' FSM8 of UnbiasedPredictors (slots 0..7), 'b' FSM<6> of
+// EvenIntervalPredictor<4> (slots 0..5), 'u' one EvenIntervalPredictor<4> (slot 0).
+template <int TYPE, char MODEL>
 struct GroupModel {
   uint32_t q[16];
   uint32_t mc, gc, ic;
   explicit GroupModel(uint32_t mainState) : mc(mainState), gc(2), ic(1) {
-    static const uint32_t init[16] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400,
-                                      2048, 2048, 2048, 2048, 2048, 2048, 2048, 0};
-    for (int k = 0; k < 16; ++k) q[k] = init[k];
+    static const uint32_t init[8] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400};
+    for (int k = 0; k < 8; ++k) q[k] = MODEL == 'B' ? init[k] : 2048u;
+    for (int k = 8; k < 16; ++k) q[k] = 2048;
   }
   inline uint16_t step(uint32_t v) {
     static const uint8_t kDelay[16] = {4, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 5, 5, 5, 5};
@@ -727,18 +741,23 @@ struct GroupModel {
     else slot = (v >> 1) ? 8 + gc : mc;
     const uint32_t pr = q[slot], delay = kDelay[slot];
     const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
-    q[slot] = bit ? up : down;
-    if (TYPE == kRoot) mc = kNext8[mc][bit];
+    uint32_t moved = bit ? up : down;
+    if (MODEL != 'B' && (TYPE == kRoot || TYPE == kInner)) moved = slot < 8 ? evenMoved(pr, bit) : moved;
+    q[slot] = moved;
+    if (TYPE == kRoot) mc = nextMain(bit);
     else if (TYPE == kBothLeaves) gc = kNext4[gc][bit];
     else if (TYPE == kInteger) ic = kNext3[ic][bit];
-    else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = kNext8[mc][bit]; }
+    else { gc = (v >> 1) ? kNext4[gc][bit] : gc; mc = nextMain(bit); }
     return static_cast<uint16_t>(pr);
+  }
+  inline uint32_t nextMain(uint32_t bit) const {
+    return MODEL == 'B' ? kNext8[mc][bit] : MODEL == 'b' ? kNext6[mc][bit] : 0u;
   }
 };
 
-template <int TYPE>
-void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
-  GroupModel<TYPE> m(mc);
+template <int TYPE, char MODEL>
+void modelGroupWith(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
+  GroupModel<TYPE, MODEL> m(mc);
   uint64_t i = b;
   for (; i < e && (i & 3); ++i) prob[i] = m.step(codeAt(codes, i));
   for (; i + 4 <= e; i += 4) {                                         // four elements per byte of codes
@@ -749,6 +768,13 @@ void modelGroup(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint1
     prob[i + 3] = m.step(four >> 6);
   }
   for (; i < e; ++i) prob[i] = m.step(codeAt(codes, i));
+}
+
+template <int TYPE>
+void modelGroup(char model, const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
+  if (model == 'b') modelGroupWith<TYPE, 'b'>(codes, b, e, mc, prob);
+  else if (model == 'u') modelGroupWith<TYPE, 'u'>(codes, b, e, mc, prob);
+  else modelGroupWith<TYPE, 'B'>(codes, b, e, mc, prob);
 }
 
 }  // namespace
@@ -876,8 +902,8 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   return true;
 }
 
-StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state)
-    : plan_(plan), pos_(coded_pos), codes_(codes), end_state_(fsm8_state) {
+StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state, char model)
+    : plan_(plan), pos_(coded_pos), codes_(codes), end_state_(fsm8_state), model_(model) {
   const size_t nsec = plan.sections.size();
   // The main model's state is the one value carried from section to section.  It is a
   // function of the last few bits that advanced it: two different bits in a row, or four
@@ -911,6 +937,9 @@ StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, cons
 
 // state of the main model before group `group` of section s (group = n_nodes: after the section)
 uint32_t StreamCoder::stateBefore(size_t s, uint32_t group) const {
+  // 'b' and 'u' reset their state machine with the model: every group starts from the same state
+  if (model_ == 'b') return 3;
+  if (model_ == 'u') return 0;
   const StreamPlan::Section& sec = plan_.sections[s];
   uint8_t tail[8];
   int have = 0;
@@ -928,11 +957,11 @@ uint64_t StreamCoder::elements() const { return pos_[plan_.group_type.size()]; }
 
 void StreamCoder::model(size_t k, uint16_t* prob) const {
   const Task& t = tasks_[k];
-  if (t.type == kInteger) { modelGroup<kInteger>(codes_, t.begin, t.end, 0, prob); return; }
-  if (t.type == kBothLeaves) { modelGroup<kBothLeaves>(codes_, t.begin, t.end, 0, prob); return; }
+  if (t.type == kInteger) { modelGroup<kInteger>(model_, codes_, t.begin, t.end, 0, prob); return; }
+  if (t.type == kBothLeaves) { modelGroup<kBothLeaves>(model_, codes_, t.begin, t.end, 0, prob); return; }
   const uint32_t mc = stateBefore(t.section, t.group);
-  if (t.type == kRoot) modelGroup<kRoot>(codes_, t.begin, t.end, mc, prob);
-  else modelGroup<kInner>(codes_, t.begin, t.end, mc, prob);
+  if (t.type == kRoot) modelGroup<kRoot>(model_, codes_, t.begin, t.end, mc, prob);
+  else modelGroup<kInner>(model_, codes_, t.begin, t.end, mc, prob);
 }
 
 void StreamCoder::codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const {
@@ -945,9 +974,9 @@ void StreamCoder::codeSection(size_t k, const uint16_t* prob, std::vector<Sectio
 }
 
 void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, unsigned threads,
-                 uint32_t* fsm8_state, std::vector<SectionOutput>* out, std::vector<uint16_t>* scratch) {
+                 uint32_t* fsm8_state, std::vector<SectionOutput>* out, std::vector<uint16_t>* scratch, char model) {
   out->assign(plan.sections.size(), SectionOutput());
-  StreamCoder coder(plan, coded_pos, codes, *fsm8_state);
+  StreamCoder coder(plan, coded_pos, codes, *fsm8_state, model);
   *fsm8_state = coder.endState();
   const uint64_t total = coder.elements();
   std::vector<uint16_t> local;

@@ -35,8 +35,12 @@ struct SectionOutput {
 
 // Encodes all sections of one block.  fsm8_state is the probability model's carried state
 // (4 for a fresh encoder) and is updated to the state after the last section.
+// `model` is the coder letter = the main probability model (giveProbabilityModel,
+// probmodels/ProbabilityModel.cpp:47-76): 'B' FSM8 (the default), 'b' FSM<6,
+// EvenIntervalPredictor<4>>, 'u' EvenIntervalPredictor<4>; only 'B' carries a state.
 void encodeSections(const std::vector<SectionRuns>& sections, unsigned threads,
-                    uint32_t* fsm8_state, std::vector<SectionOutput>* out);
+                    uint32_t* fsm8_state, std::vector<SectionOutput>* out, char model = 'B');
+inline bool isWaveletModel(char c) { return c == 'B' || c == 'b' || c == 'u'; }
 
 // ---- device-built streams -------------------------------------------------------------------
 // With the tree shapes known (they follow from the run statistics alone) every coded bit has a
@@ -88,7 +92,8 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan);
 // plan, coded_pos and codes must outlive the object.
 class StreamCoder {
  public:
-  StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state);
+  StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state,
+              char model = 'B');
   uint32_t endState() const { return end_state_; }        // the carried state after the block
   uint64_t elements() const;                              // size of the probability buffer
   size_t modelTasks() const { return tasks_.size(); }
@@ -103,6 +108,7 @@ class StreamCoder {
   const uint32_t* pos_;
   const uint8_t* codes_;
   uint32_t end_state_;
+  char model_;
   std::vector<uint32_t> start_;
   std::vector<Task> tasks_;
   std::vector<uint32_t> sections_;
@@ -111,7 +117,7 @@ class StreamCoder {
 // All of it on `threads` threads; `scratch` (optional) keeps the probability buffer between calls.
 void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes,
                  unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out,
-                 std::vector<uint16_t>* scratch = nullptr);
+                 std::vector<uint16_t>* scratch = nullptr, char model = 'B');
 
 // What wavelet_tree.hip computes, stated with plain host loops (expand, stable sort, gap flags,
 // select, pack).  Only the host-only test hook bwtc_hip_host_wavelet_streams calls it, so that

@@ -39,7 +39,7 @@ EXPORTS = [
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
-    "bwtc_hip_wavelet_reset", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -97,7 +97,8 @@ def load():
     L.bwtc_hip_wavelet_encode_end.argtypes = [_vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_reset.restype = None
     L.bwtc_hip_wavelet_reset.argtypes = [_vp]
-    L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64,
+    L.bwtc_hip_wavelet_start.argtypes = [_vp, ctypes.c_char]
+    L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_char, _vp, _vp, _u64,
                                                  ctypes.POINTER(_u64)]
     L.bwtc_hip_host_wavelet_streams.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
     L.bwtc_hip_host_huffman_lengths.restype = None
@@ -298,6 +299,10 @@ class Context:
                                                        ctypes.byref(n)),
                "bwtc_hip_wavelet_encode_device")
         return int(n.value)
+
+    def wavelet_start(self, coder="B"):
+        """New wavelet stream with the main model of coder letter `coder` ('B', 'b' or 'u')."""
+        _check(self.lib.bwtc_hip_wavelet_start(self.handle, coder.encode()), "bwtc_hip_wavelet_start")
 
     def wavelet_encode_device_begin(self, d_bwt_ptr, size, lf, freqs, out, threads=0):
         """First half: device work now, models + range coder queued on the worker threads.

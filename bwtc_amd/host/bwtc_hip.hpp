@@ -343,12 +343,12 @@ class HuffmanEncoder : public EntropyEncoder {
   std::vector<byte> m_record;
 };
 
-// WaveletCoders.hpp:48-77, the 'B' models.  The encoder object carries the main model's
+// WaveletCoders.hpp:48-77; the letter picks the main model (giveProbabilityModel).  The encoder object carries the main model's
 // state from block to block (m_probModel; FSM8::resetModel keeps its state): that state
 // lives in the context and a new encoder starts a new stream there.
 class WaveletEncoder : public EntropyEncoder {
  public:
-  explicit WaveletEncoder(char encoder = 'B') : m_fresh(true), m_ctx(0), m_dev(0), m_devBytes(0), m_next(0) { (void)encoder; }
+  explicit WaveletEncoder(char encoder = 'B') : m_letter(encoder), m_fresh(true), m_ctx(0), m_dev(0), m_devBytes(0), m_next(0) {}
   ~WaveletEncoder() {
     if (m_ctx && m_dev) bwtc_hip_free(m_ctx, m_dev);
     for (size_t i = 0; i < m_slots.size(); ++i) std::free(m_slots[i].rec);
@@ -420,8 +420,9 @@ class WaveletEncoder : public EntropyEncoder {
   struct Slot { byte* rec; uint64 cap; uint64_t ticket; Slot() : rec(0), cap(0), ticket(0) {} };
   void start(BWTManager& bwtm) {
     m_ctx = bwtm.hipContext();
-    if (m_fresh) { bwtc_hip_wavelet_reset(m_ctx); m_fresh = false; }
+    if (m_fresh) { hipFatal(bwtc_hip_wavelet_start(m_ctx, m_letter), "bwtc_hip_wavelet_start"); m_fresh = false; }
   }
+  char m_letter;                     // 'B', 'b' or 'u': the main probability model, also the stream's header byte
   bool m_fresh;
   bwtc_hip_ctx* m_ctx;
   void* m_dev;
@@ -434,8 +435,9 @@ class WaveletEncoder : public EntropyEncoder {
 
 inline EntropyEncoder* giveEntropyEncoder(char encoder) {        // EntropyCoders.cpp:38-51
   if (encoder == 'H') return new HuffmanEncoder();
-  if (encoder == 'B') return new WaveletEncoder(encoder);
-  std::fprintf(stderr, "bwtc-hip: entropy coder '%c' is not built (this build offers H and B)\n", encoder);
+  if (encoder == 'B' || encoder == 'b' || encoder == 'u') return new WaveletEncoder(encoder);
+  std::fprintf(stderr, "bwtc-hip: entropy coder '%c' is not offered (H, B, b, u are; the reference's m / M index past "
+               "their history table)\n", encoder);
   std::exit(1);
 }
 

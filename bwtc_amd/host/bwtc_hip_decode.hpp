@@ -4,8 +4,8 @@
 // nothing in a block can be decoded ahead); the inverse transform runs on the GPU
 // (HipInverseBWTransform).  WaveletDecoder ('B'; WaveletCoders.cpp:232-291, WaveletTree.hpp
 // readShape :403-500, decodeTreeBF :857-1174, message :1277-1378, BitDecoder BitCoders.cpp:115-148)
-// is serial host code for the same reason plus the adaptive models.  Coders 'H' and 'B' and
-// streams without precompression are accepted.
+// is serial host code for the same reason plus the adaptive models.  Coders 'H', 'B', 'b', 'u'
+// and streams without precompression are accepted.
 #pragma once
 #include <cstring>
 #include <deque>
@@ -157,12 +157,16 @@ namespace detail {
 // moves 1/2^delay of the way towards its bound (BitPredictors.hpp:37-65); the upper four of
 // the main model predict the inverted bit and are kept as 4096 - p.
 struct WaveletModels {
+  char model;                              // coder letter: 'B' FSM8, 'b' FSM<6, EvenIntervalPredictor<4>>, 'u' EvenIntervalPredictor<4>
   uint32 q[15];
   uint32 mc, gc, ic;
-  WaveletModels() : mc(4), gc(2), ic(1) { resetMain(); resetGaps(); resetInts(); }
-  void resetMain() {                                   // FSM8::resetModel keeps the state, FSM.hpp:196-205
+  explicit WaveletModels(char model_ = 'B') : model(model_), mc(model_ == 'B' ? 4 : model_ == 'b' ? 3 : 0), gc(2), ic(1) {
+    resetMain(); resetGaps(); resetInts();
+  }
+  void resetMain() {                                   // FSM8::resetModel keeps the state (FSM.hpp:196-205), FSM<N> does not (:94-97)
     static const uint32 init[8] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400};
-    for (int i = 0; i < 8; ++i) q[i] = init[i];
+    for (int i = 0; i < 8; ++i) q[i] = model == 'B' ? init[i] : 2048;
+    if (model == 'b') mc = 3;
   }
   void resetGaps() { for (int i = 8; i < 12; ++i) q[i] = 2048; gc = 2; }
   void resetInts() { for (int i = 12; i < 15; ++i) q[i] = 2048; ic = 1; }
@@ -179,9 +183,16 @@ struct WaveletModels {
   void move(uint32 slot, bool bit, uint32 floor, uint32 delay) {
     q[slot] = bit ? q[slot] + (((4096 - floor) - q[slot]) >> delay) : q[slot] - ((q[slot] - floor) >> delay);
   }
+  void moveEven(uint32 slot, bool bit) {                              // EvenIntervalPredictor<4>, BitPredictors.hpp:95-125
+    if (bit) { if (q[slot] + 1024 < 4096) q[slot] += 1024; }
+    else if (q[slot] > 1024) q[slot] -= 1024;
+  }
   uint32 mainP() const { return q[mc]; }
-  void mainUpdate(bool bit) { move(mc, bit, 2, (mc == 0 || mc == 7) ? 4 : 5); mc = next(8, mc, bit); }
-  void mainState(bool bit) { mc = next(8, mc, bit); }
+  void mainUpdate(bool bit) {
+    if (model == 'B') move(mc, bit, 2, (mc == 0 || mc == 7) ? 4 : 5); else moveEven(mc, bit);
+    mainState(bit);
+  }
+  void mainState(bool bit) { if (model == 'B') mc = next(8, mc, bit); else if (model == 'b') mc = next(6, mc, bit); }
   uint32 gapP() const { return q[8 + gc]; }
   void gapUpdate(bool bit) { move(8 + gc, bit, 2, 5); gc = next(4, gc, bit); }
   uint32 intP() const { return q[12 + ic]; }
@@ -264,7 +275,7 @@ inline uint64 readPackedIntegerRev(MemoryBitReader& in) {           // utils::re
 
 class WaveletDecoder : public EntropyDecoder {
  public:
-  explicit WaveletDecoder(char decoder = 'B') { (void)decoder; }
+  explicit WaveletDecoder(char decoder = 'B') : m_models(decoder) {}
   void decodeBlock(BWTBlock& block, MemoryBitReader& in, size_t capacity) {
     const uint64 compressed = in.readBits(48);                       // readBlockHeader, WaveletCoders.cpp:232-244
     const size_t start = in.position();
@@ -527,8 +538,9 @@ class WaveletDecoder : public EntropyDecoder {
 
 inline EntropyDecoder* giveEntropyDecoder(char decoder) {            // EntropyCoders.cpp:53-65
   if (decoder == 'H') return new HuffmanDecoder();
-  if (decoder == 'B') return new WaveletDecoder(decoder);
-  std::fprintf(stderr, "bwtc-hip: entropy decoder '%c' is not built (this build offers H and B)\n", decoder);
+  if (decoder == 'B' || decoder == 'b' || decoder == 'u') return new WaveletDecoder(decoder);
+  std::fprintf(stderr, "bwtc-hip: entropy decoder '%c' is not offered (H, B, b, u are; the reference's m / M index past "
+               "their history table)\n", decoder);
   std::exit(1);
 }
 

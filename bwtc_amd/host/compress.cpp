@@ -5,13 +5,14 @@
 //     -m, --mem MB       memory budget; BWT block = 0.185 * MB * 1e6 bytes   (default 100)
 //     -s, --starts N     starting points for the inverse transform, 1..256    (default 8)
 //         --bwt C        BWT algorithm: g (GPU) or a (auto = g)              (default a)
-//     -e, --enc C        entropy coder: B (wavelet, the reference's default) or H (Huffman)  (default B)
+//     -e, --enc C        entropy coder: B (wavelet, the reference's default), b, u (wavelet with
+//                        other main models) or H (Huffman)                    (default B)
 //     -i, --stdin        read from standard input
 //     -c, --stdout       write to standard output
 //     -d, --device N     GPU to use                                          (default 0)
 //     -v, --verb N       verbosity
-// Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc b/m/M/u
-// (the other wavelet model tables) are rejected, --prepr is not offered.
+// Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc m/M (models
+// whose reference implementation reads past its table) are rejected, --prepr is not offered.
 #include <getopt.h>
 #include <chrono>
 #include <cstring>
@@ -42,7 +43,7 @@ int main(int argc, char** argv) {
       case 'd': device = std::atoi(optarg); break;
       case 'v': verbosity = std::atoi(optarg); break;
       default:
-        std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|H] [-i] [-c] [input] [output]\n");
+        std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|b|u|H] [-i] [-c] [input] [output]\n");
         return o == 'h' ? 0 : 1;
     }
   }

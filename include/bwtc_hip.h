@@ -187,6 +187,13 @@ int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt
                                          uint64_t* ticket);
 int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
+/* A new wavelet stream with the main probability model of coder letter `coder`
+ * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,
+ * probmodels/ProbabilityModel.cpp:47-76): 'B' FSM8 (what bwtc_hip_wavelet_reset selects),
+ * 'b' FSM<6, EvenIntervalPredictor<4>>, 'u' EvenIntervalPredictor<4>.  -1 for other letters:
+ * 'm' / 'M' (SimpleMarkov) index one entry past their history table in the reference
+ * (:91-93 vs :110-118), their output is undefined and they are not offered. */
+int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder);
 
 /* Host half of the 'B' coder alone (no device work): the sections' runs as the GPU scanner
  * delivers them -> the concatenated section payloads (packed bitsInRoot, tree shape, range-coded
@@ -198,7 +205,7 @@ int bwtc_hip_host_wavelet_sections(uint32_t n_sections, const uint32_t* first_ru
                                    const uint8_t* run_sym, const uint32_t* run_start,
                                    const uint32_t* run_freqs, const uint32_t* dist_offset,
                                    const uint32_t* dist_len, const uint32_t* dist_cnt,
-                                   uint32_t threads, uint32_t* state, uint8_t* out,
+                                   uint32_t threads, char coder, uint32_t* state, uint8_t* out,
                                    uint64_t out_cap, uint64_t* out_bytes);
 
 /* Same arguments and same bytes as bwtc_hip_host_wavelet_sections, computed the way the device
@@ -211,7 +218,7 @@ int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run
                                   const uint8_t* run_sym, const uint32_t* run_start,
                                   const uint32_t* run_freqs, const uint32_t* dist_offset,
                                   const uint32_t* dist_len, const uint32_t* dist_cnt,
-                                  uint32_t threads, uint32_t* state, uint8_t* out,
+                                  uint32_t threads, char coder, uint32_t* state, uint8_t* out,
                                   uint64_t out_cap, uint64_t* out_bytes);
 
 /* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the

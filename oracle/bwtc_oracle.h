@@ -64,6 +64,15 @@ size_t orc_wavelet_encode_block(const uint8_t *bwt, uint32_t size, const uint32_
                                 const uint32_t freqs[256], uint8_t *out, size_t out_cap);
 size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_t starting_points,
                       uint8_t *out, size_t out_cap);
+/* the same with the main model chosen by the coder letter (giveProbabilityModel,
+ * probmodels/ProbabilityModel.cpp:47-76): 'B' (and any other letter) FSM8, 'b' FSM<6,
+ * EvenIntervalPredictor<4>>, 'u' EvenIntervalPredictor<4>.  'm' / 'M' return 0: the
+ * reference's SimpleMarkov indexes one past its history table, its output is undefined.
+ * No reference-produced vector exists for 'b' and 'u' (parity unpinned for those letters). */
+size_t orc_wavelet_encode_block_with(char coder, const uint8_t *bwt, uint32_t size, const uint32_t *lf,
+                                     uint32_t n_lf, const uint32_t freqs[256], uint8_t *out, size_t out_cap);
+size_t orc_compress_wavelet(char coder, const uint8_t *in, size_t size, size_t block_size,
+                            uint32_t starting_points, uint8_t *out, size_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,9 @@
  * restated.  Where the reference runs into undefined behaviour (bitsForIntegers walking a
  * reverse iterator past rend(), WaveletTree.hpp:1606-1613) the candidate is dropped here.
  * Pin: the 36-byte 'B' stream recorded from the reference (tests/golden/streams.json).
+ * The letters 'b' and 'u' (other main models, same everything else) have NO reference-produced
+ * vector here: parity unpinned for them.  'm' / 'M' are not restated (undefined behaviour in
+ * the reference, see model_init).
  */
 #include "bwtc_oracle.h"
 #include <math.h>
@@ -434,10 +437,19 @@ static uint32_t next_state(uint32_t states, uint32_t cur, int bit)
     if (bit) return cur >= states / 2 ? (cur + 1 < states - 1 ? cur + 1 : states - 1) : states / 2;
     return cur < states / 2 ? (cur > 0 ? cur - 1 : 0) : (states - 1) / 2;
 }
-/* model = FSM<N, UnbiasedPredictor> (FSM.hpp:81-110) or FSM8 (:168-227).  For FSM8 states 4..7
- * are InversePredictors (BitPredictors.hpp:300-319) of z1..z4 and resetModel() keeps the
- * current state. */
-typedef struct { int is_fsm8; uint32_t n, cur; upred st[8]; } model;
+/* EvenIntervalPredictor<M>, probmodels/BitPredictors.hpp:95-125: the probability steps by
+ * 4096/M and stays strictly inside (0, 4096) */
+static void ei_update(upred *u, int bit, uint16_t interval)
+{
+    if (bit) { if ((uint32_t)u->p + interval < 4096u) u->p = (uint16_t)(u->p + interval); }
+    else if (interval < u->p) u->p = (uint16_t)(u->p - interval);
+}
+/* model = FSM<N, Predictor> (FSM.hpp:81-110), FSM8 (:168-227) or a lone predictor.  For FSM8
+ * states 4..7 are InversePredictors (BitPredictors.hpp:300-319) of z1..z4 and resetModel()
+ * keeps the current state; a lone predictor has no state machine (ProbabilityModel::updateState
+ * is a no-op, probmodels/ProbabilityModel.hpp:48-50).  even = EvenIntervalPredictor<4> states
+ * instead of UnbiasedPredictors. */
+typedef struct { int is_fsm8, even; uint32_t n, cur; upred st[8]; } model;
 static void model_reset(model *m)
 {
     uint32_t i;
@@ -449,27 +461,40 @@ static uint16_t model_p1(const model *m)
     if (m->is_fsm8 && m->cur >= 4) return (uint16_t)(4096 - m->st[m->cur].p);
     return m->st[m->cur].p;
 }
-static void model_update_state(model *m, int bit) { m->cur = next_state(m->n, m->cur, bit); }
+static void model_update_state(model *m, int bit) { if (m->n > 1) m->cur = next_state(m->n, m->cur, bit); }
 static void model_update(model *m, int bit)
 {
-    if (m->is_fsm8 && m->cur >= 4) up_update(&m->st[m->cur], !bit);
+    if (m->even) ei_update(&m->st[m->cur], bit, 1024);
+    else if (m->is_fsm8 && m->cur >= 4) up_update(&m->st[m->cur], !bit);
     else up_update(&m->st[m->cur], bit);
     model_update_state(m, bit);
 }
-static void model_init_B(model *pm, model *gm, model *gapm)
+/* giveProbabilityModel(choice), probmodels/ProbabilityModel.cpp:47-76.  'm' and 'M'
+ * (SimpleMarkov) are not restated: their history table is one entry short of the contexts it
+ * is indexed with (:91-93 vs :110-118), so their output is undefined.  Returns 0 for them. */
+static int model_init(char choice, model *pm, model *gm, model *gapm)
 {
-    /* giveProbabilityModel('B'), probmodels/ProbabilityModel.cpp:63-75: FSM8<Z4,Z3,Z2,Z1> with
-     * states z4 z3 z2 z1 o1 o2 o3 o4 */
     uint32_t i;
-    pm->is_fsm8 = 1; pm->n = 8; pm->cur = 4;
-    up_init(&pm->st[0], 2, 4, 2400); up_init(&pm->st[1], 2, 5, 2300);
-    up_init(&pm->st[2], 2, 5, 2200); up_init(&pm->st[3], 2, 5, 2100);
-    up_init(&pm->st[4], 2, 5, 2100); up_init(&pm->st[5], 2, 5, 2200);
-    up_init(&pm->st[6], 2, 5, 2300); up_init(&pm->st[7], 2, 4, 2400);
-    gm->is_fsm8 = 0; gm->n = 3; gm->cur = 1;                       /* giveModelForIntegerCodes :38-41 */
+    memset(pm, 0, sizeof *pm); memset(gm, 0, sizeof *gm); memset(gapm, 0, sizeof *gapm);
+    if (choice == 'm' || choice == 'M') return 0;
+    if (choice == 'u') {                                           /* EvenIntervalPredictor<4> */
+        pm->even = 1; pm->n = 1; pm->cur = 0;
+        up_init(&pm->st[0], 0, 0, 2048);
+    } else if (choice == 'b') {                                    /* FSM<6, EvenIntervalPredictor<4> > */
+        pm->even = 1; pm->n = 6; pm->cur = 3;
+        for (i = 0; i < 6; ++i) up_init(&pm->st[i], 0, 0, 2048);
+    } else {                                                       /* 'B' and default: FSM8<Z4,Z3,Z2,Z1>, states z4 z3 z2 z1 o1 o2 o3 o4 */
+        pm->is_fsm8 = 1; pm->n = 8; pm->cur = 4;
+        up_init(&pm->st[0], 2, 4, 2400); up_init(&pm->st[1], 2, 5, 2300);
+        up_init(&pm->st[2], 2, 5, 2200); up_init(&pm->st[3], 2, 5, 2100);
+        up_init(&pm->st[4], 2, 5, 2100); up_init(&pm->st[5], 2, 5, 2200);
+        up_init(&pm->st[6], 2, 5, 2300); up_init(&pm->st[7], 2, 4, 2400);
+    }
+    gm->n = 3; gm->cur = 1;                                        /* giveModelForIntegerCodes :38-41 */
     for (i = 0; i < 3; ++i) up_init(&gm->st[i], 100, 5, 2048);
-    gapm->is_fsm8 = 0; gapm->n = 4; gapm->cur = 2;                 /* giveModelForGaps :43-45 */
+    gapm->n = 4; gapm->cur = 2;                                    /* giveModelForGaps :43-45 */
     for (i = 0; i < 4; ++i) up_init(&gapm->st[i], 2, 5, 2048);
+    return 1;
 }
 
 /* BitEncoder, BitCoders.cpp:59-113 */
@@ -653,26 +678,33 @@ static size_t wavelet_encode_block(wstate *ws, const uint8_t *bwt, uint32_t size
     return pos;
 }
 
-size_t orc_wavelet_encode_block(const uint8_t *bwt, uint32_t size, const uint32_t *lf, uint32_t n_lf,
-                                const uint32_t freqs[256], uint8_t *out, size_t out_cap)
+size_t orc_wavelet_encode_block_with(char coder, const uint8_t *bwt, uint32_t size, const uint32_t *lf,
+                                     uint32_t n_lf, const uint32_t freqs[256], uint8_t *out, size_t out_cap)
 {
     wstate ws;
     (void)out_cap;
-    model_init_B(&ws.pm, &ws.gm, &ws.gapm);
+    if (!model_init(coder, &ws.pm, &ws.gm, &ws.gapm)) return 0;
     ws.rc.low = 0; ws.rc.high = 0xFFFFFFFFu;
     return wavelet_encode_block(&ws, bwt, size, lf, n_lf, freqs, out);
 }
 
-/* Compressor::compress with coder 'B' and no precompression (Compressor.cpp:65-118) */
-size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_t starting_points,
-                      uint8_t *out, size_t out_cap)
+size_t orc_wavelet_encode_block(const uint8_t *bwt, uint32_t size, const uint32_t *lf, uint32_t n_lf,
+                                const uint32_t freqs[256], uint8_t *out, size_t out_cap)
+{
+    return orc_wavelet_encode_block_with('B', bwt, size, lf, n_lf, freqs, out, out_cap);
+}
+
+/* Compressor::compress with a wavelet coder and no precompression (Compressor.cpp:65-118);
+ * the coder letter is the global header byte and selects the main model */
+size_t orc_compress_wavelet(char coder, const uint8_t *in, size_t size, size_t block_size,
+                            uint32_t starting_points, uint8_t *out, size_t out_cap)
 {
     size_t pos = 0, off = 0;
     wstate ws;
-    model_init_B(&ws.pm, &ws.gm, &ws.gapm);
+    if (!model_init(coder, &ws.pm, &ws.gm, &ws.gapm)) return 0;
     ws.rc.low = 0; ws.rc.high = 0xFFFFFFFFu;
     (void)out_cap;
-    out[pos++] = 'B';
+    out[pos++] = (uint8_t)coder;
     while (off < size) {
         size_t bs = size - off < block_size ? size - off : block_size;
         uint8_t *blk = (uint8_t *)malloc(bs + 1);
@@ -690,4 +722,10 @@ size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_
     }
     out[pos++] = 0;
     return pos;
+}
+
+size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_t starting_points,
+                      uint8_t *out, size_t out_cap)
+{
+    return orc_compress_wavelet('B', in, size, block_size, starting_points, out, out_cap);
 }

@@ -193,6 +193,21 @@ static void testWaveletDecompressor(std::mt19937& rng) {
       CHECK(n == data.size() && plain->data == data, "'B' oracle stream -> Decompressor (input %zu, block %zu)", k, bs);
     }
   }
+  for (const char* letter = "bu"; *letter; ++letter) {                // the other model letters, several blocks
+    std::vector<byte> data = repetitiveData(rng, 1200000);
+    MemoryOutStream* packed = new MemoryOutStream();
+    Compressor compressor(new MemoryInStream(&data[0], data.size()), packed, 2000000, *letter);
+    compressor.initializeBwtAlgorithm('g', 8);
+    compressor.compress(1);
+    std::vector<byte> stream = packed->data;
+    std::vector<byte> want(orc_compress_bound(data.size()) + 100000);
+    const size_t wn = orc_compress_wavelet(*letter, &data[0], data.size(), compressor.bwtBlockSize(), 8, &want[0], want.size());
+    CHECK(wn == stream.size() && std::memcmp(&want[0], &stream[0], wn) == 0, "'%c' stream differs from the oracle's", *letter);
+    MemoryOutStream* plain = new MemoryOutStream();
+    Decompressor d(new MemoryInStream(&stream[0], stream.size()), plain);
+    const size_t n = d.decompress(1);
+    CHECK(n == data.size() && plain->data == data, "'%c' Compressor -> Decompressor round trip", *letter);
+  }
   {                                                                   // own compressor -> own decompressor
     std::vector<byte> data = repetitiveData(rng, 3000000);
     MemoryOutStream* packed = new MemoryOutStream();

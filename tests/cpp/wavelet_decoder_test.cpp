@@ -88,6 +88,36 @@ int main() {
     }
     CHECK(off == data.size(), "multi-block stream length");
   }
+  // the other model letters: 'b' and 'u' streams of the oracle through decoders of that letter
+  for (const char* letter = "bu"; *letter; ++letter) {
+    for (size_t k = 0; k < inputs.size(); k += 2) {
+      const std::vector<byte>& data = inputs[k];
+      const size_t bs = std::max<size_t>(data.size() / 2 + 1, 1);   // two blocks
+      std::vector<byte> whole(orc_compress_bound(data.size()) + 100000);
+      const size_t sn = orc_compress_wavelet(*letter, &data[0], data.size(), bs, 8, &whole[0], whole.size());
+      MemoryBitReader in(&whole[0], sn);
+      CHECK(in.readByte() == (byte)*letter, "global header letter");
+      WaveletDecoder dec(*letter);
+      size_t off = 0;
+      for (;;) {
+        const uint64 n = in.readPackedInteger();
+        if (n == 0) break;
+        CHECK(in.readPackedInteger() == 1 && in.readByte() == 0, "block prefix");
+        std::vector<byte> t(data.begin() + off, data.begin() + off + n);
+        t.push_back(0);
+        std::vector<uint32> lf(256);
+        uint32 n_lf = 0, freqs[256];
+        std::memset(freqs, 0, sizeof freqs);
+        orc_bwt_block(&t[0], (uint32)n, 8, &lf[0], &n_lf, freqs);
+        std::vector<byte> out(n + 16);
+        BWTBlock block(&out[0], 0, true);
+        dec.decodeBlock(block, in, n);
+        CHECK(block.size() == n && std::memcmp(&out[0], &t[0], n) == 0, "coder '%c', input %zu, block at %zu", *letter, k, off);
+        off += n;
+      }
+      CHECK(off == data.size(), "coder '%c' stream length (input %zu)", *letter, k);
+    }
+  }
   std::printf(failures ? "%d FAILURES\n" : "wavelet decoder: all tests passed\n", failures);
   return failures ? 1 : 0;
 }

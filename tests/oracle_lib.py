@@ -68,6 +68,10 @@ def lib():
         L.orc_decompress_H.restype = _sz
         L.orc_decompress_H.argtypes = [_vp, _sz, _vp, _sz]
         L.orc_compress_B.restype = _sz
+        L.orc_compress_wavelet.restype = _sz
+        L.orc_compress_wavelet.argtypes = [ctypes.c_char, _vp, _sz, _sz, _u32, _vp, _sz]
+        L.orc_wavelet_encode_block_with.restype = _sz
+        L.orc_wavelet_encode_block_with.argtypes = [ctypes.c_char, _vp, _u32, _vp, _u32, _vp, _vp, _sz]
         L.orc_compress_B.argtypes = [_vp, _sz, _sz, _u32, _vp, _sz]
         L.orc_wavelet_encode_block.restype = _sz
         L.orc_wavelet_encode_block.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _sz]
@@ -186,6 +190,28 @@ def oracle_compress_B(data, block_size, sp=8):
     cap = lib().orc_compress_bound(data.size) + nblocks * 8192
     out = np.zeros(cap, np.uint8)
     n = lib().orc_compress_B(_ptr(data), data.size, block_size, sp, _ptr(out), cap)
+    return out[:n].copy()
+
+
+def oracle_compress_wavelet(coder, data, block_size, sp=8):
+    """Whole stream with wavelet coder letter `coder` ('B', 'b', 'u'); None for 'm' / 'M'."""
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    data = np.ascontiguousarray(data)
+    nblocks = (data.size + block_size - 1) // max(block_size, 1) + 1
+    cap = lib().orc_compress_bound(data.size) + nblocks * 8192
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_compress_wavelet(coder.encode(), _ptr(data), data.size, block_size, sp, _ptr(out), cap)
+    return out[:n].copy() if n else None
+
+
+def oracle_wavelet_encode_block_with(coder, bwt, lf, freqs):
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    lf = np.ascontiguousarray(lf, dtype=np.uint32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    cap = lib().orc_compress_bound(bwt.size)
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_wavelet_encode_block_with(coder.encode(), _ptr(bwt), bwt.size, _ptr(lf), lf.size, _ptr(freqs),
+                                            _ptr(out), cap)
     return out[:n].copy()
 
 

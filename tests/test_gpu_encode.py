@@ -252,3 +252,27 @@ def test_wavelet_B_pipeline_limits_and_misuse(oracle):
         ctx.dfree(d_in)
     finally:
         ctx.close()
+
+
+def test_wavelet_other_model_letters_on_the_device_route(hip_ctx, oracle):
+    """Coder letters 'b' and 'u' through the C ABI (bwtc_hip_wavelet_start picks the main model;
+    the stream kernels are the same, only the host models differ) against the oracle, two blocks
+    per stream; 'm' / 'M' are refused."""
+    from bwtc_amd import hip
+    d = synth.gen_text(900000, 17)
+    bs = 500000
+    try:
+        for coder in ("b", "u"):
+            hip_ctx.wavelet_start(coder)
+            out = coder.encode()
+            for off in range(0, d.size, bs):
+                blk = d[off:off + bs]
+                rec, _ = hip_ctx.transform_and_encode_wavelet(blk, 8)
+                out += _packed(blk.size) + _packed(1) + b"\x00" + rec.tobytes()
+            out += b"\x00"
+            assert out == oracle.oracle_compress_wavelet(coder, d, bs, 8).tobytes(), coder
+        for coder in ("m", "M", "H", "x"):
+            with pytest.raises(hip.BwtcHipError):
+                hip_ctx.wavelet_start(coder)
+    finally:
+        hip_ctx.wavelet_reset()

@@ -57,6 +57,17 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     r = subprocess.run([unexe, "-v", "1", str(dstb), str(outb)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert outb.read_bytes() == data.tobytes()
+    # another model letter through both tools
+    dstu = tmp_path / "input.u.bwtc"
+    outu = tmp_path / "roundtrip.u.bin"
+    r = subprocess.run([exe, "-m", "10", "-e", "u", str(src), str(dstu)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert dstu.read_bytes() == oracle.oracle_compress_wavelet("u", data, int(10 * 1000000 * 0.185), 8).tobytes()
+    r = subprocess.run([unexe, str(dstu), str(outu)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert outu.read_bytes() == data.tobytes()
+    r = subprocess.run([exe, "-e", "m", str(src), str(dstu)], capture_output=True, text=True)
+    assert r.returncode != 0
     # rejected choices, as the reference's validators do (compress.cpp:86-96)
     r = subprocess.run([exe, "--bwt", "d", str(src), str(dst)], capture_output=True, text=True)
     assert r.returncode != 0

@@ -106,7 +106,7 @@ def _runs_of(section):
     return s[heads], np.concatenate([heads, [s.size]]).astype(np.uint32)
 
 
-def _host_wavelet_payload(H, bwt, sections, state=4, threads=2, entry="bwtc_hip_host_wavelet_sections"):
+def _host_wavelet_payload(H, bwt, sections, state=4, threads=2, entry="bwtc_hip_host_wavelet_sections", coder=b"B"):
     import ctypes
     first = [0]
     syms, starts, rfs, doff, dl, dc = [], [], [], [0], [], []
@@ -129,7 +129,7 @@ def _host_wavelet_payload(H, bwt, sections, state=4, threads=2, entry="bwtc_hip_
     n = ctypes.c_uint64(0)
     st = ctypes.c_uint32(state)
     rc = getattr(H, entry)(len(sections), _p(first), _p(run_sym), _p(run_start), _p(rf), _p(doff),
-                           _p(dl), _p(dc), threads, ctypes.byref(st), _p(out), out.size, ctypes.byref(n))
+                           _p(dl), _p(dc), threads, coder, ctypes.byref(st), _p(out), out.size, ctypes.byref(n))
     assert rc == 0
     return out[:n.value].tobytes(), st.value
 
@@ -164,6 +164,36 @@ def test_wavelet_host_half_matches_oracle(oracle):
             got2, end_state2 = _host_wavelet_payload(H, bwt, sections, 4, threads, "bwtc_hip_host_wavelet_streams")
             assert got2 == want[skip:], ("streams", d.size, threads)
             assert end_state2 == end_state
+
+
+def test_wavelet_other_model_letters(oracle):
+    """Coder letters 'b' (FSM<6, EvenIntervalPredictor<4>>) and 'u' (EvenIntervalPredictor<4>):
+    both host routes of the product against the oracle's restatement.  No reference-produced
+    vector exists for these letters (parity unpinned); 'B' stays pinned by the golden stream.
+    'm' / 'M' are refused everywhere (the reference indexes past its history table)."""
+    from bwtc_amd import synth
+    H = _host()
+    rng = np.random.default_rng(5)
+    cases = [np.frombuffer(b"abracadabra", np.uint8), synth.gen_text(150000, 4), synth.gen_dna(80000, 6),
+             synth.gen_random_bytes(100000, 2),
+             np.repeat(rng.integers(0, 5, 1500).astype(np.uint8), rng.integers(1, 300, 1500))]
+    for coder in ("b", "u", "B"):
+        for d in cases:
+            bwt, lf, freqs = oracle.oracle_bwt_block(d, 4)
+            sections = oracle.oracle_sections(freqs)
+            want = oracle.oracle_wavelet_encode_block_with(coder, bwt, lf, freqs).tobytes()
+            lfa = np.ascontiguousarray(lf, np.uint32)
+            hdr = np.zeros(2048, np.uint8)
+            k = oracle.lib().orc_write_bwtblock_header(_p(lfa), lfa.size, _p(hdr))
+            skip = 6 + k + 1 + sum(len(_packed(int(x))) for x in sections)
+            for entry in ("bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams"):
+                got, _ = _host_wavelet_payload(H, bwt, sections, 4, 2, entry, coder.encode())
+                assert got == want[skip:], (coder, d.size, entry)
+    assert oracle.oracle_compress_wavelet("m", cases[0], 100, 1) is None
+    assert oracle.oracle_compress_wavelet("M", cases[0], 100, 1) is None
+    # different letters give different streams (the models really differ)
+    s = {c: oracle.oracle_compress_wavelet(c, cases[1], cases[1].size, 8).tobytes()[1:] for c in "Bbu"}
+    assert len(set(s.values())) == 3
 
 
 def _packed(v):
