@@ -67,6 +67,8 @@ struct BwtEngine {
   u64 h_wt_bytes = 0;
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
   WorkerPool* pool = nullptr;
+  StageClock stage_clock;
+  BlockGroupSource* model_groups = nullptr;   // groups of all blocks under way, for the 16-lane model engines
   std::map<u64, std::shared_ptr<WaveletJob> > jobs;
   u64 next_ticket = 1;
   unsigned max_inflight = 12;          // BWTC_HIP_WAVELET_DEPTH

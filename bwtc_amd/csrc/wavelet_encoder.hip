@@ -32,8 +32,28 @@ static void finish_wavelet_job(WaveletJob& job) {
   const u64 len = rec.size() - 6;
   for (int i = 0; i < 6; ++i) rec[i] = (uint8_t)(len >> (8 * (5 - i)));
   if (job.user_out && rec.size() <= job.user_cap) std::memcpy(job.user_out, rec.data(), rec.size());
+  job.t_finished = std::chrono::steady_clock::now();
   { std::lock_guard<std::mutex> g(job.mu); job.done = true; }
   job.cv.notify_all();
+}
+
+// Every group of the block is modelled: its sections' range coders go to the front of the
+// queue, ahead of newer blocks' work.
+static void submit_sections(const std::shared_ptr<WaveletJob>& jobp, WorkerPool* pool, StageClock* clock) {
+  jobp->t_modelled = std::chrono::steady_clock::now();
+  std::vector<std::function<void()> > next;
+  for (size_t q = 0; q < jobp->coder->sectionTasks(); ++q) {
+    next.push_back([jobp, q, clock] {
+      WaveletJob& j = *jobp;
+      const auto t0 = std::chrono::steady_clock::now();
+      j.coder->codeSection(q, j.prob.data(), &j.outs);
+      clock->coder_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      bool fin;
+      { std::lock_guard<std::mutex> g(j.mu); fin = --j.sections_left == 0; }
+      if (fin) finish_wavelet_job(j);
+    });
+  }
+  pool->submit(jobp->rank, next);
 }
 
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
@@ -48,6 +68,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
   }
   std::shared_ptr<WaveletJob> jobp(new WaveletJob());
   WaveletJob& job = *jobp;
+  job.rank = e.next_ticket;
   job.user_out = out;
   job.user_cap = out_cap;
   // header: WaveletEncoder::writeBlockHeader, WaveletCoders.cpp:173-219
@@ -99,6 +120,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(job.coder->elements() + 8)) return -2;
       job.outs.assign(nsec, bwtc::wavelet::SectionOutput());
+      job.t_queued = std::chrono::steady_clock::now();
       job.models_left = job.coder->modelTasks();
       job.sections_left = job.coder->sectionTasks();
       if (!e.pool) e.pool = new WorkerPool(threads);
@@ -107,26 +129,69 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
         finish_wavelet_job(job);
       } else {
         WorkerPool* pool = e.pool;
-        for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
-          pool->submit([jobp, pool, k] {
-            WaveletJob& j = *jobp;
-            j.coder->model(k, j.prob.data());
-            bool last;
-            { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
-            if (!last) return;
-            // every group is modelled: the sections' range coders, ahead of newer blocks' work
-            std::vector<std::function<void()> > next;
-            for (size_t q = 0; q < j.coder->sectionTasks(); ++q) {
-              next.push_back([jobp, q] {
-                WaveletJob& jj = *jobp;
-                jj.coder->codeSection(q, jj.prob.data(), &jj.outs);
-                bool fin;
-                { std::lock_guard<std::mutex> g(jj.mu); fin = --jj.sections_left == 0; }
-                if (fin) finish_wavelet_job(jj);
+        if (e.wavelet_model == 'B' && bwtc::wavelet::simdModelsAvailable()) {
+          // sixteen groups per thread at a time, lanes refilled across blocks (wavelet_simd.hpp,
+          // BlockGroupSource).  A few engines keep up with the GPU; the range coders need the rest.
+          if (!e.model_groups) {
+            e.model_groups = new BlockGroupSource();
+            StageClock* clock = &e.stage_clock;
+            e.model_groups->on_block_modelled = [pool, clock](const std::shared_ptr<WaveletJob>& j) { submit_sections(j, pool, clock); };
+          }
+          BlockGroupSource* groups = e.model_groups;
+          const unsigned max_engines = std::max(1u, (pool->size() + 3) / 4);
+          // the block's few huge groups keep their own scalar tasks: a lane would hold the block's
+          // range coders back for as long as the largest of them takes at a lane's pace
+          if (debug) {
+            uint64_t cnt[8] = {0}, el[8] = {0};
+            for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
+              const uint64_t n = job.coder->taskElements(k);
+              const int b = n >= (32u << 20) ? 7 : n >= (16u << 20) ? 6 : n >= (8u << 20) ? 5 : n >= (4u << 20) ? 4 : n >= (1u << 20) ? 3 : n >= (1u << 16) ? 2 : n >= 256 ? 1 : 0;
+              ++cnt[b]; el[b] += n;
+            }
+            std::fprintf(stderr, "wavelet groups by size (<256, <64Ki, <1Mi, <4Mi, <8Mi, <16Mi, <32Mi, more): ");
+            for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
+            std::fprintf(stderr, "\n");
+          }
+          const uint64_t kHuge = 16u << 20;
+          size_t huge = 0;
+          while (huge < job.coder->modelTasks() && job.coder->taskElements(huge) >= kHuge) ++huge;
+          {
+            StageClock* clock = &e.stage_clock;
+            std::vector<std::function<void()> > own;
+            for (size_t k = 0; k < huge; ++k) {
+              own.push_back([jobp, pool, k, clock] {
+                WaveletJob& j = *jobp;
+                const auto t0 = std::chrono::steady_clock::now();
+                j.coder->model(k, j.prob.data());
+                clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                bool last;
+                { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
+                if (last) submit_sections(jobp, pool, clock);
               });
             }
-            pool->submitFront(next);
-          });
+            pool->submit(job.rank, own);
+          }
+          if (huge < job.coder->modelTasks() && groups->add(jobp, huge, max_engines)) {
+            StageClock* clock = &e.stage_clock;
+            pool->submit(0, [groups, clock] {
+              const auto t0 = std::chrono::steady_clock::now();
+              bwtc::wavelet::runModelLanes(*groups);
+              clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            });
+          }
+        } else {
+          for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
+            StageClock* clock = &e.stage_clock;
+            pool->submit(job.rank, [jobp, pool, k, clock] {
+              WaveletJob& j = *jobp;
+              const auto t0 = std::chrono::steady_clock::now();
+              j.coder->model(k, j.prob.data());
+              clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+              bool last;
+              { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
+              if (last) submit_sections(jobp, pool, clock);
+            });
+          }
         }
       }
       if (debug) {
@@ -156,6 +221,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
     }
   }
   if (!queued) finish_wavelet_job(job);
+  ++e.stage_clock.blocks;
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;
   return 0;
@@ -167,6 +233,12 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
   std::shared_ptr<WaveletJob> jobp = it->second;
   WaveletJob& job = *jobp;
   { std::unique_lock<std::mutex> g(job.mu); job.cv.wait(g, [&] { return job.done; }); }
+  if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
+    std::fprintf(stderr, "wavelet block %llu: queued -> modelled %.0f ms, -> finished %.0f ms, -> collected %.0f ms\n",
+                 (unsigned long long)ticket,
+                 std::chrono::duration<double, std::milli>(job.t_modelled - job.t_queued).count(),
+                 std::chrono::duration<double, std::milli>(job.t_finished - job.t_modelled).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t_finished).count());
   e.jobs.erase(it);
   // keep the two big buffers: fresh ones would be paged in again for every block
   if (job.codes.size() && e.codes_free.size() < e.max_inflight) {
@@ -189,8 +261,13 @@ void wavelet_pipeline_release(BwtEngine& e) {
     job.cv.wait(g, [&] { return job.done; });
   }
   e.jobs.clear();
-  delete e.pool;
+  if (std::getenv("BWTC_HIP_DEBUG") && e.stage_clock.blocks)
+    std::fprintf(stderr, "wavelet pipeline: %llu blocks; host time in models %.3f s, in range coders %.3f s (summed over threads)\n",
+                 (unsigned long long)e.stage_clock.blocks.load(), e.stage_clock.model_ns.load() * 1e-9, e.stage_clock.coder_ns.load() * 1e-9);
+  delete e.pool;                                  // joins the workers (engines retire when nothing is queued)
   e.pool = nullptr;
+  delete e.model_groups;
+  e.model_groups = nullptr;
   e.codes_free.clear();
   e.prob_free.clear();
 }

@@ -964,6 +964,17 @@ void StreamCoder::model(size_t k, uint16_t* prob) const {
   else modelGroup<kInner>(model_, codes_, t.begin, t.end, mc, prob);
 }
 
+void StreamCoder::describe(size_t k, uint16_t* prob, ModelGroupDesc* d) const {
+  const Task& t = tasks_[k];
+  d->codes = codes_;
+  d->prob = prob;
+  d->begin = t.begin;
+  d->end = t.end;
+  d->type = t.type;
+  d->mainState = (t.type == kInteger || t.type == kBothLeaves) ? 0u : stateBefore(t.section, t.group);
+  d->cookie = 0;
+}
+
 void StreamCoder::codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const {
   const size_t s = sections_[k];
   const StreamPlan::Section& sec = plan_.sections[s];
@@ -984,7 +995,24 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
   if (prob.size() < total) { std::vector<uint16_t>().swap(prob); prob.resize(total + total / 8); }
   const bool debug = std::getenv("BWTC_HIP_DEBUG") != 0;
   const auto t0 = std::chrono::steady_clock::now();
-  parallelFor(coder.modelTasks(), threads, 0, [&](size_t k) { coder.model(k, prob.data()); });
+  if (model == 'B' && simdModelsAvailable()) {
+    // sixteen groups per thread at a time (wavelet_simd.hpp); the engines share one cursor
+    struct Source : GroupSource {
+      const StreamCoder* coder; uint16_t* prob; std::mutex mu; size_t next_;
+      bool next(ModelGroupDesc* d) {
+        size_t k;
+        { std::lock_guard<std::mutex> g(mu); if (next_ >= coder->modelTasks()) return false; k = next_++; }
+        coder->describe(k, prob, d);
+        return true;
+      }
+      void done(void*) {}
+    } source;
+    source.coder = &coder; source.prob = prob.data(); source.next_ = 0;
+    const unsigned engines = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>(coder.modelTasks() / 16 + 1)));
+    parallelFor(engines, engines, 0, [&](size_t) { runModelLanes(source); });
+  } else {
+    parallelFor(coder.modelTasks(), threads, 0, [&](size_t k) { coder.model(k, prob.data()); });
+  }
   const auto t1 = std::chrono::steady_clock::now();
   parallelFor(coder.sectionTasks(), threads, 0, [&](size_t k) { coder.codeSection(k, prob.data(), out); });
   if (debug) {

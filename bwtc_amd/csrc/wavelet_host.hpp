@@ -15,6 +15,8 @@
 #include <utility>
 #include <vector>
 
+#include "wavelet_simd.hpp"
+
 namespace bwtc {
 namespace wavelet {
 
@@ -98,6 +100,10 @@ class StreamCoder {
   uint64_t elements() const;                              // size of the probability buffer
   size_t modelTasks() const { return tasks_.size(); }
   void model(size_t k, uint16_t* prob) const;
+  // the same task as a descriptor for the 16-lane engine (wavelet_simd.hpp; coder 'B' only)
+  void describe(size_t k, uint16_t* prob, ModelGroupDesc* d) const;
+  char modelLetter() const { return model_; }
+  uint64_t taskElements(size_t k) const { return tasks_[k].end - tasks_[k].begin; }
   size_t sectionTasks() const { return sections_.size(); }
   void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
 

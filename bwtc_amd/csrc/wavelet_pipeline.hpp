@@ -7,11 +7,14 @@
 // and is known before its coding starts, so the bytes are those of a strictly sequential
 // encoder.
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -25,11 +28,17 @@
 
 namespace bwtc_hip {
 
-// Fixed set of threads, two-ended queue: new blocks' work goes to the back, the follow-up work
-// of blocks already under way to the front, so the oldest block finishes first.
+// host time spent in the two stages (summed over threads), for BWTC_HIP_DEBUG
+struct StageClock {
+  std::atomic<uint64_t> model_ns{0}, coder_ns{0}, blocks{0};
+};
+
+// Fixed set of threads over one queue ordered by (block, submission order): whatever the
+// oldest block still needs runs first, so the block the caller will collect next is never
+// overtaken by the work of newer ones.  Rank 0 is for the cross-block model engines.
 class WorkerPool {
  public:
-  explicit WorkerPool(unsigned threads) : stop_(false) {
+  explicit WorkerPool(unsigned threads) : seq_(0), stop_(false) {
     for (unsigned i = 0; i < (threads ? threads : 1u); ++i) workers_.push_back(std::thread([this] { loop(); }));
   }
   ~WorkerPool() {
@@ -38,13 +47,13 @@ class WorkerPool {
     for (size_t i = 0; i < workers_.size(); ++i) workers_[i].join();
   }
   unsigned size() const { return static_cast<unsigned>(workers_.size()); }
-  void submit(std::function<void()> f, bool front = false) {
-    { std::lock_guard<std::mutex> g(mu_); if (front) q_.push_front(std::move(f)); else q_.push_back(std::move(f)); }
+  void submit(uint64_t rank, std::function<void()> f) {
+    { std::lock_guard<std::mutex> g(mu_); q_.insert(std::make_pair(std::make_pair(rank, seq_++), std::move(f))); }
     cv_.notify_one();
   }
   // the tasks keep their order: first of `fs` runs first
-  void submitFront(std::vector<std::function<void()> >& fs) {
-    { std::lock_guard<std::mutex> g(mu_); for (size_t i = fs.size(); i-- > 0;) q_.push_front(std::move(fs[i])); }
+  void submit(uint64_t rank, std::vector<std::function<void()> >& fs) {
+    { std::lock_guard<std::mutex> g(mu_); for (size_t i = 0; i < fs.size(); ++i) q_.insert(std::make_pair(std::make_pair(rank, seq_++), std::move(fs[i]))); }
     cv_.notify_all();
   }
 
@@ -58,15 +67,16 @@ class WorkerPool {
         std::unique_lock<std::mutex> g(mu_);
         cv_.wait(g, [this] { return stop_ || !q_.empty(); });
         if (q_.empty()) return;                      // stop_ and drained
-        f = std::move(q_.front());
-        q_.pop_front();
+        f = std::move(q_.begin()->second);
+        q_.erase(q_.begin());
       }
       f();
     }
   }
   std::mutex mu_;
   std::condition_variable cv_;
-  std::deque<std::function<void()> > q_;
+  std::map<std::pair<uint64_t, uint64_t>, std::function<void()> > q_;
+  uint64_t seq_;
   std::vector<std::thread> workers_;
   bool stop_;
 };
@@ -98,8 +108,42 @@ class RawBuffer {
   size_t n_;
 };
 
+struct WaveletJob;
+
+// The groups of all blocks under way, oldest block first and largest group first within a
+// block, for the 16-lane model engines (wavelet_simd.hpp).  Lanes are refilled across block
+// borders: one block's few huge groups (the root of its largest section holds a tenth of its
+// elements) share vectors with the next blocks' groups instead of running in a nearly empty
+// vector.  Engines are few (the models are a small part of the host work; the range coders
+// need the other threads) and come and go with the work: begin() starts one when there are
+// fewer than the limit, an engine that finds nothing left retires -- both decided under the
+// source's lock.
+class BlockGroupSource : public bwtc::wavelet::GroupSource {
+ public:
+  BlockGroupSource() : engines_(0) {}
+  // queues a block's groups from `first_group` on (the list is largest first; the caller keeps
+  // the few huge ones for the scalar loop, which finishes a single chain four times sooner than
+  // a lane does); true = the caller should start one more engine
+  bool add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines);
+  bool next(bwtc::wavelet::ModelGroupDesc* d);
+  void done(void* cookie);
+  bool retire() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!queue_.empty()) return false;
+    --engines_;
+    return true;
+  }
+  // set once: what to do when a block's last group is modelled
+  std::function<void(const std::shared_ptr<WaveletJob>&)> on_block_modelled;
+ private:
+  struct Entry { std::shared_ptr<WaveletJob> job; size_t next; };
+  std::mutex mu_;
+  std::deque<Entry> queue_;
+  unsigned engines_;
+};
+
 // One block between bwtc_hip_wavelet_encode_device_begin and ..._end.
-struct WaveletJob {
+struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   std::vector<uint8_t> record;                       // header + section sizes, then the sections, finished in place
   bwtc::wavelet::StreamPlan plan;
   std::vector<uint32_t> coded_pos;
@@ -111,8 +155,45 @@ struct WaveletJob {
   std::condition_variable cv;
   size_t models_left = 0, sections_left = 0;
   bool done = false;
+  uint64_t rank = 0;                                 // the block's place in the worker pool's order (its ticket)
   uint8_t* user_out = nullptr;
   uint64_t user_cap = 0;
+  std::chrono::steady_clock::time_point t_queued, t_modelled, t_finished;   // BWTC_HIP_DEBUG timeline
 };
+
+}  // namespace bwtc_hip
+
+namespace bwtc_hip {
+
+inline bool BlockGroupSource::add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines) {
+  std::lock_guard<std::mutex> g(mu_);
+  Entry e = {job, first_group};
+  queue_.push_back(e);
+  if (engines_ >= max_engines) return false;
+  ++engines_;
+  return true;
+}
+
+inline bool BlockGroupSource::next(bwtc::wavelet::ModelGroupDesc* d) {
+  std::shared_ptr<WaveletJob> job;
+  size_t k = 0;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    while (!queue_.empty() && queue_.front().next >= queue_.front().job->coder->modelTasks()) queue_.pop_front();
+    if (queue_.empty()) return false;
+    job = queue_.front().job;
+    k = queue_.front().next++;
+  }
+  job->coder->describe(k, job->prob.data(), d);
+  d->cookie = job.get();
+  return true;
+}
+
+inline void BlockGroupSource::done(void* cookie) {
+  WaveletJob* job = static_cast<WaveletJob*>(cookie);
+  bool last;
+  { std::lock_guard<std::mutex> g(job->mu); last = --job->models_left == 0; }
+  if (last) on_block_modelled(job->shared_from_this());
+}
 
 }  // namespace bwtc_hip

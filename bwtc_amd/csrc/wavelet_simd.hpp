@@ -1,0 +1,44 @@
+// Stage 1 of the stream coder (the adaptive models of coder 'B'), sixteen groups at a time.
+//
+// One group's predictor recurrence is a serial chain, but groups are independent (fresh
+// predictors at every group start, wavelet_host.hpp), so a thread steps sixteen groups in
+// lockstep, one per AVX-512 lane: per step every lane reads its 2-bit element, selects its
+// predictor (15 per lane, kept as 15 vectors), emits the probability, moves the predictor
+// and its three small state machines.  Lanes that finish are refilled from a source that may
+// span several blocks, so long and short groups share vectors; when too few lanes are left
+// the remaining groups are finished with the scalar loop.  Heads and tails that do not fill a
+// 16-element word of the packed streams are scalar as well.  Results are identical to
+// modelGroup() by construction (same integer operations per element).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace bwtc {
+namespace wavelet {
+
+struct ModelGroupDesc {
+  const uint8_t* codes;      // packed streams of the group's block
+  uint16_t* prob;            // probabilities of the group's block
+  uint64_t begin, end;       // elements [begin, end)
+  uint8_t type;              // GroupType
+  uint32_t mainState;        // main model's state at the group's start
+  void* cookie;              // handed back through done()
+};
+
+class GroupSource {
+ public:
+  virtual ~GroupSource() {}
+  virtual bool next(ModelGroupDesc* g) = 0;     // false: none available now
+  virtual void done(void* cookie) = 0;          // the group is fully modelled
+  // An engine with nothing left asks before it returns; false = more groups have arrived
+  virtual bool retire() { return true; }
+};
+
+// AVX-512 (F, BW, VL, DQ) present on this CPU and not switched off with BWTC_HIP_SIMD=0
+bool simdModelsAvailable();
+
+// Models groups from `src` until it is empty and every lane has drained.
+void runModelLanes(GroupSource& src);
+
+}  // namespace wavelet
+}  // namespace bwtc
