@@ -492,10 +492,23 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
+  BWTC_HIP_TRY(hipEventCreateWithFlags(&ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+  {
+    const char* m = std::getenv("BWTC_HIP_SYNC");
+    wait_mode = m && std::strcmp(m, "spin") == 0 ? 1 : m && std::strcmp(m, "block") == 0 ? 2 : 0;
+  }
   BWTC_HIP_TRY(hipEventCreate(&ev_begin));
   BWTC_HIP_TRY(hipEventCreate(&ev_end));
   for (int i = 0; i < kMaxSortEvents; ++i) BWTC_HIP_TRY(hipEventCreate(&ev_sort[i]));
   return 0;
+}
+
+hipError_t BwtEngine::wait() {
+  const bool block = wait_mode == 2 || (wait_mode == 0 && pool != nullptr);
+  if (!block || !ev_wait) return hipStreamSynchronize(stream);
+  hipError_t rc = hipEventRecord(ev_wait, stream);
+  if (rc != hipSuccess) return rc;
+  return hipEventSynchronize(ev_wait);
 }
 
 void BwtEngine::release() {
@@ -507,6 +520,8 @@ void BwtEngine::release() {
   if (d_wt) (void)hipFree(d_wt);
   if (h_wt) (void)hipHostFree(h_wt);
   d_wt = nullptr; h_wt = nullptr; wt_bytes = 0; h_wt_bytes = 0;
+  if (ev_wait) (void)hipEventDestroy(ev_wait);
+  ev_wait = nullptr;
   if (ev_begin) (void)hipEventDestroy(ev_begin);
   if (ev_end) (void)hipEventDestroy(ev_end);
   for (int i = 0; i < kMaxSortEvents; ++i) if (ev_sort[i]) (void)hipEventDestroy(ev_sort[i]);
@@ -677,7 +692,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   }
   stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(wait());
   if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
   u32 m = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
 
@@ -719,7 +734,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
                          aglob_other, d_GRP, (u32*)nullptr, (u32*)nullptr);
     }
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(hipStreamSynchronize(st));
+    BWTC_HIP_TRY(wait());
     if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
     m = h_small[kSmallCounts];
     groups = h_small[kSmallCounts + 1];
@@ -742,7 +757,7 @@ int BwtEngine::load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* h
                      d_T, ncopy, padded, reverse ? 1 : 0, aligned, d_small + kSmallFreqs);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFreqs, d_small + kSmallFreqs, 256 * 4,
                               hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(wait());
   for (int c = 0; c < 256; ++c) hist_T[c] = h_small[kSmallFreqs + c];
   hist_T[0] += n - ncopy;
   return 0;
@@ -773,7 +788,7 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
     BWTC_HIP_TRY(hipMemcpyAsync(d_dst, d_out, raw ? n : size, hipMemcpyDeviceToDevice, st));
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallLf, d_small + kSmallLf, 264 * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipEventRecord(ev_end, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(wait());
   BWTC_HIP_TRY(hipGetLastError());
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
   probe.harvest();

@@ -78,6 +78,13 @@ struct BwtEngine {
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
 
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_wait = nullptr;        // blocking-sync event (hipEventBlockingSync)
+  int wait_mode = 0;                   // 0 auto: block while the 'B' worker pool exists, spin otherwise; 1 spin; 2 block (BWTC_HIP_SYNC)
+  // Waits for the context's stream.  hipStreamSynchronize spins, which costs the calling thread
+  // (and a runtime helper thread) a CPU or two for the whole device time of a block; harmless
+  // when nothing else runs, but the 'B' coder's worker threads need those CPUs, so the wait then
+  // sleeps on an interrupt instead.
+  hipError_t wait();
   static constexpr int kMaxSortEvents = 160;
   hipEvent_t ev_sort[kMaxSortEvents];
   int n_sort_events = 0;

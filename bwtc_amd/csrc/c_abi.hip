@@ -32,7 +32,7 @@ static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int
   BWTC_HIP_TRY(hipMemcpyAsync(keys, ks, n * sizeof(K), hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(hipMemcpyAsync(vals, vs, n * 4, hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 522, e.d_small + 522, 4, hipMemcpyDeviceToHost, e.stream));
-  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(e.wait());
   if (e.h_small[522]) return -3;
   BWTC_HIP_TRY(hipGetLastError());
   return 0;
@@ -131,7 +131,7 @@ static int stage_in(BwtEngine& e, const uint8_t* host, uint32_t bytes) {
 static int stage_out(BwtEngine& e, uint8_t* host, uint32_t bytes) {
   if (!bytes) return 0;
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_stage, e.d_in, bytes, hipMemcpyDeviceToHost, e.stream));
-  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(e.wait());
   std::memcpy(host, e.h_stage, bytes);
   return 0;
 }
@@ -217,7 +217,7 @@ int bwtc_hip_huffman_encode(bwtc_hip_ctx* ctx, const uint8_t* bwt, uint32_t size
   if (rc) return rc;
   if (n > out_cap) return -1;
   BWTC_HIP_TRY(hipMemcpyAsync(out, e.d_comp, n, hipMemcpyDeviceToHost, e.stream));
-  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(e.wait());
   *out_bytes = n;
   return 0;
 }
@@ -478,7 +478,7 @@ int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, 
   rc = e.suffix_sort(length, hist, false);
   if (rc) return rc;
   BWTC_HIP_TRY(hipMemcpyAsync(sa, e.d_SA, (u64)length * 4, hipMemcpyDeviceToHost, e.stream));
-  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(e.wait());
   return 0;
 }
 
@@ -499,7 +499,7 @@ int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n) {
   BWTC_HIP_TRY(hipMemcpyAsync(d, data, n * 4, hipMemcpyHostToDevice, e.stream));
   exclusive_scan_u32(d, n, static_cast<u32*>(e.d_R2), e.stream);
   BWTC_HIP_TRY(hipMemcpyAsync(data, d, n * 4, hipMemcpyDeviceToHost, e.stream));
-  BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+  BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   return 0;
 }

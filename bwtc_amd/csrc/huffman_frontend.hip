@@ -382,7 +382,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
     for (int i = 0; i < 6; ++i) head[i] = (uint8_t)(len >> (8 * (5 - i)));
     if (head.size() > out_cap) return -1;
     BWTC_HIP_TRY(hipMemcpyAsync(d_out, head.data(), head.size(), hipMemcpyHostToDevice, st));
-    BWTC_HIP_TRY(hipStreamSynchronize(st));
+    BWTC_HIP_TRY(e.wait());
     *out_bytes = head.size();
     return 0;
   }
@@ -421,7 +421,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
                      nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
   u32 n_runs = 0;
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   n_runs = e.h_small[0];
   if (n_runs == 0 || n_runs > size) return -3;
 
@@ -434,7 +434,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   BWTC_HIP_TRY(hipMemcpyAsync(h_run_freqs.data(), d_run_freqs, (size_t)nsec * 1024, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(h_gbits.data(), d_gbits, (size_t)nsec * 8, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(h_first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
 
   // ---- host: per-section tables and layout (encodeData, :133-198)
   std::vector<uint8_t> clen_tab((size_t)nsec * 256);
@@ -495,7 +495,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
                      d_first_run, nsec, d_clen, d_tile_base, d_base_bit, d_adj);
   hipLaunchKernelGGL(k_pack_emit<1>, dim3(ptiles), dim3(kPackTPB), 0, st, d_run_start, d_run_sym,
                      n_runs, d_first_run, nsec, d_clen, d_code, d_tile_base, d_adj, out32);
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   *out_bytes = total;
   return 0;
@@ -587,7 +587,7 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   hipLaunchKernelGGL(k_runs_emit, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
                      nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   const u32 n_runs = e.h_small[0];
   if (n_runs == 0 || n_runs > size) return -3;
   const u32 stiles = ceil_div(n_runs, kStatTile);
@@ -601,13 +601,13 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   BWTC_HIP_TRY(hipMemcpyAsync(first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(dense.data(), d_dense, dense.size() * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   if (n_over > over_cap) return -2;
   std::vector<u32> osec(n_over), olen(n_over);
   if (n_over) {
     BWTC_HIP_TRY(hipMemcpyAsync(osec.data(), d_over_sec, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipMemcpyAsync(olen.data(), d_over_len, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(hipStreamSynchronize(st));
+    BWTC_HIP_TRY(e.wait());
   }
   BWTC_HIP_TRY(hipGetLastError());
   out->first_run = first;

@@ -206,7 +206,7 @@ int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const
   BWTC_HIP_TRY(hipMemcpyAsync(d_out, e.d_out, size, hipMemcpyDeviceToDevice, st));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 600, e.d_small + 600, 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipEventRecord(e.ev_end, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   (void)hipEventElapsedTime(&e.stats.ms_total, e.ev_begin, e.ev_end);
   e.stats.n = n;

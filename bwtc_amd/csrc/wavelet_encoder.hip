@@ -212,7 +212,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       std::vector<u32> run_start((size_t)n_runs + 1);
       BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
       BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(hipStreamSynchronize(e.stream));
+      BWTC_HIP_TRY(e.wait());
       for (u32 s = 0; s < nsec; ++s) {
         secs[s].symbols = run_sym.data() + st.first_run[s];
         secs[s].starts = run_start.data() + st.first_run[s];

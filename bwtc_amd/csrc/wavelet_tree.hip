@@ -329,7 +329,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
                      d_run_start, d_run_sym, n_runs, t, d_cnt);
   exclusive_scan_u32(d_cnt, (u64)n_runs + 1, ptr32(o_cnt_partial), st);
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_cnt + n_runs, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   const u32 n = e.h_small[0];
   if (n == 0 || (u64)n > cap) return -3;
   hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_start,
@@ -361,7 +361,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_tile + tiles, 4, hipMemcpyDeviceToHost, st));
   coded_pos->assign((size_t)n_groups + 1, 0);
   BWTC_HIP_TRY(hipMemcpyAsync(coded_pos->data(), ptr32(o_gpos), n_groups * 4ull, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   const u32 n_coded = e.h_small[0];
   if (n_coded > n) return -3;
   const u32 words = ceil_div(n_coded, 16);
@@ -370,7 +370,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
                        ptr32(o_packed));
     BWTC_HIP_TRY(hipMemcpyAsync(e.h_wt, base + o_packed, words * 4ull, hipMemcpyDeviceToHost, st));
   }
-  BWTC_HIP_TRY(hipStreamSynchronize(st));
+  BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   (*coded_pos)[n_groups] = n_coded;
   for (u32 g = n_groups; g-- > 0;)
