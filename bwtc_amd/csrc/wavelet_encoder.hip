@@ -103,6 +103,10 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
     const auto t0 = std::chrono::steady_clock::now();
     const bool on_device = !e.wavelet_on_host && bwtc::wavelet::planStreams(secs, &job.plan) &&
                            job.plan.max_elements + (1u << 16) < (1ull << 32);
+    if (!on_device && !e.wavelet_on_host)
+      std::fprintf(stderr, "bwtc_hip: block of %u bytes is outside the stream kernels' range (%llu steps, %zu groups); "
+                   "its wavelet trees are built by the host route instead (same bytes, much slower)\n", size,
+                   (unsigned long long)job.plan.max_elements, job.plan.group_type.size());
     if (on_device) {
       const auto t1 = std::chrono::steady_clock::now();
       const u8* codes = nullptr;
