@@ -259,8 +259,7 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
 
 void wavelet_pipeline_release(BwtEngine& e) {
   for (std::map<u64, std::shared_ptr<WaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it) {
-    WaveletJob& job = *it->second;
-    job.user_out = nullptr;
+    WaveletJob& job = *it->second;                // uncollected blocks are finished, not abandoned half way
     std::unique_lock<std::mutex> g(job.mu);
     job.cv.wait(g, [&] { return job.done; });
   }

@@ -19,8 +19,8 @@ namespace {
 const int kLanes = 16;
 const int kSlots = 15;                   // main 0..7, gaps 8..11, integers 12..14
 const uint64_t kScalarOnly = 256;        // groups shorter than this never enter a lane
-const int kMinLanes = 2;                 // a single busy lane and an empty source: finish it scalar (a vector
-                                         // step costs about as much as one and a half scalar elements)
+const int kMinLanes = 6;                 // fewer busy lanes and an empty source: finish them scalar (on the GPU
+                                         // box's EPYC a vector step costs as much as six scalar elements)
 
 const uint32_t kInit[16] = {2400, 2300, 2200, 2100, 4096 - 2100, 4096 - 2200, 4096 - 2300, 4096 - 2400,
                             2048, 2048, 2048, 2048, 2048, 2048, 2048, 0};

@@ -180,7 +180,8 @@ int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint
  * are those of a strictly sequential encoder whatever the overlap.  At most
  * BWTC_HIP_WAVELET_DEPTH (default 12) blocks are under way; a further _begin waits for the
  * oldest, and returns -6 if that one is finished but not collected.  `out` must stay valid
- * until _end; _begin/_end of one context are called from one thread. */
+ * until _end (or until bwtc_hip_destroy returns: it lets blocks under way finish);
+ * _begin/_end of one context are called from one thread. */
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                          const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
                                          uint32_t threads, uint8_t* out, uint64_t out_cap,

@@ -276,3 +276,25 @@ def test_wavelet_other_model_letters_on_the_device_route(hip_ctx, oracle):
                 hip_ctx.wavelet_start(coder)
     finally:
         hip_ctx.wavelet_reset()
+
+
+def test_wavelet_B_context_closed_with_blocks_under_way():
+    """bwtc_hip_destroy with uncollected blocks: they are finished (their records land in the
+    buffers given to _begin), nothing hangs or crashes."""
+    from bwtc_amd import hip
+    ctx = hip.Context(device=0, max_block_size=(1 << 20) + 1024)
+    outs = []
+    d_in = ctx.dmalloc((1 << 20) + 64)
+    ctx.wavelet_reset()
+    for i in range(3):
+        blk = synth.gen_text(400000, 70 + i)
+        ctx.to_device(d_in, blk)
+        lf, freqs = ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+        out = np.zeros(ctx.compress_bound(blk.size), np.uint8)
+        ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=3)
+        outs.append(out)
+    ctx.dfree(d_in)
+    ctx.close()
+    for out in outs:
+        n = int.from_bytes(out[:6].tobytes(), "big")
+        assert 1000 < n < out.size and out[6 + n - 1] == 255     # closed record: length patched, coder flushed
