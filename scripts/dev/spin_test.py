@@ -1,5 +1,6 @@
+"""How much CPU the GPU-feeding thread burns while it waits (BWTC_HIP_SYNC=spin|block)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))) if False else "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from bwtc_amd import hip, synth
