@@ -177,6 +177,11 @@ def test_wavelet_B_large_text_block(hip_ctx, oracle):
     rec, bwt = hip_ctx.transform_and_encode_wavelet(data, 8)
     want = oracle.oracle_compress_B(data, data.size, 8).tobytes()
     assert _frame(b"B", rec.tobytes(), data.size) == want
+    # and the other extreme of the run structure: DNA, almost every byte its own run, 4 symbols
+    data = synth.gen_dna(16 << 20, 9)
+    hip_ctx.wavelet_reset()
+    rec, bwt = hip_ctx.transform_and_encode_wavelet(data, 8)
+    assert _frame(b"B", rec.tobytes(), data.size) == oracle.oracle_compress_B(data, data.size, 8).tobytes()
 
 
 def test_wavelet_B_overlapped_blocks_equal_the_sequential_stream(hip_ctx, oracle):
