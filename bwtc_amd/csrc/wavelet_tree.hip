@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_count(const u32* __restrict__ run
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
-                                                      u32* __restrict__ key, u32* __restrict__ val) {
+                                                      u32* __restrict__ key) {
   __shared__ u32 s_first[257];
   for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
   __syncthreads();
@@ -90,11 +90,11 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   const uint2 sy = t.symtab[s * 256u + run_sym[r]];
   u32 o = off[r];
   const u32 ns = sy.y & 255u;
-  for (u32 i = 0; i < ns; ++i, ++o) { key[o] = t.pool[sy.x + i]; val[o] = o; }
+  for (u32 i = 0; i < ns; ++i, ++o) key[o] = t.pool[sy.x + i];
   if (sy.y >> 16) {
     const uint2 le = wt_length_entry(t, s, run_start[r + 1] - run_start[r]);
     const u32 leaf = ((sy.y >> 8) & 255u) << kStepLeafShift;
-    for (u32 i = 0; i < le.y; ++i, ++o) { key[o] = t.pool[le.x + i] | leaf; val[o] = o; }
+    for (u32 i = 0; i < le.y; ++i, ++o) key[o] = t.pool[le.x + i] | leaf;
   }
 }
 
@@ -333,11 +333,12 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   const u32 n = e.h_small[0];
   if (n == 0 || (u64)n > cap) return -3;
   hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_start,
-                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), ptr32(o_v0));
-  // sort by (group, leaf rank); bit 0 rides along
+                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0));
+  // sort by (group, leaf rank); bit 0 rides along; the payload is the step's place in run order
+  if (n == 1) BWTC_HIP_TRY(hipMemsetAsync(ptr32(o_v0), 0, 4, st));    // a lone step is not sorted: its place is 0
   u32* ks = nullptr; u32* vs = nullptr;
   radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), ptr32(o_v0), ptr32(o_v1), n, key_bits,
-                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift);
+                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, true);
   // gaps
   u8* d_flag = base + o_flag;
   u32* d_gstart = ptr32(o_gstart);
