@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -229,3 +230,19 @@ def test_wavelet_decoder_program(oracle):
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all tests passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_wavelet_scalar_models_when_simd_is_off():
+    """The same host-half checks with the 16-lane model engine switched off (BWTC_HIP_SIMD=0 is
+    read once per process, hence the child process): machines with AVX-512 would otherwise never
+    run the scalar model loop of the stream route."""
+    import subprocess
+    import sys
+    if os.environ.get("BWTC_HIP_SIMD") == "0":
+        pytest.skip("already the child")
+    env = dict(os.environ, BWTC_HIP_SIMD="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
+                        "wavelet_host_half_matches_oracle or wavelet_golden_stream"],
+                       capture_output=True, text=True, env=env, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
