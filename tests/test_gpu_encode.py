@@ -303,3 +303,19 @@ def test_wavelet_B_context_closed_with_blocks_under_way():
     for out in outs:
         n = int.from_bytes(out[:6].tobytes(), "big")
         assert 1000 < n < out.size and out[6 + n - 1] == 255     # closed record: length patched, coder flushed
+
+
+def test_varied_block_sweep_both_coders(hip_ctx, oracle):
+    """150 small blocks of varied shape (tests/blockgen.py) through the device halves of both
+    coders, each against the oracle: rare shapes of the section / tree / run-length machinery."""
+    import blockgen
+    lf = np.zeros(1, np.uint32)
+    for case, kind, bwt in blockgen.varied_blocks(150, 60000, seed=777):
+        freqs = np.bincount(bwt, minlength=256).astype(np.uint32)   # any byte string serves as a transformed block
+        hip_ctx.wavelet_reset()
+        got = hip_ctx.wavelet_encode(bwt, lf, freqs, threads=2)
+        want = oracle.oracle_wavelet_encode_block(bwt, lf, freqs)
+        assert got.tobytes() == want.tobytes(), ("B", case, kind, bwt.size)
+        got = hip_ctx.huffman_encode(bwt, lf, freqs)
+        want = oracle.oracle_huffman_encode_block(bwt, lf, freqs)
+        assert got.tobytes() == want.tobytes(), ("H", case, kind, bwt.size)

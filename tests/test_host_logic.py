@@ -246,3 +246,29 @@ def test_wavelet_scalar_models_when_simd_is_off():
                        capture_output=True, text=True, env=env, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_wavelet_stream_route_random_sweep(oracle):
+    """Many small transformed blocks of varied shape (alphabet size, run structure, skew, long
+    runs, sparse symbols) through planning + the stated device passes + the stream coder, against
+    the oracle's literal encoder.  Looks for rare shapes: single-symbol sections, trees whose
+    inner nodes have one leaf child, escape-coded run lengths, sections at the 256 limit."""
+    H = _host()
+    import blockgen
+    lfa = np.zeros(1, np.uint32)
+    checked = 0
+    for case, kind, d in blockgen.varied_blocks(160, 30000, seed=20260):
+        n = d.size
+        bwt = np.ascontiguousarray(d, dtype=np.uint8)      # any byte string is a valid "transformed block" here
+        if bwt.size == 0:
+            continue
+        freqs = np.bincount(bwt, minlength=256).astype(np.uint32)
+        sections = oracle.oracle_sections(freqs)
+        want = oracle.oracle_wavelet_encode_block(bwt, lfa, freqs).tobytes()
+        skip = 6 + 5 + 1 + sum(len(_packed(int(x))) for x in sections)     # 1 LF power: 1 + 4 header bytes
+        got, _ = _host_wavelet_payload(H, bwt, sections, 4, 2, "bwtc_hip_host_wavelet_streams")
+        assert got == want[skip:], (case, kind, n)
+        got, _ = _host_wavelet_payload(H, bwt, sections, 4, 1, "bwtc_hip_host_wavelet_sections")
+        assert got == want[skip:], ("tree route", case, kind, n)
+        checked += 1
+    assert checked > 150
