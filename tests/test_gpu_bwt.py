@@ -180,6 +180,21 @@ def test_baseline_full_size_256MiB_text(oracle):
     print("256MiB text: %.1f ms device, rounds %d, R_eff %.2f" % (st.ms_total, st.rounds, st.active_sum / st.n))
 
 
+def test_baseline_1GiB_single_block_round_trip():
+    """BASELINE.json config 5 at full size: one 1 GiB block (N = 2^30 + 1, the largest the 31-bit
+    header fields carry), forward transform and inverse transform on the GPU; the inverse also
+    verifies every LF power against its own ranking.  Size-independent property, no oracle."""
+    from bwtc_amd import hip
+    size = 1 << 30
+    d = synth.gen_dna(size, 5)
+    with hip.Context(0, size) as ctx:
+        bwt, lf, freqs = ctx.bwt_block(d, 8)
+        assert (freqs == np.bincount(d, minlength=256)).all()
+        assert lf.size == 8 and int(lf.max()) <= size
+        back = ctx.inverse_bwt_block(bwt, lf)
+    assert back.size == size and (back == d).all()
+
+
 @pytest.mark.skipif(os.environ.get("BWTC_TEST_1GIB") != "1", reason="set BWTC_TEST_1GIB=1 (takes minutes)")
 def test_baseline_1GiB_single_block(oracle):
     """BASELINE.json config 5: one 1 GiB block, 32-bit indices, N = 2^30 + 1."""
