@@ -94,3 +94,15 @@ def test_cli_roundtrip_full_size_block_default_coder(tmp_path):
     assert r.returncode == 0, r.stderr
     back = np.fromfile(out, np.uint8)
     assert back.size == data.size and (back == data).all()
+    # three blocks (two full, one partial) overlapped by the Compressor loop, model state carried
+    # across the block borders, decoded by one decoder object
+    for f in (src, dst, out):
+        f.unlink()
+    data = np.concatenate([data, synth.gen_text(300 << 20, 31)])
+    src.write_bytes(data.tobytes())
+    r = subprocess.run([exe, "-m", "1452", "-s", "8", str(src), str(dst)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([unexe, str(dst), str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    back = np.fromfile(out, np.uint8)
+    assert back.size == data.size and (back == data).all()
