@@ -108,7 +108,7 @@ def main():
     d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev)
     h_comp = np.empty(ctx.compress_bound(size), np.uint8)      # the 'B' coder runs on host threads
     cores = usable_cpus()
-    threads = max(1, min(64, cores // max(world, 1) - 1))   # one CPU per rank feeds the GPU
+    threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits
     torch.cuda.synchronize()
     comp = [0]
 

@@ -299,8 +299,9 @@ static unsigned usable_cpus() {
 
 static unsigned pick_threads(uint32_t threads) {
   if (threads) return threads;
-  const unsigned n = usable_cpus();
-  return n > 1 ? std::min(n - 1, 64u) : 1;   // one is left to the thread that feeds the GPU
+  // all of them: the thread that feeds the GPU sleeps while it waits (BwtEngine::wait), and what
+  // it computes between waits is a tenth of a CPU
+  return std::min(usable_cpus(), 64u);
 }
 
 int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {

@@ -175,7 +175,7 @@ int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint
  * the device work of the block (run scanner, tree bit vectors, traversal order, gap flags),
  * advances the encoder's carried model state and queues the block's adaptive models and range
  * coders on the context's worker threads (created by the first call, `threads` of them, 0 =
- * all cores up to 64); it returns as soon as the GPU is free for the next block.  _end waits
+ * the CPUs the process may use -- affinity and cgroup quota -- up to 64); it returns as soon as the GPU is free for the next block.  _end waits
  * for that block; the record is then in the `out` given to _begin, *out_bytes long.  Records
  * are those of a strictly sequential encoder whatever the overlap.  At most
  * BWTC_HIP_WAVELET_DEPTH (default 12) blocks are under way; a further _begin waits for the

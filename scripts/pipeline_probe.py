@@ -29,7 +29,7 @@ for i in range(steps):
         w = time.perf_counter() - b
     c = time.perf_counter()
     ctx.wavelet_reset()
-    pend.append(ctx.wavelet_encode_device_begin(d_out.data_ptr(), n, lf, fr, ring[i % depth], 0))
+    pend.append(ctx.wavelet_encode_device_begin(d_out.data_ptr(), n, lf, fr, ring[i % depth], int(os.environ.get("PROBE_THREADS", "0"))))
     d = time.perf_counter()
     print("step %2d: bwt %.1f ms (device %.1f), wait oldest %.1f ms, begin %.1f ms" % (i, 1e3 * (b - a), ctx.stats().ms_total, 1e3 * w, 1e3 * (d - c)), flush=True)
 while pend:
