@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 template <typename K>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
-    u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_are_positions) {
+    u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode) {
   constexpr int E = RadixCfg<K>::E;
   constexpr int TILE = kRadixTPB * E;
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
@@ -111,8 +111,9 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     u32 slot = wslot + e * kWave;
     bool ok = slot < tile_n;
     k[e] = ok ? kin[tile_base + slot] : (K)0;
-    // first pass of a sort whose values are the items' own positions: nothing to read
-    v[e] = !ok ? 0u : values_are_positions ? (u32)(tile_base + slot) : vin[tile_base + slot];
+    // values_mode 1: first pass of a sort whose values are the items' own positions, nothing to
+    // read; 2: keys only
+    v[e] = (!ok || values_mode == 2) ? 0u : values_mode == 1 ? (u32)(tile_base + slot) : vin[tile_base + slot];
   }
   __syncthreads();
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (int e = 0; e < E; ++e) {
     if ((wslot + e * kWave) < tile_n) {
       s_key[r[e]] = k[e];
-      s_val[r[e]] = v[e];
+      if (values_mode != 2) s_val[r[e]] = v[e];
     }
   }
   __syncthreads();
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
     // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
     kout[dst] = kk;
-    vout[dst] = s_val[i];
+    if (values_mode != 2) vout[dst] = s_val[i];
   }
 }
 
@@ -219,12 +220,13 @@ struct ScatterProbe {
 
 // Sorts n pairs by key bits [bit_lo, nbits) (stable, so lower bits keep their order).  Buffers ping-pong; on return *k_sorted/*v_sorted
 // point at whichever of (k0,v0)/(k1,v1) holds the result.  values_are_positions: v0 need not be
-// filled, item i's value is i (the first pass makes them up instead of reading them).
+// filled, item i's value is i (the first pass makes them up instead of reading them).  keys_only:
+// v0/v1 are not touched at all.
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
                                     K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
-                                    int bit_lo = 0, bool values_are_positions = false) {
+                                    int bit_lo = 0, bool values_are_positions = false, bool keys_only = false) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1) {
@@ -236,8 +238,8 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       const bool timed = probe && probe->begin(st);
       hipLaunchKernelGGL(k_radix_scatter<K>, dim3(((ntiles + 7u) / 8u) * 8u), dim3(kRadixTPB), 0,
                          st, kin, vin, kout, vout, table, n, shift, ntiles,
-                         (values_are_positions && shift == bit_lo) ? 1 : 0);
-      if (timed) probe->end(st, n * 2 * (sizeof(K) + sizeof(u32)));
+                         keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0);
+      if (timed) probe->end(st, n * 2 * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
       K* tk = kin; kin = kout; kout = tk;
       u32* tv = vin; vin = vout; vout = tv;
     }

@@ -784,6 +784,7 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   plan->sections.assign(nsec, StreamPlan::Section());
   plan->group_type.clear();
   plan->symtab.assign(nsec * 512, 0);
+  plan->symcode.assign(nsec * 256, 0);
   plan->lendense.assign(nsec * 2 * static_cast<size_t>(kLenDense), 0);
   plan->over_first.assign(nsec + 1, 0);
   plan->over.clear();
@@ -864,6 +865,10 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
     // steps of every symbol: the visited nodes on its path
     for (uint32_t c = 0; c < 256; ++c) {
       if (tree.codes[c].empty()) continue;
+      if (tree.codes[c].size() > 64) return false;
+      uint64_t packed = 0;
+      for (size_t i = 0; i < tree.codes[c].size(); ++i) packed |= static_cast<uint64_t>(tree.codes[c][i]) << (63 - i);
+      plan->symcode[s * 256 + c] = packed;
       const uint32_t off = static_cast<uint32_t>(plan->pool.size());
       int nd = tree.root;
       for (size_t i = 0; i < tree.codes[c].size(); ++i) {
@@ -1026,15 +1031,19 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
 bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>& sections,
                          std::vector<uint32_t>* coded_pos, std::vector<uint8_t>* codes) {
   const size_t nsec = sections.size();
+  const uint32_t groupMask = kMaxGroups - 1;
   std::vector<uint32_t> key;                                         // expand
   std::vector<uint32_t> runOff, runSymSteps;
   for (size_t s = 0; s < nsec; ++s) {
     for (uint64_t r = 0; r < sections[s].n_runs; ++r) {
       const uint32_t c = sections[s].symbols[r], len = sections[s].starts[r + 1] - sections[s].starts[r];
       const uint32_t off = plan.symtab[(s * 256 + c) * 2], meta = plan.symtab[(s * 256 + c) * 2 + 1];
+      // gap flag of a symbol step: deeper than the common prefix with the previous run's code
+      uint32_t common = 0;
+      if (r > 0) common = static_cast<uint32_t>(__builtin_clzll(plan.symcode[s * 256 + c] ^ plan.symcode[s * 256 + sections[s].symbols[r - 1]]));
       runOff.push_back(static_cast<uint32_t>(key.size()));
       runSymSteps.push_back(meta & 255u);
-      for (uint32_t i = 0; i < (meta & 255u); ++i) key.push_back(plan.pool[off + i]);
+      for (uint32_t i = 0; i < (meta & 255u); ++i) key.push_back(plan.pool[off + i] | ((i > common ? 1u : 0u) << kStepGapShift));
       if (!(meta >> 16)) continue;
       uint32_t loff = 0, lsteps = 0;
       if (len < kLenDense) {
@@ -1050,32 +1059,42 @@ bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>&
   const size_t n = key.size();
   std::vector<uint32_t> order(n);                                    // sort
   for (size_t i = 0; i < n; ++i) order[i] = static_cast<uint32_t>(i);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (key[a] >> 1) < (key[b] >> 1); });
+  auto sortKey = [&](uint32_t i) { return key[i] >> kStepLeafShift; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sortKey(a) < sortKey(b); });
   const size_t groups = plan.group_type.size();
-  std::vector<uint8_t> flag(n, 0);                                   // gaps
+  auto groupOf = [&](size_t j) { return (key[order[j]] >> kStepGroupShift) & groupMask; };
+  // The gap flags once more the way the reference derives them -- changed = the bit differs from
+  // the previous bit of the node, OR-ed down each run -- as a check of the prefix rule above.
+  {
+    std::vector<uint8_t> flag(n, 0);
+    for (size_t j = 0; j < n; ++j) {
+      const uint32_t g = groupOf(j);
+      if (plan.group_type[g] == kInteger) continue;
+      const bool first = j == 0 || groupOf(j - 1) != g;
+      flag[order[j]] = first || ((key[order[j]] ^ key[order[j - 1]]) & 1u);
+    }
+    for (size_t r = 0; r < runOff.size(); ++r) {
+      uint8_t g = 0;
+      for (uint32_t i = 0; i < runSymSteps[r]; ++i) {
+        const size_t at = runOff[r] + i;
+        if (g != ((key[at] >> kStepGapShift) & 1u)) return false;
+        g |= flag[at];
+      }
+    }
+  }
   std::vector<uint32_t> groupStart(groups + 1, 0xFFFFFFFFu);
-  for (size_t j = 0; j < n; ++j) {
-    const uint32_t k = key[order[j]], g = k >> kStepGroupShift;
-    const bool first = j == 0 || (key[order[j - 1]] >> kStepGroupShift) != g;
-    if (first) groupStart[g] = static_cast<uint32_t>(j);
-    if (plan.group_type[g] != kInteger) flag[order[j]] = first || ((k ^ key[order[j - 1]]) & 1u);
-  }
-  for (size_t r = 0; r < runOff.size(); ++r) {
-    uint8_t g = 0;
-    for (uint32_t i = 0; i < runSymSteps[r]; ++i) { const uint8_t c = flag[runOff[r] + i]; flag[runOff[r] + i] = g; g |= c; }
-  }
   coded_pos->assign(groups + 1, 0);                                   // select + pack
   codes->clear();
   uint64_t coded = 0;
   for (size_t j = 0; j < n; ++j) {
-    const uint32_t k = key[order[j]], g = k >> kStepGroupShift, bit = k & 1u;
-    const bool first = j == 0 || (key[order[j - 1]] >> kStepGroupShift) != g;
-    if (first) (*coded_pos)[g] = static_cast<uint32_t>(coded);
+    const uint32_t k = key[order[j]], g = groupOf(j), bit = k & 1u;
+    const bool first = j == 0 || groupOf(j - 1) != g;
+    if (first) { groupStart[g] = static_cast<uint32_t>(j); (*coded_pos)[g] = static_cast<uint32_t>(coded); }
     const uint8_t type = plan.group_type[g];
     uint32_t gap = 0;
     bool keep = true;
     if (type != kRoot && type != kInteger) {
-      gap = flag[order[j]];
+      gap = (k >> kStepGapShift) & 1u;
       const uint32_t prev = first ? (bit ^ 1u) : (key[order[j - 1]] & 1u);
       if (type == kBothLeaves) keep = gap != 0;
       else if (type == kLeftLeaf) keep = (prev | gap) != 0;

@@ -50,13 +50,14 @@ inline bool isWaveletModel(char c) { return c == 'B' || c == 'b' || c == 'u'; }
 // the nodes are coded in the breadth-first order of encodeTreeBF (WaveletTree.hpp:637-809),
 // the integer subtrees level by level after the symbol tree.  planStreams() numbers those
 // places ("groups") and emits lookup tables from which the GPU (wavelet_tree.hip) expands every
-// run into (group, bit) steps, sorts them into coding order, derives the gap flags and drops
-// the bits encodeTreeBF skips.  codeStreams() then only runs the adaptive models and the range
+// run into (group, bit, gap flag) steps, sorts them into coding order and drops the bits
+// encodeTreeBF skips.  codeStreams() then only runs the adaptive models and the range
 // coder over the finished streams.
 constexpr uint32_t kStepBitShift = 0;      // step word: bit 0 = the bit,
-constexpr uint32_t kStepLeafShift = 1;     //   bits 1..8 = rank of the symbol leaf (integer steps),
-constexpr uint32_t kStepGroupShift = 9;    //   bits 9..  = group number (block-wide)
-constexpr uint32_t kMaxGroups = 1u << 23;
+constexpr uint32_t kStepGapShift = 1;      //   bit 1 = gap flag (symbol-tree steps); bits 0-1 are below the sort key
+constexpr uint32_t kStepLeafShift = 2;     //   bits 2..9 = rank of the symbol leaf (integer steps),
+constexpr uint32_t kStepGroupShift = 10;   //   bits 10..31 = group number (block-wide)
+constexpr uint32_t kMaxGroups = 1u << 22;
 constexpr uint32_t kLenDense = 4096;       // run lengths below this are looked up in a dense table
 
 enum GroupType { kRoot = 0, kBothLeaves = 1, kLeftLeaf = 2, kInner = 3, kInteger = 4 };
@@ -72,6 +73,8 @@ struct StreamPlan {
   std::vector<uint8_t> group_type;         // per block-wide group
   // device tables
   std::vector<uint32_t> symtab;            // [section][256] x {pool offset, steps | leaf rank << 8 | live << 16}
+  std::vector<uint64_t> symcode;           // [section][256] the symbol's code, first bit in bit 63 (gap flags:
+                                           //   common prefix of consecutive runs' codes, see wavelet_tree.hip)
   std::vector<uint32_t> lendense;          // [section][kLenDense] x {pool offset, steps}
   std::vector<uint32_t> over_first;        // [section + 1] ranges into `over`
   std::vector<uint32_t> over;              // x {length, pool offset, steps, 0}, ascending by length
@@ -79,8 +82,9 @@ struct StreamPlan {
   uint64_t max_elements;                   // upper bound of the number of steps of the block
 };
 
-// false: the shapes need something the device path does not do (too many groups, a length code
-// that is a prefix of another); the caller then uses encodeSections().
+// false: the shapes need something the device path does not do (too many groups, a symbol code
+// longer than 64 bits, a length code that is a prefix of another); the caller then uses
+// encodeSections().
 bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan);
 
 // The coder over finished streams.  coded_pos[g] = index of group g's first coded element in
@@ -125,8 +129,9 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
                  unsigned threads, uint32_t* fsm8_state, std::vector<SectionOutput>* out,
                  std::vector<uint16_t>* scratch = nullptr, char model = 'B');
 
-// What wavelet_tree.hip computes, stated with plain host loops (expand, stable sort, gap flags,
-// select, pack).  Only the host-only test hook bwtc_hip_host_wavelet_streams calls it, so that
+// What wavelet_tree.hip computes, stated with plain host loops (expand with gap flags, stable
+// sort, select, pack); it also derives the gap flags the reference's way and fails when the two
+// disagree.  Only the host-only test hook bwtc_hip_host_wavelet_streams calls it, so that
 // planStreams/codeStreams can be checked where there is no GPU; false = the plan's tables do
 // not cover a run of the input.
 bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>& sections,

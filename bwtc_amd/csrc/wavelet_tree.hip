@@ -5,18 +5,23 @@
 // The host numbers every coded place of the block ("group": a visited node of a section's
 // symbol tree, or one node position of an integer level; wavelet_host.cpp planStreams) and
 // hands over lookup tables.  Then
-//   expand    every run -> its steps (group, leaf rank, bit): the code of its symbol along
-//             the symbol tree, then the code of its length below the symbol's leaf
-//   sort      stable LSD radix sort of the steps by (group, leaf rank): the bits of every
-//             node, in run order, nodes in coding order (radix_sort.hpp, the suffix sorter's
-//             passes)
-//   gaps      a step is "changed" when its bit differs from the previous bit of its node; the
-//             gap flag of a step is the OR of the changed flags of the run's steps above it
-//             (WaveletTree.hpp:672-676, :735-741, :771-777) -- scattered back to run order,
-//             OR-ed down each run, gathered again
-//   select    encodeTreeBF codes every bit of some nodes and only part of others (:716-787);
-//             the survivors are compacted to 2 bits each (bit, gap flag) for the host's models
-//             and range coder
+//   expand    every run -> its steps (group, leaf rank, bit, gap flag): the code of its symbol
+//             along the symbol tree, then the code of its length below the symbol's leaf.
+//             The reference derives a step's gap flag from gap vectors handed down the tree
+//             (WaveletTree.hpp:672-676, :735-741, :771-777): it is the OR, over the nodes above
+//             the step on the run's path, of "this run's bit differs from the bit of the previous
+//             run through that node".  Above the point where the codes of this run's and the
+//             previous run's symbols part, the previous run through every node is the previous
+//             run itself, with the same bit; at the parting node the bits differ; so the flag
+//             is simply  depth > common prefix of the two codes  (0 for a section's first run,
+//             whose every node sees it first), and is written into the step word here, below
+//             the bits the sort looks at.
+//   sort      stable LSD radix sort of the step words by (group, leaf rank), keys only: the bits
+//             of every node, in run order, nodes in coding order (radix_sort.hpp, the suffix
+//             sorter's passes)
+//   select    encodeTreeBF codes every bit of some nodes and only part of others (:716-787,
+//             "previous bit of the node" is the neighbour in sorted order); the survivors are
+//             compacted to 2 bits each (bit, gap flag) for the host's models and range coder
 // Everything is HBM-streaming integer work; the sort dominates.
 #include "bwt_engine.hpp"
 #include "radix_sort.hpp"
@@ -30,6 +35,8 @@ namespace bwtc_hip {
 
 using bwtc::wavelet::kStepGroupShift;
 using bwtc::wavelet::kStepLeafShift;
+using bwtc::wavelet::kStepGapShift;
+constexpr u32 kStepGroupMask = bwtc::wavelet::kMaxGroups - 1;
 constexpr u32 kWtLenDense = bwtc::wavelet::kLenDense;
 
 constexpr int kWtTPB = 256;
@@ -40,6 +47,7 @@ struct WtTables {
   const u32* first_run;     // [nsec + 1]
   u32 nsec;
   const uint2* symtab;      // [nsec][256]
+  const u64* symcode;       // [nsec][256] codes, first bit in bit 63
   const uint2* lendense;    // [nsec][kWtLenDense]
   const u32* over_first;    // [nsec + 1]
   const uint4* over;
@@ -87,10 +95,14 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   const u32 r = blockIdx.x * kWtTPB + threadIdx.x;
   if (r >= n_runs) return;
   const u32 s = wt_section_of(s_first, t.nsec, r);
-  const uint2 sy = t.symtab[s * 256u + run_sym[r]];
+  const u32 c = run_sym[r];
+  const uint2 sy = t.symtab[s * 256u + c];
+  // steps at depth > (common prefix with the previous run's code) carry the gap flag
+  u32 common = 0;
+  if (r > s_first[s]) common = (u32)__clzll(t.symcode[s * 256u + c] ^ t.symcode[s * 256u + run_sym[r - 1]]);
   u32 o = off[r];
   const u32 ns = sy.y & 255u;
-  for (u32 i = 0; i < ns; ++i, ++o) key[o] = t.pool[sy.x + i];
+  for (u32 i = 0; i < ns; ++i, ++o) key[o] = t.pool[sy.x + i] | ((i > common ? 1u : 0u) << kStepGapShift);
   if (sy.y >> 16) {
     const uint2 le = wt_length_entry(t, s, run_start[r + 1] - run_start[r]);
     const u32 leaf = ((sy.y >> 8) & 255u) << kStepLeafShift;
@@ -98,50 +110,15 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   }
 }
 
-// sorted order: first element of every group, and the changed flag of the symbol-tree steps
-// scattered back to run order
-__global__ __launch_bounds__(kWtTPB) void k_wt_changed(const u32* __restrict__ key,
-                                                       const u32* __restrict__ val, u32 n,
-                                                       const u8* __restrict__ group_type,
-                                                       u32* __restrict__ group_start,
-                                                       u8* __restrict__ flag) {
-  const u32 j = blockIdx.x * kWtTPB + threadIdx.x;
-  if (j >= n) return;
-  const u32 k = key[j];
-  const u32 kp = j ? key[j - 1] : ~k;
-  const u32 g = k >> kStepGroupShift;
-  if (j == 0 || (kp >> kStepGroupShift) != g) group_start[g] = j;
-  if (group_type[g] == bwtc::wavelet::kInteger) return;
-  const bool first = j == 0 || (kp >> kStepGroupShift) != g;
-  flag[val[j]] = (first || ((k ^ kp) & 1u)) ? 1 : 0;
-}
-
-// run order: flag[step] = OR of the changed flags of the run's steps above it
-__global__ __launch_bounds__(kWtTPB) void k_wt_gap_flags(const u8* __restrict__ run_sym, u32 n_runs,
-                                                         WtTables t, const u32* __restrict__ off,
-                                                         u8* __restrict__ flag) {
-  __shared__ u32 s_first[257];
-  for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
-  __syncthreads();
-  const u32 r = blockIdx.x * kWtTPB + threadIdx.x;
-  if (r >= n_runs) return;
-  const u32 s = wt_section_of(s_first, t.nsec, r);
-  const u32 ns = t.symtab[s * 256u + run_sym[r]].y & 255u;
-  u32 o = off[r];
-  u8 g = 0;
-  for (u32 i = 0; i < ns; ++i, ++o) { const u8 c = flag[o]; flag[o] = g; g |= c; }
-}
-
 constexpr u8 kWtSkip = 0xFF;
 
 // sorted order: what encodeTreeBF does with the bit -> code[j] = bit | gap << 1, or kWtSkip;
-// coded elements per tile -> tile_count
-__global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ key,
-                                                      const u32* __restrict__ val, u32 n,
+// coded elements per tile -> tile_count; first element of every group -> group_start
+__global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ key, u32 n,
                                                       const u8* __restrict__ group_type,
-                                                      const u8* __restrict__ flag,
                                                       u8* __restrict__ code,
-                                                      u32* __restrict__ tile_count) {
+                                                      u32* __restrict__ tile_count,
+                                                      u32* __restrict__ group_start) {
   __shared__ u32 scratch[kWtTPB / kWave + 1];
   const u32 base = blockIdx.x * kWtTile;
   u32 coded = 0;
@@ -149,16 +126,17 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
     const u32 j = base + e * kWtTPB + threadIdx.x;
     if (j >= n) break;
     const u32 k = key[j];
-    const u32 kp = j ? key[j - 1] : ~k;
-    const u32 g = k >> kStepGroupShift;
+    const u32 g = (k >> kStepGroupShift) & kStepGroupMask;
+    const u32 kp = j ? key[j - 1] : 0u;
+    const bool first = j == 0 || ((kp >> kStepGroupShift) & kStepGroupMask) != g;
+    if (first) group_start[g] = j;
     const u32 bit = k & 1u;
     const u8 type = group_type[g];
     u8 c;
     if (type == bwtc::wavelet::kRoot || type == bwtc::wavelet::kInteger) {
       c = (u8)bit;
     } else {
-      const u32 gap = flag[val[j]];
-      const bool first = j == 0 || (kp >> kStepGroupShift) != g;
+      const u32 gap = (k >> kStepGapShift) & 1u;
       const u32 prev = first ? (bit ^ 1u) : (kp & 1u);
       bool keep = true;
       if (type == bwtc::wavelet::kBothLeaves) keep = gap != 0;
@@ -272,6 +250,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   auto take = [&](u64 bytes) { const u64 o = at; at = align_up(at + bytes, 256); return o; };
   const u64 o_first = take((nsec + 1) * 4ull);
   const u64 o_symtab = take(plan.symtab.size() * 4ull);
+  const u64 o_symcode = take(plan.symcode.size() * 8ull);
   const u64 o_lendense = take(plan.lendense.size() * 4ull);
   const u64 o_overfirst = take(plan.over_first.size() * 4ull);
   const u64 o_over = take(plan.over.size() * 4ull + 16);
@@ -283,11 +262,9 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   const u64 o_cnt = take(((u64)n_runs + 1) * 4);
   const u64 o_cnt_partial = take(((u64)ceil_div((u64)n_runs + 1, kScanTile) + 1) * 4);
   const u64 o_k0 = take(cap * 4 + 64), o_k1 = take(cap * 4 + 64);
-  const u64 o_v0 = take(cap * 4 + 64), o_v1 = take(cap * 4 + 64);
   const u64 table_words = (u64)ceil_div(cap, radix_tile<u32>()) * kRadixBins + kRadixBins;
   const u64 o_table = take(table_words * 4);
   const u64 o_partial = take(((u64)ceil_div(table_words, kScanTile) + 1) * 4);
-  const u64 o_flag = take(cap + 64);
   const u64 o_code = take(cap + 64);
   const u64 o_compact = take(cap + 64);
   const u64 o_packed = take(cap / 4 + 64);
@@ -304,6 +281,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
     u8* h = e.h_wt;
     std::memcpy(h + o_first, first_run.data(), (nsec + 1) * 4ull);
     std::memcpy(h + o_symtab, plan.symtab.data(), plan.symtab.size() * 4ull);
+    std::memcpy(h + o_symcode, plan.symcode.data(), plan.symcode.size() * 8ull);
     std::memcpy(h + o_lendense, plan.lendense.data(), plan.lendense.size() * 4ull);
     std::memcpy(h + o_overfirst, plan.over_first.data(), plan.over_first.size() * 4ull);
     if (!plan.over.empty()) std::memcpy(h + o_over, plan.over.data(), plan.over.size() * 4ull);
@@ -315,6 +293,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   t.first_run = ptr32(o_first);
   t.nsec = nsec;
   t.symtab = reinterpret_cast<const uint2*>(base + o_symtab);
+  t.symcode = reinterpret_cast<const u64*>(base + o_symcode);
   t.lendense = reinterpret_cast<const uint2*>(base + o_lendense);
   t.over_first = ptr32(o_overfirst);
   t.over = reinterpret_cast<const uint4*>(base + o_over);
@@ -334,25 +313,17 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   if (n == 0 || (u64)n > cap) return -3;
   hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_start,
                      d_run_sym, n_runs, t, d_cnt, ptr32(o_k0));
-  // sort by (group, leaf rank); bit 0 rides along; the payload is the step's place in run order
-  if (n == 1) BWTC_HIP_TRY(hipMemsetAsync(ptr32(o_v0), 0, 4, st));    // a lone step is not sorted: its place is 0
+  // sort by (group, leaf rank), keys only; the bit and the gap flag ride along in the word
   u32* ks = nullptr; u32* vs = nullptr;
-  radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), ptr32(o_v0), ptr32(o_v1), n, key_bits,
-                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, true);
-  // gaps
-  u8* d_flag = base + o_flag;
+  radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), nullptr, nullptr, n, key_bits,
+                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, false, true);
+  // select + compact + pack
   u32* d_gstart = ptr32(o_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_gstart, 0xFF, (n_groups + 1) * 4ull, st));
-  hipLaunchKernelGGL(k_wt_changed, dim3(ceil_div(n, kWtTPB)), dim3(kWtTPB), 0, st, ks, vs, n,
-                     d_gtype, d_gstart, d_flag);
-  hipLaunchKernelGGL(k_wt_gap_flags, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_sym,
-                     n_runs, t, d_cnt, d_flag);
-  // select + compact + pack
   const u32 tiles = ceil_div(n, kWtTile);
   u8* d_code = base + o_code;
   u32* d_tile = ptr32(o_tile);
-  hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, vs, n, d_gtype, d_flag,
-                     d_code, d_tile);
+  hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_code, d_tile, d_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_tile + tiles, 0, 4, st));
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
   hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB)), dim3(kWtTPB), 0, st, d_gstart,
