@@ -120,9 +120,9 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       std::memcpy(job.codes.data(), codes, (e.wt_coded + 3) / 4);
       job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state,
                                                       e.wavelet_model));
-      e.wavelet_state = job.coder->endState();
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(job.coder->elements() + 8)) return -2;
+      e.wavelet_state = job.coder->endState();        // nothing can fail from here on: the stream moves on
       job.outs.assign(nsec, bwtc::wavelet::SectionOutput());
       job.t_queued = std::chrono::steady_clock::now();
       job.models_left = job.coder->modelTasks();
