@@ -106,3 +106,22 @@ def test_cli_roundtrip_full_size_block_default_coder(tmp_path):
     assert r.returncode == 0, r.stderr
     back = np.fromfile(out, np.uint8)
     assert back.size == data.size and (back == data).all()
+
+
+def test_cli_roundtrip_1GiB_single_block_default_coder(tmp_path):
+    """The largest block the format carries (1 GiB, N = 2^30 + 1) through the default coder:
+    2.2 billion steps in the stream kernels, one serial decoder pass, GPU inverse transform."""
+    exe = os.path.join(ROOT, "bwtc_amd", "host", "compress")
+    unexe = os.path.join(ROOT, "bwtc_amd", "host", "uncompress")
+    data = synth.gen_text(1 << 30, 5)
+    src = tmp_path / "t1g.bin"
+    dst = tmp_path / "t1g.bwtc"
+    out = tmp_path / "t1g.out"
+    data.tofile(src)
+    r = subprocess.run([exe, "-m", "5806", "-v", "1", str(src), str(dst)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert "outside the stream kernels" not in r.stderr          # the device route took it
+    r = subprocess.run([unexe, str(dst), str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    back = np.fromfile(out, np.uint8)
+    assert back.size == data.size and (back == data).all()
