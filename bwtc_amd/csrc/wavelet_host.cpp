@@ -779,8 +779,142 @@ void modelGroup(char model, const uint8_t* codes, uint64_t b, uint64_t e, uint32
 
 }  // namespace
 
+namespace {
+
+// One section's share of the plan with group numbers and pool offsets local to the section;
+// sections are planned in parallel and then laid end to end.
+struct SectionPlan {
+  bool ok;
+  std::vector<uint8_t> prefix;
+  uint32_t n_nodes, n_groups;
+  std::vector<uint32_t> level_first;
+  std::vector<uint8_t> types;
+  std::vector<uint32_t> pool;
+  uint32_t symtab[512];
+  uint64_t symcode[256];
+  struct Length { uint32_t len, off, steps; };
+  std::vector<Length> lengths;
+  uint64_t max_elements;
+  SectionPlan() : ok(true), n_nodes(0), n_groups(0), max_elements(0) {
+    std::memset(symtab, 0, sizeof symtab);
+    std::memset(symcode, 0, sizeof symcode);
+  }
+};
+
+void planSection(const SectionRuns& in, SectionPlan* sec) {
+  if (in.n_runs == 0) { sec->level_first.assign(1, 0); return; }
+  Tree tree;
+  tree.buildCodes(in);
+  utils::packInteger(in.n_runs, sec->prefix);                        // bitsInRoot: one bit per run
+  tree.shape(sec->prefix);
+
+  // the nodes encodeTreeBF visits, in its order, and the order the symbol leaves are met in
+  std::vector<int> groupOf(tree.nodes.size(), -1);
+  std::vector<int> leafRank(tree.nodes.size(), -1);
+  std::vector<uint8_t>& types = sec->types;
+  int leaves = 0;
+  {
+    std::deque<int> queue;
+    const Node& r = tree.nodes[tree.root];
+    groupOf[tree.root] = 0; types.push_back(kRoot);
+    if (r.left >= 0) { if (tree.nodes[r.left].hasSymbol) leafRank[r.left] = leaves++; else queue.push_back(r.left); }
+    if (r.right >= 0) { if (tree.nodes[r.right].hasSymbol) leafRank[r.right] = leaves++; else queue.push_back(r.right); }
+    while (!queue.empty()) {
+      const int id = queue.front();
+      queue.pop_front();
+      const Node& nd = tree.nodes[id];
+      if (nd.left < 0 || nd.right < 0) { sec->ok = false; return; }   // the reference would read out of bounds
+      const bool leftSym = tree.nodes[nd.left].hasSymbol, rightSym = tree.nodes[nd.right].hasSymbol;
+      if (leftSym && rightSym) {
+        groupOf[id] = static_cast<int>(types.size()); types.push_back(kBothLeaves);
+        leafRank[nd.left] = leaves++; leafRank[nd.right] = leaves++;
+      } else if (leftSym) {
+        groupOf[id] = static_cast<int>(types.size()); types.push_back(kLeftLeaf);
+        queue.push_back(nd.right);
+        leafRank[nd.left] = leaves++;
+      } else if (!rightSym) {
+        groupOf[id] = static_cast<int>(types.size()); types.push_back(kInner);
+        queue.push_back(nd.left); queue.push_back(nd.right);
+      }                                                              // right leaf only: dropped with its subtree (sic)
+    }
+  }
+  if (leaves > 256) { sec->ok = false; return; }
+  sec->n_nodes = static_cast<uint32_t>(types.size());
+
+  // the integer levels: union trie of the section's length codes
+  LengthTrie trie;
+  std::vector<Bits> lengthCodes(in.n_dist);
+  for (size_t i = 0; i < in.n_dist; ++i) {
+    lengthCodes[i] = tree.lengthCodeOf(in.dist[i].first);
+    if (lengthCodes[i].empty() || !trie.insert(lengthCodes[i])) { sec->ok = false; return; }
+  }
+  uint32_t nextGroup = sec->n_nodes;
+  {
+    std::vector<int> level(1, 0), lefts, rights;                     // next level = all lefts, then all rights
+    while (!level.empty()) {
+      sec->level_first.push_back(nextGroup);
+      lefts.clear(); rights.clear();
+      for (size_t i = 0; i < level.size(); ++i) {
+        LengthTrie::N& t = trie.n[level[i]];
+        t.group = nextGroup++;
+        if (t.child[0] >= 0 && !trie.n[t.child[0]].terminal) lefts.push_back(t.child[0]);
+        if (t.child[1] >= 0 && !trie.n[t.child[1]].terminal) rights.push_back(t.child[1]);
+      }
+      level = lefts;
+      level.insert(level.end(), rights.begin(), rights.end());
+    }
+    sec->level_first.push_back(nextGroup);
+  }
+  sec->n_groups = nextGroup;
+  types.resize(nextGroup, static_cast<uint8_t>(kInteger));
+
+  // steps of every symbol: the visited nodes on its path
+  for (uint32_t c = 0; c < 256; ++c) {
+    if (tree.codes[c].empty()) continue;
+    if (tree.codes[c].size() > 64) { sec->ok = false; return; }
+    uint64_t packed = 0;
+    for (size_t i = 0; i < tree.codes[c].size(); ++i) packed |= static_cast<uint64_t>(tree.codes[c][i]) << (63 - i);
+    sec->symcode[c] = packed;
+    const uint32_t off = static_cast<uint32_t>(sec->pool.size());
+    int nd = tree.root;
+    for (size_t i = 0; i < tree.codes[c].size(); ++i) {
+      const uint32_t bit = tree.codes[c][i];
+      if (groupOf[nd] >= 0) sec->pool.push_back((static_cast<uint32_t>(groupOf[nd]) << kStepGroupShift) | bit);
+      nd = bit ? tree.nodes[nd].right : tree.nodes[nd].left;
+    }
+    const uint32_t steps = static_cast<uint32_t>(sec->pool.size()) - off;
+    const bool live = leafRank[nd] >= 0;
+    sec->symtab[c * 2] = off;
+    sec->symtab[c * 2 + 1] = steps | (live ? static_cast<uint32_t>(leafRank[nd]) << 8 : 0u) | (live ? 1u << 16 : 0u);
+    sec->max_elements += static_cast<uint64_t>(steps) * in.run_freqs[c];
+  }
+  // steps of every run length
+  for (size_t i = 0; i < in.n_dist; ++i) {
+    const uint32_t off = static_cast<uint32_t>(sec->pool.size());
+    int nd = 0;
+    for (size_t k = 0; k < lengthCodes[i].size(); ++k) {
+      const uint32_t bit = lengthCodes[i][k];
+      sec->pool.push_back((trie.n[nd].group << kStepGroupShift) | bit);
+      nd = trie.n[nd].child[bit];
+    }
+    const SectionPlan::Length entry = {in.dist[i].first, off, static_cast<uint32_t>(lengthCodes[i].size())};
+    sec->lengths.push_back(entry);                                   // dist is ascending by length
+    sec->max_elements += static_cast<uint64_t>(entry.steps) * in.dist[i].second;
+  }
+}
+
+}  // namespace
+
 bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   const size_t nsec = sections.size();
+  // the sections' codes and shapes are independent (and the semi-fixed-code search is the
+  // expensive part): planned on a few threads, then laid end to end
+  std::vector<SectionPlan> local(nsec);
+  std::vector<uint64_t> weight(nsec);
+  for (size_t s = 0; s < nsec; ++s) weight[s] = sections[s].n_dist;
+  const unsigned hc = std::thread::hardware_concurrency();
+  parallelFor(nsec, std::max(1u, std::min(8u, hc ? hc : 1u)), weight.data(), [&](size_t s) { planSection(sections[s], &local[s]); });
+
   plan->sections.assign(nsec, StreamPlan::Section());
   plan->group_type.clear();
   plan->symtab.assign(nsec * 512, 0);
@@ -791,117 +925,35 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   plan->pool.clear();
   plan->max_elements = 0;
   for (size_t s = 0; s < nsec; ++s) {
-    const SectionRuns& in = sections[s];
+    SectionPlan& in = local[s];
+    if (!in.ok) return false;
     StreamPlan::Section& sec = plan->sections[s];
     sec.group_base = static_cast<uint32_t>(plan->group_type.size());
-    sec.n_nodes = 0;
+    sec.n_nodes = in.n_nodes;
+    sec.prefix.swap(in.prefix);
+    sec.level_first.swap(in.level_first);
     plan->over_first[s] = static_cast<uint32_t>(plan->over.size() / 4);
-    if (in.n_runs == 0) { sec.level_first.assign(1, 0); continue; }
-    Tree tree;
-    tree.buildCodes(in);
-    utils::packInteger(in.n_runs, sec.prefix);                       // bitsInRoot: one bit per run
-    tree.shape(sec.prefix);
-
-    // the nodes encodeTreeBF visits, in its order, and the order the symbol leaves are met in
-    std::vector<int> groupOf(tree.nodes.size(), -1);
-    std::vector<int> leafRank(tree.nodes.size(), -1);
-    std::vector<uint8_t> types;
-    int leaves = 0;
-    {
-      std::deque<int> queue;
-      const Node& r = tree.nodes[tree.root];
-      groupOf[tree.root] = 0; types.push_back(kRoot);
-      if (r.left >= 0) { if (tree.nodes[r.left].hasSymbol) leafRank[r.left] = leaves++; else queue.push_back(r.left); }
-      if (r.right >= 0) { if (tree.nodes[r.right].hasSymbol) leafRank[r.right] = leaves++; else queue.push_back(r.right); }
-      while (!queue.empty()) {
-        const int id = queue.front();
-        queue.pop_front();
-        const Node& nd = tree.nodes[id];
-        if (nd.left < 0 || nd.right < 0) return false;               // the reference would read out of bounds
-        const bool leftSym = tree.nodes[nd.left].hasSymbol, rightSym = tree.nodes[nd.right].hasSymbol;
-        if (leftSym && rightSym) {
-          groupOf[id] = static_cast<int>(types.size()); types.push_back(kBothLeaves);
-          leafRank[nd.left] = leaves++; leafRank[nd.right] = leaves++;
-        } else if (leftSym) {
-          groupOf[id] = static_cast<int>(types.size()); types.push_back(kLeftLeaf);
-          queue.push_back(nd.right);
-          leafRank[nd.left] = leaves++;
-        } else if (!rightSym) {
-          groupOf[id] = static_cast<int>(types.size()); types.push_back(kInner);
-          queue.push_back(nd.left); queue.push_back(nd.right);
-        }                                                            // right leaf only: dropped with its subtree (sic)
-      }
-    }
-    if (leaves > 256) return false;
-    sec.n_nodes = static_cast<uint32_t>(types.size());
-
-    // the integer levels: union trie of the section's length codes
-    LengthTrie trie;
-    std::vector<Bits> lengthCodes(in.n_dist);
-    for (size_t i = 0; i < in.n_dist; ++i) {
-      lengthCodes[i] = tree.lengthCodeOf(in.dist[i].first);
-      if (lengthCodes[i].empty() || !trie.insert(lengthCodes[i])) return false;
-    }
-    uint32_t nextGroup = sec.n_nodes;
-    {
-      std::vector<int> level(1, 0), lefts, rights;                   // next level = all lefts, then all rights
-      while (!level.empty()) {
-        sec.level_first.push_back(nextGroup);
-        lefts.clear(); rights.clear();
-        for (size_t i = 0; i < level.size(); ++i) {
-          LengthTrie::N& t = trie.n[level[i]];
-          t.group = nextGroup++;
-          if (t.child[0] >= 0 && !trie.n[t.child[0]].terminal) lefts.push_back(t.child[0]);
-          if (t.child[1] >= 0 && !trie.n[t.child[1]].terminal) rights.push_back(t.child[1]);
-        }
-        level = lefts;
-        level.insert(level.end(), rights.begin(), rights.end());
-      }
-      sec.level_first.push_back(nextGroup);
-    }
-    if (static_cast<uint64_t>(sec.group_base) + nextGroup >= kMaxGroups) return false;
-    for (uint32_t g = 0; g < nextGroup; ++g) plan->group_type.push_back(g < sec.n_nodes ? types[g] : static_cast<uint8_t>(kInteger));
-
-    // steps of every symbol: the visited nodes on its path
+    if (static_cast<uint64_t>(sec.group_base) + in.n_groups >= kMaxGroups) return false;
+    plan->group_type.insert(plan->group_type.end(), in.types.begin(), in.types.end());
+    const uint32_t poolBase = static_cast<uint32_t>(plan->pool.size());
+    const uint32_t groupBits = sec.group_base << kStepGroupShift;
+    for (size_t i = 0; i < in.pool.size(); ++i) plan->pool.push_back(in.pool[i] + groupBits);
     for (uint32_t c = 0; c < 256; ++c) {
-      if (tree.codes[c].empty()) continue;
-      if (tree.codes[c].size() > 64) return false;
-      uint64_t packed = 0;
-      for (size_t i = 0; i < tree.codes[c].size(); ++i) packed |= static_cast<uint64_t>(tree.codes[c][i]) << (63 - i);
-      plan->symcode[s * 256 + c] = packed;
-      const uint32_t off = static_cast<uint32_t>(plan->pool.size());
-      int nd = tree.root;
-      for (size_t i = 0; i < tree.codes[c].size(); ++i) {
-        const uint32_t bit = tree.codes[c][i];
-        if (groupOf[nd] >= 0)
-          plan->pool.push_back(((sec.group_base + static_cast<uint32_t>(groupOf[nd])) << kStepGroupShift) | bit);
-        nd = bit ? tree.nodes[nd].right : tree.nodes[nd].left;
-      }
-      const uint32_t steps = static_cast<uint32_t>(plan->pool.size()) - off;
-      const bool live = leafRank[nd] >= 0;
-      plan->symtab[(s * 256 + c) * 2] = off;
-      plan->symtab[(s * 256 + c) * 2 + 1] = steps | (live ? static_cast<uint32_t>(leafRank[nd]) << 8 : 0u) | (live ? 1u << 16 : 0u);
-      plan->max_elements += static_cast<uint64_t>(steps) * in.run_freqs[c];
+      if (!(in.symtab[c * 2 + 1] & 255u)) continue;
+      plan->symtab[(s * 256 + c) * 2] = in.symtab[c * 2] + poolBase;
+      plan->symtab[(s * 256 + c) * 2 + 1] = in.symtab[c * 2 + 1];
+      plan->symcode[s * 256 + c] = in.symcode[c];
     }
-    // steps of every run length
-    for (size_t i = 0; i < in.n_dist; ++i) {
-      const uint32_t len = in.dist[i].first;
-      const uint32_t off = static_cast<uint32_t>(plan->pool.size());
-      int nd = 0;
-      for (size_t k = 0; k < lengthCodes[i].size(); ++k) {
-        const uint32_t bit = lengthCodes[i][k];
-        plan->pool.push_back(((sec.group_base + trie.n[nd].group) << kStepGroupShift) | bit);
-        nd = trie.n[nd].child[bit];
+    for (size_t i = 0; i < in.lengths.size(); ++i) {
+      const SectionPlan::Length& l = in.lengths[i];
+      if (l.len < kLenDense) {
+        plan->lendense[(s * kLenDense + l.len) * 2] = l.off + poolBase;
+        plan->lendense[(s * kLenDense + l.len) * 2 + 1] = l.steps;
+      } else {
+        plan->over.push_back(l.len); plan->over.push_back(l.off + poolBase); plan->over.push_back(l.steps); plan->over.push_back(0);
       }
-      const uint32_t steps = static_cast<uint32_t>(lengthCodes[i].size());
-      if (len < kLenDense) {
-        plan->lendense[(s * kLenDense + len) * 2] = off;
-        plan->lendense[(s * kLenDense + len) * 2 + 1] = steps;
-      } else {                                                       // dist is ascending by length
-        plan->over.push_back(len); plan->over.push_back(off); plan->over.push_back(steps); plan->over.push_back(0);
-      }
-      plan->max_elements += static_cast<uint64_t>(steps) * in.dist[i].second;
     }
+    plan->max_elements += in.max_elements;
   }
   plan->over_first[nsec] = static_cast<uint32_t>(plan->over.size() / 4);
   return true;
