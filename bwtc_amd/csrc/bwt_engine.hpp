@@ -72,7 +72,7 @@ struct BwtEngine {
   std::map<u64, std::shared_ptr<WaveletJob> > jobs;
   u64 next_ticket = 1;
   unsigned max_inflight = 12;          // BWTC_HIP_WAVELET_DEPTH
-  std::vector<std::unique_ptr<RawBuffer<uint8_t> > > codes_free;     // recycled: no fresh pages per block
+  std::vector<std::unique_ptr<PinnedBytes> > codes_free;              // recycled: no fresh pages per block
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
@@ -133,11 +133,11 @@ struct WaveletSectionStats {
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
                                  WaveletSectionStats* out);
 
-// Steps of all runs of the block sorted into coding order, gap flags derived, skipped bits
-// dropped (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
+// Steps of all runs of the block sorted into coding order, skipped bits dropped, the packed
+// streams copied into `codes` (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
 int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           const u8** codes);
+                           PinnedBytes* codes);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
 // 112-157, 159-163) for a device-resident transformed block, in two halves so that blocks

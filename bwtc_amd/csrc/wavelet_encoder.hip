@@ -109,15 +109,10 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
                    (unsigned long long)job.plan.max_elements, job.plan.group_type.size());
     if (on_device) {
       const auto t1 = std::chrono::steady_clock::now();
-      const u8* codes = nullptr;
-      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &codes);
+      if (!e.codes_free.empty()) { job.codes.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
+      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes);
       if (rc) return rc;
       const auto t2 = std::chrono::steady_clock::now();
-      // the streams leave the engine's pinned buffer, the next block will overwrite it
-      const u64 code_bytes = (e.wt_coded + 3) / 4 + 8;
-      if (!e.codes_free.empty()) { job.codes.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-      if (!job.codes.reserve(code_bytes)) return -2;
-      std::memcpy(job.codes.data(), codes, (e.wt_coded + 3) / 4);
       job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state,
                                                       e.wavelet_model));
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
@@ -246,7 +241,7 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
   e.jobs.erase(it);
   // keep the two big buffers: fresh ones would be paged in again for every block
   if (job.codes.size() && e.codes_free.size() < e.max_inflight) {
-    e.codes_free.push_back(std::unique_ptr<RawBuffer<uint8_t> >(new RawBuffer<uint8_t>()));
+    e.codes_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
     e.codes_free.back()->swap(job.codes);
   }
   if (job.prob.size() && e.prob_free.size() < e.max_inflight) {

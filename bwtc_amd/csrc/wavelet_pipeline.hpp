@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -108,6 +109,32 @@ class RawBuffer {
   size_t n_;
 };
 
+// Page-locked host bytes: the packed streams are copied from the device straight into the
+// block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
+class PinnedBytes {
+ public:
+  PinnedBytes() : p_(nullptr), n_(0) {}
+  ~PinnedBytes() { if (p_) (void)hipHostFree(p_); }
+  PinnedBytes(const PinnedBytes&) = delete;
+  PinnedBytes& operator=(const PinnedBytes&) = delete;
+  void swap(PinnedBytes& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); }
+  bool reserve(size_t n) {
+    if (n <= n_) return true;
+    if (p_) (void)hipHostFree(p_);
+    p_ = nullptr; n_ = 0;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) != hipSuccess) return false;
+    p_ = static_cast<uint8_t*>(q);
+    n_ = n + n / 8;
+    return true;
+  }
+  uint8_t* data() { return p_; }
+  size_t size() const { return n_; }
+ private:
+  uint8_t* p_;
+  size_t n_;
+};
+
 struct WaveletJob;
 
 // The groups of all blocks under way, oldest block first and largest group first within a
@@ -147,7 +174,7 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   std::vector<uint8_t> record;                       // header + section sizes, then the sections, finished in place
   bwtc::wavelet::StreamPlan plan;
   std::vector<uint32_t> coded_pos;
-  RawBuffer<uint8_t> codes;                          // packed streams, copied out of the engine's pinned buffer
+  PinnedBytes codes;                                 // packed streams, copied here straight from the device
   RawBuffer<uint16_t> prob;                          // probability of every coded element
   std::unique_ptr<bwtc::wavelet::StreamCoder> coder;
   std::vector<bwtc::wavelet::SectionOutput> outs;

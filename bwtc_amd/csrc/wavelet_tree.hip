@@ -231,11 +231,11 @@ int BwtEngine::reserve_wavelet(u64 device_bytes, u64 host_bytes) {
 }
 
 // Runs of the block are in e.d_R1 (starts) / e.d_R2 (symbols) as wavelet_section_stats_device
-// left them.  On success coded_pos has plan.group_type.size() + 1 entries and *codes points at
-// the packed elements in the engine's pinned buffer (valid until the next call).
+// left them.  On success coded_pos has plan.group_type.size() + 1 entries and `codes` holds the
+// packed elements.
 int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           const u8** codes) {
+                           PinnedBytes* codes) {
   hipStream_t st = e.stream;
   const u32 nsec = (u32)plan.sections.size();
   const u32 n_groups = (u32)plan.group_type.size();
@@ -271,7 +271,7 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   const u64 n_tiles_cap = (u64)ceil_div(cap, kWtTile) + 1;
   const u64 o_tile = take(n_tiles_cap * 4);
   const u64 o_tile_partial = take(((u64)ceil_div(n_tiles_cap, kScanTile) + 1) * 4);
-  int rc = e.reserve_wavelet(at, std::max<u64>(cap / 4 + 64, tables_end));
+  int rc = e.reserve_wavelet(at, tables_end);
   if (rc) return rc;
   u8* base = static_cast<u8*>(e.d_wt);
   auto ptr32 = [&](u64 o) { return reinterpret_cast<u32*>(base + o); };
@@ -337,17 +337,17 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   const u32 n_coded = e.h_small[0];
   if (n_coded > n) return -3;
   const u32 words = ceil_div(n_coded, 16);
+  if (!codes->reserve(words * 4ull + 16)) return -2;
   if (words) {
     hipLaunchKernelGGL(k_wt_pack, dim3(ceil_div(words, kWtTPB)), dim3(kWtTPB), 0, st, d_compact, n_coded,
                        ptr32(o_packed));
-    BWTC_HIP_TRY(hipMemcpyAsync(e.h_wt, base + o_packed, words * 4ull, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(codes->data(), base + o_packed, words * 4ull, hipMemcpyDeviceToHost, st));
   }
   BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   (*coded_pos)[n_groups] = n_coded;
   for (u32 g = n_groups; g-- > 0;)
     if ((*coded_pos)[g] == 0xFFFFFFFFu) (*coded_pos)[g] = (*coded_pos)[g + 1];
-  *codes = e.h_wt;
   e.wt_elements = n;
   e.wt_coded = n_coded;
   return 0;
