@@ -41,15 +41,21 @@ static void finish_wavelet_job(WaveletJob& job) {
 // queue, ahead of newer blocks' work.
 static void submit_sections(const std::shared_ptr<WaveletJob>& jobp, WorkerPool* pool, StageClock* clock) {
   jobp->t_modelled = std::chrono::steady_clock::now();
+  // two tasks per block, each stepping two sections' chains at a time (StreamCoder::
+  // codeSectionsPaired): the pair costs a quarter less host time than two chains run apart, and
+  // with two tasks the block's longest chain is alone again (at its own full speed) as soon as
+  // the other sections are used up
   std::vector<std::function<void()> > next;
-  for (size_t q = 0; q < jobp->coder->sectionTasks(); ++q) {
-    next.push_back([jobp, q, clock] {
+  static const size_t kTasks = [] { const char* v = std::getenv("BWTC_HIP_CODER_TASKS"); return v && std::atoi(v) > 0 ? (size_t)std::atoi(v) : (size_t)2; }();
+  const size_t engines = std::min<size_t>(kTasks, (jobp->coder->sectionTasks() + 1) / 2);
+  for (size_t q = 0; q < std::max<size_t>(engines, 1); ++q) {
+    next.push_back([jobp, clock] {
       WaveletJob& j = *jobp;
       const auto t0 = std::chrono::steady_clock::now();
-      j.coder->codeSection(q, j.prob.data(), &j.outs);
+      const size_t did = j.coder->codeSectionsPaired(&j.section_cursor, j.prob.data(), &j.outs);
       clock->coder_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       bool fin;
-      { std::lock_guard<std::mutex> g(j.mu); fin = --j.sections_left == 0; }
+      { std::lock_guard<std::mutex> g(j.mu); j.sections_left -= did; fin = did > 0 && j.sections_left == 0; }
       if (fin) finish_wavelet_job(j);
     });
   }

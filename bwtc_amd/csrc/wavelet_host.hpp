@@ -10,6 +10,7 @@
 // yields every section's state transition, after which all sections are range-coded in
 // parallel on host threads.
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <utility>
@@ -110,10 +111,14 @@ class StreamCoder {
   uint64_t taskElements(size_t k) const { return tasks_[k].end - tasks_[k].begin; }
   size_t sectionTasks() const { return sections_.size(); }
   void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
+  // the same for sections taken from a shared cursor, two chains at a time in one thread;
+  // returns how many sections this call finished
+  size_t codeSectionsPaired(std::atomic<size_t>* cursor, const uint16_t* prob, std::vector<SectionOutput>* out) const;
 
  private:
   struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };
   uint32_t stateBefore(size_t s, uint32_t group) const;
+  void startSection(size_t k, std::vector<SectionOutput>* out, void* chain) const;
   const StreamPlan& plan_;
   const uint32_t* pos_;
   const uint8_t* codes_;

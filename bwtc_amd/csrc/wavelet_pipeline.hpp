@@ -181,6 +181,7 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   std::mutex mu;
   std::condition_variable cv;
   size_t models_left = 0, sections_left = 0;
+  std::atomic<size_t> section_cursor{0};            // sections handed to the paired range-coder tasks
   bool done = false;
   uint64_t rank = 0;                                 // the block's place in the worker pool's order (its ticket)
   uint8_t* user_out = nullptr;
