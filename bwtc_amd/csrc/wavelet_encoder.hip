@@ -143,7 +143,8 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
             e.model_groups->on_block_modelled = [pool, clock](const std::shared_ptr<WaveletJob>& j) { submit_sections(j, pool, clock); };
           }
           BlockGroupSource* groups = e.model_groups;
-          const unsigned max_engines = std::max(1u, (pool->size() + 3) / 4);
+          static const unsigned kEngineShare = [] { const char* v = std::getenv("BWTC_HIP_ENGINE_SHARE"); return (unsigned)(v && std::atoi(v) > 0 ? std::atoi(v) : 4); }();
+          const unsigned max_engines = std::max(1u, (pool->size() + kEngineShare - 1) / kEngineShare);
           // the block's few huge groups keep their own scalar tasks: a lane would hold the block's
           // range coders back for as long as the largest of them takes at a lane's pace
           if (debug) {
@@ -157,7 +158,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
             for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
             std::fprintf(stderr, "\n");
           }
-          const uint64_t kHuge = 16u << 20;
+          static const uint64_t kHuge = [] { const char* v = std::getenv("BWTC_HIP_HUGE_MI"); return (uint64_t)(v && std::atoi(v) > 0 ? std::atoi(v) : 32) << 20; }();
           size_t huge = 0;
           while (huge < job.coder->modelTasks() && job.coder->taskElements(huge) >= kHuge) ++huge;
           {
