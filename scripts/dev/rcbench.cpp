@@ -1,7 +1,8 @@
 // Scratch micro-benchmark behind DESIGN.md's note on the range coder loop: the loop as shipped
 // ("branchy") against branch-free byte output with 1-4 interleaved chains, on synthetic
 // (bit, probability) streams.  clang -O3 -march=native; EPYC 9575F: 1.92 / 2.63 / 1.70 / 1.89 / 1.92
-// ns per element -- interleaving buys about a tenth, not worth a second code path.
+// ns per element on an easy stream, 2.06 / 2.65 / 1.69 / 1.89 / 1.91 on one with the text block's
+// entropy: two chains are the sweet spot (StreamCoder::codeSectionsPaired).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
