@@ -1,7 +1,9 @@
 // See wavelet_simd.hpp.  The scalar statement of the same models is GroupModel<TYPE, 'B'> in
 // wavelet_host.cpp (probmodels/ProbabilityModel.cpp:38-75, BitPredictors.hpp:37-65,
 // FSM.hpp:42-67, :196-205); the structures here repeat its rules in a type-generic form so
-// that lanes of different group types can share a vector.
+// that lanes of different group types can share a vector.  (A 32-lane form on 16-bit elements --
+// every value fits 12 bits -- was tried: on the GPU box's Zen 5 its step is more than twice as
+// slow as the 32-bit one, so it lost on both host time and latency.)
 #include "wavelet_simd.hpp"
 
 #include <immintrin.h>
