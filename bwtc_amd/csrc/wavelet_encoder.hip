@@ -23,7 +23,8 @@ namespace bwtc_hip {
 
 // Appends the finished sections to the record and closes it (finishBlock,
 // WaveletCoders.cpp:159-163); the worker that finishes a block's last section runs this.
-static void finish_wavelet_job(WaveletJob& job) {
+static void finish_wavelet_job(WaveletJob& job, StageClock* clock = nullptr) {
+  if (clock) --clock->unfinished;
   std::vector<uint8_t>& rec = job.record;
   size_t total = rec.size();
   for (size_t s = 0; s < job.outs.size(); ++s) total += job.outs[s].bytes.size();
@@ -46,8 +47,11 @@ static void submit_sections(const std::shared_ptr<WaveletJob>& jobp, WorkerPool*
   // with two tasks the block's longest chain is alone again (at its own full speed) as soon as
   // the other sections are used up
   std::vector<std::function<void()> > next;
+  // (one task -- the longest chain paired all the way -- costs a tenth less host time again but
+  // lengthens every block by 0.3 s; measured slower over 48 blocks, equal over 96)
   static const size_t kTasks = [] { const char* v = std::getenv("BWTC_HIP_CODER_TASKS"); return v && std::atoi(v) > 0 ? (size_t)std::atoi(v) : (size_t)2; }();
-  const size_t engines = std::min<size_t>(kTasks, (jobp->coder->sectionTasks() + 1) / 2);
+  const size_t want = kTasks;
+  const size_t engines = std::min<size_t>(want, (jobp->coder->sectionTasks() + 1) / 2);
   for (size_t q = 0; q < std::max<size_t>(engines, 1); ++q) {
     next.push_back([jobp, clock] {
       WaveletJob& j = *jobp;
@@ -56,7 +60,7 @@ static void submit_sections(const std::shared_ptr<WaveletJob>& jobp, WorkerPool*
       clock->coder_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       bool fin;
       { std::lock_guard<std::mutex> g(j.mu); j.sections_left -= did; fin = did > 0 && j.sections_left == 0; }
-      if (fin) finish_wavelet_job(j);
+      if (fin) finish_wavelet_job(j, clock);
     });
   }
   pool->submit(jobp->rank, next);
@@ -133,6 +137,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       if (job.models_left == 0 || job.sections_left == 0) {
         finish_wavelet_job(job);
       } else {
+        ++e.stage_clock.unfinished;
         WorkerPool* pool = e.pool;
         if (e.wavelet_model == 'B' && bwtc::wavelet::simdModelsAvailable()) {
           // sixteen groups per thread at a time, lanes refilled across blocks (wavelet_simd.hpp,
