@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--coder", choices=["B", "H"], default="B",
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
-    ap.add_argument("--depth", type=int, default=12,
+    ap.add_argument("--depth", type=int, default=16,
                     help="'B': blocks under way at once (device half of block i+1 overlaps the host half of block i)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -71,7 +71,7 @@ struct BwtEngine {
   BlockGroupSource* model_groups = nullptr;   // groups of all blocks under way, for the 16-lane model engines
   std::map<u64, std::shared_ptr<WaveletJob> > jobs;
   u64 next_ticket = 1;
-  unsigned max_inflight = 12;          // BWTC_HIP_WAVELET_DEPTH
+  unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH
   std::vector<std::unique_ptr<PinnedBytes> > codes_free;              // recycled: no fresh pages per block
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block

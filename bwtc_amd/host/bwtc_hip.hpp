@@ -416,7 +416,7 @@ class WaveletEncoder : public EntropyEncoder {
     return (size_t)n;
   }
  private:
-  enum { kDepth = 8 };
+  enum { kDepth = 12 };
   struct Slot { byte* rec; uint64 cap; uint64_t ticket; Slot() : rec(0), cap(0), ticket(0) {} };
   void start(BWTManager& bwtm) {
     m_ctx = bwtm.hipContext();

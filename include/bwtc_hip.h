@@ -178,7 +178,7 @@ int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint
  * the CPUs the process may use -- affinity and cgroup quota -- up to 64); it returns as soon as the GPU is free for the next block.  _end waits
  * for that block; the record is then in the `out` given to _begin, *out_bytes long.  Records
  * are those of a strictly sequential encoder whatever the overlap.  At most
- * BWTC_HIP_WAVELET_DEPTH (default 12) blocks are under way; a further _begin waits for the
+ * BWTC_HIP_WAVELET_DEPTH (default 16) blocks are under way; a further _begin waits for the
  * oldest, and returns -6 if that one is finished but not collected.  `out` must stay valid
  * until _end (or until bwtc_hip_destroy returns: it lets blocks under way finish);
  * _begin/_end of one context are called from one thread. */

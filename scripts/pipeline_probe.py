@@ -15,7 +15,7 @@ host = synth.gen_text(n, 3)
 d_in = torch.from_numpy(host).to(dev)
 d_out = torch.empty_like(d_in)
 ctx = hip.Context(0, n)
-depth = int(os.environ.get("PROBE_DEPTH", "12"))
+depth = int(os.environ.get("PROBE_DEPTH", "16"))
 ring = [np.empty(ctx.compress_bound(n), np.uint8) for _ in range(depth)]
 pend = []
 t0 = time.perf_counter()
