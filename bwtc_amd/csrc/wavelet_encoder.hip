@@ -169,14 +169,15 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
           {
             StageClock* clock = &e.stage_clock;
             std::vector<std::function<void()> > own;
-            for (size_t k = 0; k < huge; ++k) {
-              own.push_back([jobp, pool, k, clock] {
+            for (size_t k = 0; k < huge; k += 2) {
+              const size_t k2 = k + 1 < huge ? k + 1 : k;              // two at a time: a chain alone leaves the core half idle
+              own.push_back([jobp, pool, k, k2, clock] {
                 WaveletJob& j = *jobp;
                 const auto t0 = std::chrono::steady_clock::now();
-                j.coder->model(k, j.prob.data());
+                if (k2 != k) j.coder->modelPair(k, k2, j.prob.data()); else j.coder->model(k, j.prob.data());
                 clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 bool last;
-                { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
+                { std::lock_guard<std::mutex> g(j.mu); j.models_left -= (k2 != k ? 2 : 1); last = j.models_left == 0; }
                 if (last) submit_sections(jobp, pool, clock);
               });
             }

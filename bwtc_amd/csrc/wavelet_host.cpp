@@ -825,6 +825,30 @@ void modelGroupWith(const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, u
   for (; i < e; ++i) prob[i] = m.step(codeAt(codes, i));
 }
 
+// Two groups of coder 'B' stepped alternately by one thread: each is a serial chain that leaves
+// most of the core idle (used for a block's few huge groups, which do not go through the lanes).
+template <int TA, int TB>
+void modelTwo(const uint8_t* codes, uint64_t ia, uint64_t ea, uint32_t mca, uint64_t ib, uint64_t eb, uint32_t mcb, uint16_t* prob) {
+  GroupModel<TA, 'B'> A(mca);
+  GroupModel<TB, 'B'> B(mcb);
+  for (uint64_t n = std::min(ea - ia, eb - ib); n > 0; --n) {
+    prob[ia] = A.step(codeAt(codes, ia)); ++ia;
+    prob[ib] = B.step(codeAt(codes, ib)); ++ib;
+  }
+  for (; ia < ea; ++ia) prob[ia] = A.step(codeAt(codes, ia));
+  for (; ib < eb; ++ib) prob[ib] = B.step(codeAt(codes, ib));
+}
+
+template <int TA>
+void modelTwoB(int tb, const uint8_t* codes, uint64_t ia, uint64_t ea, uint32_t mca, uint64_t ib, uint64_t eb, uint32_t mcb, uint16_t* prob) {
+  switch (tb) {
+    case kRoot: modelTwo<TA, kRoot>(codes, ia, ea, mca, ib, eb, mcb, prob); break;
+    case kBothLeaves: modelTwo<TA, kBothLeaves>(codes, ia, ea, mca, ib, eb, mcb, prob); break;
+    case kInteger: modelTwo<TA, kInteger>(codes, ia, ea, mca, ib, eb, mcb, prob); break;
+    default: modelTwo<TA, kInner>(codes, ia, ea, mca, ib, eb, mcb, prob); break;
+  }
+}
+
 template <int TYPE>
 void modelGroup(char model, const uint8_t* codes, uint64_t b, uint64_t e, uint32_t mc, uint16_t* prob) {
   if (model == 'b') modelGroupWith<TYPE, 'b'>(codes, b, e, mc, prob);
@@ -1074,6 +1098,20 @@ void StreamCoder::model(size_t k, uint16_t* prob) const {
   const uint32_t mc = stateBefore(t.section, t.group);
   if (t.type == kRoot) modelGroup<kRoot>(model_, codes_, t.begin, t.end, mc, prob);
   else modelGroup<kInner>(model_, codes_, t.begin, t.end, mc, prob);
+}
+
+void StreamCoder::modelPair(size_t k1, size_t k2, uint16_t* prob) const {
+  if (model_ != 'B') { model(k1, prob); model(k2, prob); return; }
+  const Task& a = tasks_[k1];
+  const Task& b = tasks_[k2];
+  const uint32_t mca = (a.type == kInteger || a.type == kBothLeaves) ? 0u : stateBefore(a.section, a.group);
+  const uint32_t mcb = (b.type == kInteger || b.type == kBothLeaves) ? 0u : stateBefore(b.section, b.group);
+  switch (a.type) {
+    case kRoot: modelTwoB<kRoot>(b.type, codes_, a.begin, a.end, mca, b.begin, b.end, mcb, prob); break;
+    case kBothLeaves: modelTwoB<kBothLeaves>(b.type, codes_, a.begin, a.end, mca, b.begin, b.end, mcb, prob); break;
+    case kInteger: modelTwoB<kInteger>(b.type, codes_, a.begin, a.end, mca, b.begin, b.end, mcb, prob); break;
+    default: modelTwoB<kInner>(b.type, codes_, a.begin, a.end, mca, b.begin, b.end, mcb, prob); break;
+  }
 }
 
 void StreamCoder::describe(size_t k, uint16_t* prob, ModelGroupDesc* d) const {

@@ -105,6 +105,7 @@ class StreamCoder {
   uint64_t elements() const;                              // size of the probability buffer
   size_t modelTasks() const { return tasks_.size(); }
   void model(size_t k, uint16_t* prob) const;
+  void modelPair(size_t k1, size_t k2, uint16_t* prob) const;   // two groups stepped alternately by one thread
   // the same task as a descriptor for the 16-lane engine (wavelet_simd.hpp; coder 'B' only)
   void describe(size_t k, uint16_t* prob, ModelGroupDesc* d) const;
   char modelLetter() const { return model_; }
