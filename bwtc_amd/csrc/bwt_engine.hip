@@ -489,6 +489,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     wavelet_on_host = w && std::strcmp(w, "host") == 0;
     const char* d = std::getenv("BWTC_HIP_WAVELET_DEPTH");
     if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
+    const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
+    if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));

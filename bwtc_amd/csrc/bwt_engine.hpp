@@ -72,6 +72,7 @@ struct BwtEngine {
   std::map<u64, std::shared_ptr<WaveletJob> > jobs;
   u64 next_ticket = 1;
   unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH
+  u64 huge_group_elements = 32u << 20; // BWTC_HIP_HUGE_MI: groups this large are modelled by scalar tasks, not lanes
   std::vector<std::unique_ptr<PinnedBytes> > codes_free;              // recycled: no fresh pages per block
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block

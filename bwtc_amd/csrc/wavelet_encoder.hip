@@ -163,7 +163,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
             for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
             std::fprintf(stderr, "\n");
           }
-          static const uint64_t kHuge = [] { const char* v = std::getenv("BWTC_HIP_HUGE_MI"); return (uint64_t)(v && std::atoi(v) > 0 ? std::atoi(v) : 32) << 20; }();
+          const uint64_t kHuge = e.huge_group_elements;
           size_t huge = 0;
           while (huge < job.coder->modelTasks() && job.coder->taskElements(huge) >= kHuge) ++huge;
           {

@@ -319,3 +319,22 @@ def test_varied_block_sweep_both_coders(hip_ctx, oracle):
         got = hip_ctx.huffman_encode(bwt, lf, freqs)
         want = oracle.oracle_huffman_encode_block(bwt, lf, freqs)
         assert got.tobytes() == want.tobytes(), ("H", case, kind, bwt.size)
+
+
+def test_wavelet_B_huge_group_tasks_at_test_size(oracle):
+    """The scalar tasks for huge groups (two groups stepped alternately) only appear at 256 MiB
+    with the default threshold; lowered to 1 Mi elements they run on a 32 MiB block, whose record
+    is checked against the oracle."""
+    from bwtc_amd import hip
+    os.environ["BWTC_HIP_HUGE_MI"] = "1"
+    try:
+        ctx = hip.Context(device=0, max_block_size=(32 << 20) + 1024)
+    finally:
+        del os.environ["BWTC_HIP_HUGE_MI"]
+    try:
+        data = synth.gen_text(32 << 20, 5)
+        ctx.wavelet_reset()
+        rec, _ = ctx.transform_and_encode_wavelet(data, 8)
+        assert _frame(b"B", rec.tobytes(), data.size) == oracle.oracle_compress_B(data, data.size, 8).tobytes()
+    finally:
+        ctx.close()
