@@ -73,7 +73,7 @@ def cpu_baseline(size_mib_sample, seed, coder):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--coder", choices=["B", "H"], default="B",
