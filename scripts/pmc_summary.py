@@ -14,7 +14,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         out.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
