@@ -183,11 +183,12 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
             }
             pool->submit(job.rank, own);
           }
-          if (huge < job.coder->modelTasks() && groups->add(jobp, huge, max_engines)) {
+          const int prefer = huge < job.coder->modelTasks() ? groups->add(jobp, huge, max_engines) : 0;
+          if (prefer) {
             StageClock* clock = &e.stage_clock;
-            pool->submit(0, [groups, clock] {
+            pool->submit(0, [groups, clock, prefer] {
               const auto t0 = std::chrono::steady_clock::now();
-              bwtc::wavelet::runModelLanes(*groups);
+              bwtc::wavelet::runModelLanes(*groups, prefer);
               clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             });
           }

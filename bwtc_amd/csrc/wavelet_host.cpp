@@ -1179,7 +1179,7 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
     // sixteen groups per thread at a time (wavelet_simd.hpp); the engines share one cursor
     struct Source : GroupSource {
       const StreamCoder* coder; uint16_t* prob; std::mutex mu; size_t next_;
-      bool next(ModelGroupDesc* d) {
+      bool next(ModelGroupDesc* d, int) {
         size_t k;
         { std::lock_guard<std::mutex> g(mu); if (next_ >= coder->modelTasks()) return false; k = next_++; }
         coder->describe(k, prob, d);

@@ -110,6 +110,7 @@ class StreamCoder {
   void describe(size_t k, uint16_t* prob, ModelGroupDesc* d) const;
   char modelLetter() const { return model_; }
   uint64_t taskElements(size_t k) const { return tasks_[k].end - tasks_[k].begin; }
+  bool taskIsInteger(size_t k) const { return tasks_[k].type == kInteger; }
   size_t sectionTasks() const { return sections_.size(); }
   void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
   // the same for sections taken from a shared cursor, two chains at a time in one thread;

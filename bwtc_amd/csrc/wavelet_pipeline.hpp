@@ -148,26 +148,28 @@ struct WaveletJob;
 // source's lock.
 class BlockGroupSource : public bwtc::wavelet::GroupSource {
  public:
-  BlockGroupSource() : engines_(0) {}
+  BlockGroupSource() { engines_[0] = engines_[1] = engines_[2] = 0; }
   // queues a block's groups from `first_group` on (the list is largest first; the caller keeps
   // the few huge ones for the scalar loop, which finishes a single chain four times sooner than
-  // a lane does); true = the caller should start one more engine
-  bool add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines);
-  bool next(bwtc::wavelet::ModelGroupDesc* d);
+  // a lane does); returns the preference (1 integer-level groups, 2 symbol-tree groups) of the
+  // engine the caller should start, 0 for none
+  int add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines);
+  bool next(bwtc::wavelet::ModelGroupDesc* d, int prefer);
   void done(void* cookie);
-  bool retire() {
+  bool retire(int prefer) {
     std::lock_guard<std::mutex> g(mu_);
     if (!queue_.empty()) return false;
-    --engines_;
+    --engines_[prefer];
     return true;
   }
   // set once: what to do when a block's last group is modelled
   std::function<void(const std::shared_ptr<WaveletJob>&)> on_block_modelled;
  private:
-  struct Entry { std::shared_ptr<WaveletJob> job; size_t next; };
+  // a block's groups by kind, each list largest first; [0] integer levels, [1] symbol-tree nodes
+  struct Entry { std::shared_ptr<WaveletJob> job; std::vector<uint32_t> list[2]; size_t at[2]; };
   std::mutex mu_;
   std::deque<Entry> queue_;
-  unsigned engines_;
+  unsigned engines_[3];
 };
 
 // One block between bwtc_hip_wavelet_encode_device_begin and ..._end.
@@ -194,24 +196,43 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
 
 namespace bwtc_hip {
 
-inline bool BlockGroupSource::add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines) {
+inline int BlockGroupSource::add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines) {
+  Entry e;
+  e.job = job;
+  e.at[0] = e.at[1] = 0;
+  for (size_t k = first_group; k < job->coder->modelTasks(); ++k)
+    e.list[job->coder->taskIsInteger(k) ? 0 : 1].push_back(static_cast<uint32_t>(k));
   std::lock_guard<std::mutex> g(mu_);
-  Entry e = {job, first_group};
-  queue_.push_back(e);
-  if (engines_ >= max_engines) return false;
-  ++engines_;
-  return true;
+  queue_.push_back(std::move(e));
+  if (engines_[1] + engines_[2] >= max_engines) return 0;
+  // engines of one kind keep their lanes to one kind of group while there is enough of it: a
+  // vector of integer-level lanes needs 3 of the 15 predictor selects
+  const int prefer = engines_[1] * 2 < engines_[2] || (engines_[2] > 0 && engines_[1] == 0 && max_engines > 1) ? 1 : 2;
+  ++engines_[prefer];
+  return prefer;
 }
 
-inline bool BlockGroupSource::next(bwtc::wavelet::ModelGroupDesc* d) {
+inline bool BlockGroupSource::next(bwtc::wavelet::ModelGroupDesc* d, int prefer) {
   std::shared_ptr<WaveletJob> job;
   size_t k = 0;
   {
     std::lock_guard<std::mutex> g(mu_);
-    while (!queue_.empty() && queue_.front().next >= queue_.front().job->coder->modelTasks()) queue_.pop_front();
+    while (!queue_.empty() && queue_.front().at[0] >= queue_.front().list[0].size() &&
+           queue_.front().at[1] >= queue_.front().list[1].size())
+      queue_.pop_front();
     if (queue_.empty()) return false;
-    job = queue_.front().job;
-    k = queue_.front().next++;
+    Entry* from = nullptr;
+    int kind = prefer == 1 ? 0 : 1;
+    for (size_t i = 0; i < queue_.size() && prefer; ++i)       // the preferred kind, oldest block first
+      if (queue_[i].at[kind] < queue_[i].list[kind].size()) { from = &queue_[i]; break; }
+    if (!from) {                                               // none left anywhere: whatever the oldest block has
+      from = &queue_.front();
+      kind = from->at[0] < from->list[0].size() ? 0 : 1;
+      if (prefer == 0 && from->at[1] < from->list[1].size() &&
+          (kind == 1 || from->list[1][from->at[1]] < from->list[0][from->at[0]])) kind = 1;   // largest first
+    }
+    job = from->job;
+    k = from->list[kind][from->at[kind]++];
   }
   job->coder->describe(k, job->prob.data(), d);
   d->cookie = job.get();

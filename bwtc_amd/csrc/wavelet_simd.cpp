@@ -103,16 +103,19 @@ struct Lanes {
 #define BWTC_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq")))
 
 // `words` 16-element words of every busy lane (all busy lanes have that many left, and stand
-// on a word boundary)
+// on a word boundary).  MAIN / GAPS / INTS: which of the three models any busy lane uses; a
+// vector of integer-level lanes only touches 3 of the 15 predictors.
+template <bool MAIN, bool GAPS, bool INTS>
 BWTC_AVX512 void runWords(Lanes& L, uint64_t words) {
+  constexpr int kLo = MAIN ? 0 : GAPS ? 8 : 12, kHi = INTS ? 15 : GAPS ? 12 : 8;
   __m512i Q[kSlots];
-  for (int s = 0; s < kSlots; ++s) Q[s] = _mm512_load_si512(L.q[s]);
+  for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_load_si512(L.q[s]);
   __m512i mc = _mm512_load_si512(L.mc), gc = _mm512_load_si512(L.gc), ic = _mm512_load_si512(L.ic);
   const __m512i zero = _mm512_setzero_si512(), one = _mm512_set1_epi32(1), two = _mm512_set1_epi32(2);
-  const __mmask16 kInt = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.isInt), zero);
-  const __mmask16 kGapAlways = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapAlways), zero);
-  const __mmask16 kGapCode = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapFromCode), zero);
-  const __mmask16 kMainMoves = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.mainMoves), zero);
+  const __mmask16 kInt = INTS ? _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.isInt), zero) : static_cast<__mmask16>(0);
+  const __mmask16 kGapAlways = GAPS ? _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapAlways), zero) : static_cast<__mmask16>(0);
+  const __mmask16 kGapCode = GAPS ? _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapFromCode), zero) : static_cast<__mmask16>(0);
+  const __mmask16 kMainMoves = MAIN ? _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.mainMoves), zero) : static_cast<__mmask16>(0);
   const __m512i floorV = _mm512_mask_blend_epi32(kInt, two, _mm512_set1_epi32(100));
   const __m512i topV = _mm512_sub_epi32(_mm512_set1_epi32(4096), floorV);
   const __m512i five = _mm512_set1_epi32(5), c8 = _mm512_set1_epi32(8), c12 = _mm512_set1_epi32(12);
@@ -133,30 +136,32 @@ BWTC_AVX512 void runWords(Lanes& L, uint64_t words) {
       const __m512i v = _mm512_and_si512(W, _mm512_set1_epi32(3));
       W = _mm512_srli_epi32(W, 2);
       const __mmask16 kBit = _mm512_test_epi32_mask(v, one);
-      const __mmask16 kGap = kGapAlways | (kGapCode & _mm512_test_epi32_mask(v, two));
+      const __mmask16 kGap = GAPS ? static_cast<__mmask16>(kGapAlways | (kGapCode & _mm512_test_epi32_mask(v, two))) : static_cast<__mmask16>(0);
       __m512i slot = mc;
-      slot = _mm512_mask_add_epi32(slot, kGap, gc, c8);
-      slot = _mm512_mask_add_epi32(slot, kInt, ic, c12);
+      if (GAPS) slot = _mm512_mask_add_epi32(slot, kGap, gc, c8);
+      if (INTS) slot = _mm512_mask_add_epi32(slot, kInt, ic, c12);
       // the lane's predictor: every slot's vector masked to the lanes that use it, OR-ed as a tree
       __mmask16 m[kSlots];
       __m512i part[16];
-      for (int s = 0; s < kSlots; ++s) {
+      for (int s = 0; s < 16; ++s) part[s] = zero;
+      for (int s = kLo; s < kHi; ++s) {
         m[s] = _mm512_cmpeq_epi32_mask(slot, _mm512_set1_epi32(s));
-        part[s] = _mm512_maskz_mov_epi32(m[s], Q[s]);
+        part[s - kLo] = _mm512_maskz_mov_epi32(m[s], Q[s]);
       }
-      part[15] = zero;
-      for (int width = 8; width >= 1; width >>= 1)
+      constexpr int kWidth = (kHi - kLo) > 8 ? 8 : (kHi - kLo) > 4 ? 4 : 2;
+      for (int width = kWidth; width >= 1; width >>= 1)
         for (int k = 0; k < width; ++k) part[k] = _mm512_or_si512(part[k], part[k + width]);
       const __m512i pr = part[0];
-      const __m512i delay = _mm512_mask_sub_epi32(five, m[0] | m[7], five, one);
+      __m512i delay = five;
+      if (MAIN) delay = _mm512_mask_sub_epi32(five, m[0] | m[7], five, one);
       const __m512i up = _mm512_add_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(topV, pr), delay));
       const __m512i down = _mm512_sub_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(pr, floorV), delay));
       const __m512i moved = _mm512_mask_blend_epi32(kBit, down, up);
-      for (int s = 0; s < kSlots; ++s) Q[s] = _mm512_mask_mov_epi32(Q[s], m[s], moved);
+      for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_mask_mov_epi32(Q[s], m[s], moved);
       const __m512i bit = _mm512_and_si512(v, one);
-      mc = _mm512_mask_mov_epi32(mc, kMainMoves, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(mc, 1), bit), T8));
-      gc = _mm512_mask_mov_epi32(gc, kGap, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(gc, 1), bit), T4));
-      ic = _mm512_mask_mov_epi32(ic, kInt, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(ic, 1), bit), T3));
+      if (MAIN) mc = _mm512_mask_mov_epi32(mc, kMainMoves, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(mc, 1), bit), T8));
+      if (GAPS) gc = _mm512_mask_mov_epi32(gc, kGap, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(gc, 1), bit), T4));
+      if (INTS) ic = _mm512_mask_mov_epi32(ic, kInt, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(ic, 1), bit), T3));
       if (step & 1) _mm512_store_si512(out[step >> 1], _mm512_or_si512(lo, _mm512_slli_epi32(pr, 16)));
       else lo = pr;
     }
@@ -168,10 +173,27 @@ BWTC_AVX512 void runWords(Lanes& L, uint64_t words) {
       L.i[l] += 16;
     }
   }
-  for (int s = 0; s < kSlots; ++s) _mm512_store_si512(L.q[s], Q[s]);
-  _mm512_store_si512(L.mc, mc);
-  _mm512_store_si512(L.gc, gc);
-  _mm512_store_si512(L.ic, ic);
+  for (int s = kLo; s < kHi; ++s) _mm512_store_si512(L.q[s], Q[s]);
+  if (MAIN) _mm512_store_si512(L.mc, mc);
+  if (GAPS) _mm512_store_si512(L.gc, gc);
+  if (INTS) _mm512_store_si512(L.ic, ic);
+}
+
+// picks the narrowest form that covers the busy lanes
+void runWordsFor(Lanes& L, uint64_t words) {
+  bool main = false, gaps = false, ints = false;
+  for (int l = 0; l < kLanes; ++l) {
+    if (!L.busy[l]) continue;
+    if (L.isInt[l]) ints = true;
+    else {
+      if (L.gapAlways[l] || L.gapFromCode[l]) gaps = true;
+      if (!L.gapAlways[l]) main = true;
+    }
+  }
+  if (ints && !main && !gaps) runWords<false, false, true>(L, words);
+  else if (!ints && main && !gaps) runWords<true, false, false>(L, words);
+  else if (!ints) runWords<true, true, false>(L, words);
+  else runWords<true, true, true>(L, words);
 }
 
 }  // namespace
@@ -186,7 +208,7 @@ bool simdModelsAvailable() {
   return ok;
 }
 
-void runModelLanes(GroupSource& src) {
+void runModelLanes(GroupSource& src, int prefer) {
   Lanes L;
   std::memset(&L, 0, sizeof L);
   for (int l = 0; l < kLanes; ++l) L.idle(l);
@@ -197,7 +219,7 @@ void runModelLanes(GroupSource& src) {
     for (int l = 0; l < kLanes; ++l) {
       while (!L.busy[l] && !sourceDry) {
         ModelGroupDesc d;
-        if (!src.next(&d)) { sourceDry = true; break; }
+        if (!src.next(&d, prefer)) { sourceDry = true; break; }
         GroupState g;
         g.start(d);
         const uint64_t aligned = (g.i + 15) & ~static_cast<uint64_t>(15);
@@ -208,7 +230,7 @@ void runModelLanes(GroupSource& src) {
       busy += L.busy[l];
     }
     if (busy == 0) {
-      if (sourceDry && src.retire()) return;
+      if (sourceDry && src.retire(prefer)) return;
       sourceDry = false;
       continue;
     }
@@ -226,7 +248,7 @@ void runModelLanes(GroupSource& src) {
     }
     uint64_t words = ~static_cast<uint64_t>(0);
     for (int l = 0; l < kLanes; ++l) if (L.busy[l]) words = std::min(words, (L.e[l] - L.i[l]) >> 4);
-    if (words > 0) runWords(L, std::min<uint64_t>(words, 1u << 16));
+    if (words > 0) runWordsFor(L, std::min<uint64_t>(words, 1u << 16));
     for (int l = 0; l < kLanes; ++l) {                                 // lanes with less than a word left: scalar tail
       if (!L.busy[l] || L.e[l] - L.i[l] >= 16) continue;
       GroupState g;

@@ -28,17 +28,19 @@ struct ModelGroupDesc {
 class GroupSource {
  public:
   virtual ~GroupSource() {}
-  virtual bool next(ModelGroupDesc* g) = 0;     // false: none available now
+  // prefer: 0 any, 1 integer-level groups, 2 symbol-tree groups; the preference is a hint (a
+  // vector whose lanes are all of one kind skips the other kinds' predictors), any group may come
+  virtual bool next(ModelGroupDesc* g, int prefer) = 0;     // false: none available now
   virtual void done(void* cookie) = 0;          // the group is fully modelled
   // An engine with nothing left asks before it returns; false = more groups have arrived
-  virtual bool retire() { return true; }
+  virtual bool retire(int prefer) { (void)prefer; return true; }
 };
 
 // AVX-512 (F, BW, VL, DQ) present on this CPU and not switched off with BWTC_HIP_SIMD=0
 bool simdModelsAvailable();
 
 // Models groups from `src` until it is empty and every lane has drained.
-void runModelLanes(GroupSource& src);
+void runModelLanes(GroupSource& src, int prefer = 0);
 
 }  // namespace wavelet
 }  // namespace bwtc
