@@ -506,7 +506,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
 }
 
 hipError_t BwtEngine::wait() {
-  const bool block = wait_mode == 2 || (wait_mode == 0 && pool != nullptr);
+  const bool block = wait_mode == 2 || (wait_mode == 0 && pipeline != nullptr);
   if (!block || !ev_wait) return hipStreamSynchronize(stream);
   hipError_t rc = hipEventRecord(ev_wait, stream);
   if (rc != hipSuccess) return rc;

@@ -27,6 +27,38 @@
 
 namespace bwtc_hip {
 
+// ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
+// Page-locked host bytes: the packed streams are copied from the device straight into the
+// block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
+class PinnedBytes {
+ public:
+  PinnedBytes() : p_(nullptr), n_(0) {}
+  ~PinnedBytes() { if (p_) (void)hipHostFree(p_); }
+  PinnedBytes(const PinnedBytes&) = delete;
+  PinnedBytes& operator=(const PinnedBytes&) = delete;
+  void swap(PinnedBytes& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); }
+  bool reserve(size_t n) {
+    if (n <= n_) return true;
+    if (p_) (void)hipHostFree(p_);
+    p_ = nullptr; n_ = 0;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) != hipSuccess) return false;
+    p_ = static_cast<uint8_t*>(q);
+    n_ = n + n / 8;
+    return true;
+  }
+  uint8_t* data() { return p_; }
+  size_t size() const { return n_; }
+ private:
+  uint8_t* p_;
+  size_t n_;
+};
+
+// A block of the pipeline whose streams came from this device: owns the page-locked bytes.
+struct DeviceWaveletJob : WaveletJob {
+  PinnedBytes codes_owner;
+};
+
 struct BwtEngine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -66,10 +98,8 @@ struct BwtEngine {
   u8* h_wt = nullptr;      // pinned: tables up, packed streams down
   u64 h_wt_bytes = 0;
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
-  WorkerPool* pool = nullptr;
-  StageClock stage_clock;
-  BlockGroupSource* model_groups = nullptr;   // groups of all blocks under way, for the 16-lane model engines
-  std::map<u64, std::shared_ptr<WaveletJob> > jobs;
+  HostPipeline* pipeline = nullptr;   // worker threads, lane engines, coder tasks ('B'; made by the first block)
+  std::map<u64, std::shared_ptr<DeviceWaveletJob> > jobs;
   u64 next_ticket = 1;
   unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH
   u64 huge_group_elements = 32u << 20; // BWTC_HIP_HUGE_MI: groups this large are modelled by scalar tasks, not lanes

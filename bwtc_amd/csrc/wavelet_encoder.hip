@@ -21,51 +21,6 @@
 
 namespace bwtc_hip {
 
-// Appends the finished sections to the record and closes it (finishBlock,
-// WaveletCoders.cpp:159-163); the worker that finishes a block's last section runs this.
-static void finish_wavelet_job(WaveletJob& job, StageClock* clock = nullptr) {
-  if (clock) --clock->unfinished;
-  std::vector<uint8_t>& rec = job.record;
-  size_t total = rec.size();
-  for (size_t s = 0; s < job.outs.size(); ++s) total += job.outs[s].bytes.size();
-  rec.reserve(total);
-  for (size_t s = 0; s < job.outs.size(); ++s) rec.insert(rec.end(), job.outs[s].bytes.begin(), job.outs[s].bytes.end());
-  const u64 len = rec.size() - 6;
-  for (int i = 0; i < 6; ++i) rec[i] = (uint8_t)(len >> (8 * (5 - i)));
-  if (job.user_out && rec.size() <= job.user_cap) std::memcpy(job.user_out, rec.data(), rec.size());
-  job.t_finished = std::chrono::steady_clock::now();
-  { std::lock_guard<std::mutex> g(job.mu); job.done = true; }
-  job.cv.notify_all();
-}
-
-// Every group of the block is modelled: its sections' range coders go to the front of the
-// queue, ahead of newer blocks' work.
-static void submit_sections(const std::shared_ptr<WaveletJob>& jobp, WorkerPool* pool, StageClock* clock) {
-  jobp->t_modelled = std::chrono::steady_clock::now();
-  // two tasks per block, each stepping two sections' chains at a time (StreamCoder::
-  // codeSectionsPaired): the pair costs a quarter less host time than two chains run apart, and
-  // with two tasks the block's longest chain is alone again (at its own full speed) as soon as
-  // the other sections are used up
-  std::vector<std::function<void()> > next;
-  // (one task -- the longest chain paired all the way -- costs a tenth less host time again but
-  // lengthens every block by 0.3 s; measured slower over 48 blocks, equal over 96)
-  static const size_t kTasks = [] { const char* v = std::getenv("BWTC_HIP_CODER_TASKS"); return v && std::atoi(v) > 0 ? (size_t)std::atoi(v) : (size_t)2; }();
-  const size_t want = kTasks;
-  const size_t engines = std::min<size_t>(want, (jobp->coder->sectionTasks() + 1) / 2);
-  for (size_t q = 0; q < std::max<size_t>(engines, 1); ++q) {
-    next.push_back([jobp, clock] {
-      WaveletJob& j = *jobp;
-      const auto t0 = std::chrono::steady_clock::now();
-      const size_t did = j.coder->codeSectionsPaired(&j.section_cursor, j.prob.data(), &j.outs);
-      clock->coder_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-      bool fin;
-      { std::lock_guard<std::mutex> g(j.mu); j.sections_left -= did; fin = did > 0 && j.sections_left == 0; }
-      if (fin) finish_wavelet_job(j, clock);
-    });
-  }
-  pool->submit(jobp->rank, next);
-}
-
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
@@ -76,8 +31,8 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
     if (oldest.done) return -6;                     // finished blocks must be collected with ..._end first
     oldest.cv.wait(g, [&] { return oldest.done; });
   }
-  std::shared_ptr<WaveletJob> jobp(new WaveletJob());
-  WaveletJob& job = *jobp;
+  std::shared_ptr<DeviceWaveletJob> jobp(new DeviceWaveletJob());
+  DeviceWaveletJob& job = *jobp;
   job.rank = e.next_ticket;
   job.user_out = out;
   job.user_cap = out_cap;
@@ -119,94 +74,29 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
                    (unsigned long long)job.plan.max_elements, job.plan.group_type.size());
     if (on_device) {
       const auto t1 = std::chrono::steady_clock::now();
-      if (!e.codes_free.empty()) { job.codes.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes);
+      if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
+      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner);
       if (rc) return rc;
+      job.codes = job.codes_owner.data();
       const auto t2 = std::chrono::steady_clock::now();
-      job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes.data(), e.wavelet_state,
-                                                      e.wavelet_model));
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
-      if (!job.prob.reserve(job.coder->elements() + 8)) return -2;
-      e.wavelet_state = job.coder->endState();        // nothing can fail from here on: the stream moves on
-      job.outs.assign(nsec, bwtc::wavelet::SectionOutput());
-      job.t_queued = std::chrono::steady_clock::now();
-      job.models_left = job.coder->modelTasks();
-      job.sections_left = job.coder->sectionTasks();
-      if (!e.pool) e.pool = new WorkerPool(threads);
-      const auto t3 = std::chrono::steady_clock::now();
-      if (job.models_left == 0 || job.sections_left == 0) {
-        finish_wavelet_job(job);
-      } else {
-        ++e.stage_clock.unfinished;
-        WorkerPool* pool = e.pool;
-        if (e.wavelet_model == 'B' && bwtc::wavelet::simdModelsAvailable()) {
-          // sixteen groups per thread at a time, lanes refilled across blocks (wavelet_simd.hpp,
-          // BlockGroupSource).  A few engines keep up with the GPU; the range coders need the rest.
-          if (!e.model_groups) {
-            e.model_groups = new BlockGroupSource();
-            StageClock* clock = &e.stage_clock;
-            e.model_groups->on_block_modelled = [pool, clock](const std::shared_ptr<WaveletJob>& j) { submit_sections(j, pool, clock); };
-          }
-          BlockGroupSource* groups = e.model_groups;
-          static const unsigned kEngineShare = [] { const char* v = std::getenv("BWTC_HIP_ENGINE_SHARE"); return (unsigned)(v && std::atoi(v) > 0 ? std::atoi(v) : 4); }();
-          const unsigned max_engines = std::max(1u, (pool->size() + kEngineShare - 1) / kEngineShare);
-          // the block's few huge groups keep their own scalar tasks: a lane would hold the block's
-          // range coders back for as long as the largest of them takes at a lane's pace
-          if (debug) {
-            uint64_t cnt[8] = {0}, el[8] = {0};
-            for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
-              const uint64_t n = job.coder->taskElements(k);
-              const int b = n >= (32u << 20) ? 7 : n >= (16u << 20) ? 6 : n >= (8u << 20) ? 5 : n >= (4u << 20) ? 4 : n >= (1u << 20) ? 3 : n >= (1u << 16) ? 2 : n >= 256 ? 1 : 0;
-              ++cnt[b]; el[b] += n;
-            }
-            std::fprintf(stderr, "wavelet groups by size (<256, <64Ki, <1Mi, <4Mi, <8Mi, <16Mi, <32Mi, more): ");
-            for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
-            std::fprintf(stderr, "\n");
-          }
-          const uint64_t kHuge = e.huge_group_elements;
-          size_t huge = 0;
-          while (huge < job.coder->modelTasks() && job.coder->taskElements(huge) >= kHuge) ++huge;
-          {
-            StageClock* clock = &e.stage_clock;
-            std::vector<std::function<void()> > own;
-            for (size_t k = 0; k < huge; k += 2) {
-              const size_t k2 = k + 1 < huge ? k + 1 : k;              // two at a time: a chain alone leaves the core half idle
-              own.push_back([jobp, pool, k, k2, clock] {
-                WaveletJob& j = *jobp;
-                const auto t0 = std::chrono::steady_clock::now();
-                if (k2 != k) j.coder->modelPair(k, k2, j.prob.data()); else j.coder->model(k, j.prob.data());
-                clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-                bool last;
-                { std::lock_guard<std::mutex> g(j.mu); j.models_left -= (k2 != k ? 2 : 1); last = j.models_left == 0; }
-                if (last) submit_sections(jobp, pool, clock);
-              });
-            }
-            pool->submit(job.rank, own);
-          }
-          const int prefer = huge < job.coder->modelTasks() ? groups->add(jobp, huge, max_engines) : 0;
-          if (prefer) {
-            StageClock* clock = &e.stage_clock;
-            pool->submit(0, [groups, clock, prefer] {
-              const auto t0 = std::chrono::steady_clock::now();
-              bwtc::wavelet::runModelLanes(*groups, prefer);
-              clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            });
-          }
-        } else {
-          for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
-            StageClock* clock = &e.stage_clock;
-            pool->submit(job.rank, [jobp, pool, k, clock] {
-              WaveletJob& j = *jobp;
-              const auto t0 = std::chrono::steady_clock::now();
-              j.coder->model(k, j.prob.data());
-              clock->model_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-              bool last;
-              { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
-              if (last) submit_sections(jobp, pool, clock);
-            });
-          }
+      if (!job.prob.reserve(e.wt_coded + 8)) return -2;
+      if (!e.pipeline) e.pipeline = new HostPipeline(threads, e.huge_group_elements);
+      if (debug) {
+        uint64_t cnt[8] = {0}, el[8] = {0};
+        const uint32_t* pos = job.coded_pos.data();
+        for (size_t g = 0; g + 1 < job.coded_pos.size(); ++g) {
+          const uint64_t n = pos[g + 1] - pos[g];
+          const int b = n >= (32u << 20) ? 7 : n >= (16u << 20) ? 6 : n >= (8u << 20) ? 5 : n >= (4u << 20) ? 4 : n >= (1u << 20) ? 3 : n >= (1u << 16) ? 2 : n >= 256 ? 1 : 0;
+          ++cnt[b]; el[b] += n;
         }
+        std::fprintf(stderr, "wavelet groups by coded size (<256, <64Ki, <1Mi, <4Mi, <8Mi, <16Mi, <32Mi, more): ");
+        for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
+        std::fprintf(stderr, "\n");
       }
+      const auto t3 = std::chrono::steady_clock::now();
+      // nothing can fail from here on: the stream's carried model state moves on
+      e.wavelet_state = e.pipeline->queue(jobp, e.wavelet_state, e.wavelet_model);
       if (debug) {
         const auto t4 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; run scanner %.1f ms, plan %.1f ms, "
@@ -216,7 +106,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
                      std::chrono::duration<double, std::milli>(t1 - t0).count(),
                      std::chrono::duration<double, std::milli>(t2 - t1).count(),
                      std::chrono::duration<double, std::milli>(t3 - t2).count(),
-                     std::chrono::duration<double, std::milli>(t4 - t3).count(), e.pool->size());
+                     std::chrono::duration<double, std::milli>(t4 - t3).count(), e.pipeline->threads());
       }
       queued = true;
     } else {
@@ -233,19 +123,18 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       bwtc::wavelet::encodeSections(secs, threads, &e.wavelet_state, &job.outs, e.wavelet_model);
     }
   }
-  if (!queued) finish_wavelet_job(job);
-  ++e.stage_clock.blocks;
+  if (!queued) HostPipeline::finishNow(job);
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;
   return 0;
 }
 
 int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
-  std::map<u64, std::shared_ptr<WaveletJob> >::iterator it = e.jobs.find(ticket);
+  std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.find(ticket);
   if (it == e.jobs.end() || !out_bytes) return -1;
-  std::shared_ptr<WaveletJob> jobp = it->second;
-  WaveletJob& job = *jobp;
-  { std::unique_lock<std::mutex> g(job.mu); job.cv.wait(g, [&] { return job.done; }); }
+  std::shared_ptr<DeviceWaveletJob> jobp = it->second;
+  DeviceWaveletJob& job = *jobp;
+  HostPipeline::wait(job);
   if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
     std::fprintf(stderr, "wavelet block %llu: queued -> modelled %.0f ms, -> finished %.0f ms, -> collected %.0f ms\n",
                  (unsigned long long)ticket,
@@ -254,9 +143,9 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t_finished).count());
   e.jobs.erase(it);
   // keep the two big buffers: fresh ones would be paged in again for every block
-  if (job.codes.size() && e.codes_free.size() < e.max_inflight) {
+  if (job.codes_owner.size() && e.codes_free.size() < e.max_inflight) {
     e.codes_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
-    e.codes_free.back()->swap(job.codes);
+    e.codes_free.back()->swap(job.codes_owner);
   }
   if (job.prob.size() && e.prob_free.size() < e.max_inflight) {
     e.prob_free.push_back(std::unique_ptr<RawBuffer<uint16_t> >(new RawBuffer<uint16_t>()));
@@ -267,19 +156,15 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
 }
 
 void wavelet_pipeline_release(BwtEngine& e) {
-  for (std::map<u64, std::shared_ptr<WaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it) {
-    WaveletJob& job = *it->second;                // uncollected blocks are finished, not abandoned half way
-    std::unique_lock<std::mutex> g(job.mu);
-    job.cv.wait(g, [&] { return job.done; });
-  }
+  for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
+    HostPipeline::wait(*it->second);                // uncollected blocks are finished, not abandoned half way
   e.jobs.clear();
-  if (std::getenv("BWTC_HIP_DEBUG") && e.stage_clock.blocks)
+  if (e.pipeline && std::getenv("BWTC_HIP_DEBUG") && e.pipeline->clock.blocks)
     std::fprintf(stderr, "wavelet pipeline: %llu blocks; host time in models %.3f s, in range coders %.3f s (summed over threads)\n",
-                 (unsigned long long)e.stage_clock.blocks.load(), e.stage_clock.model_ns.load() * 1e-9, e.stage_clock.coder_ns.load() * 1e-9);
-  delete e.pool;                                  // joins the workers (engines retire when nothing is queued)
-  e.pool = nullptr;
-  delete e.model_groups;
-  e.model_groups = nullptr;
+                 (unsigned long long)e.pipeline->clock.blocks.load(), e.pipeline->clock.model_ns.load() * 1e-9,
+                 e.pipeline->clock.coder_ns.load() * 1e-9);
+  delete e.pipeline;                              // joins the workers (engines retire when nothing is queued)
+  e.pipeline = nullptr;
   e.codes_free.clear();
   e.prob_free.clear();
 }

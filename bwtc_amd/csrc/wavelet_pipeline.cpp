@@ -1,0 +1,139 @@
+// See wavelet_pipeline.hpp.
+#include "wavelet_pipeline.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace bwtc_hip {
+
+namespace {
+unsigned envNumber(const char* name, unsigned fallback) {
+  const char* v = std::getenv(name);
+  return v && std::atoi(v) > 0 ? static_cast<unsigned>(std::atoi(v)) : fallback;
+}
+uint64_t since(const std::chrono::steady_clock::time_point& t0) {
+  return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+}
+}  // namespace
+
+HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements)
+    : groups_(), pool_(threads), huge_(huge_group_elements) {
+  // a few lane engines keep up with the GPU; the range coders need the other threads
+  const unsigned share = envNumber("BWTC_HIP_ENGINE_SHARE", 4);
+  max_engines_ = std::max(1u, (pool_.size() + share - 1) / share);
+  // two tasks per block, each stepping two sections' chains at a time (StreamCoder::
+  // codeSectionsPaired): the pair costs a quarter less host time than two chains run apart, and
+  // with two tasks the block's longest chain is alone again (at its own full speed) as soon as
+  // the other sections are used up.  (One task -- the longest chain paired all the way -- costs a
+  // tenth less host time again but lengthens every block by 0.3 s: measured slower over 48
+  // blocks, equal over 96.)
+  coder_tasks_ = envNumber("BWTC_HIP_CODER_TASKS", 2);
+  groups_.on_block_modelled = [this](const std::shared_ptr<WaveletJob>& j) { submitSections(j); };
+}
+
+HostPipeline::~HostPipeline() {}
+
+void HostPipeline::wait(WaveletJob& job) {
+  std::unique_lock<std::mutex> g(job.mu);
+  job.cv.wait(g, [&] { return job.done; });
+}
+
+// Appends the finished sections to the record and closes it (finishBlock,
+// WaveletCoders.cpp:159-163); the worker that finishes a block's last section runs this.
+void HostPipeline::finishNow(WaveletJob& job) {
+  std::vector<uint8_t>& rec = job.record;
+  size_t total = rec.size();
+  for (size_t s = 0; s < job.outs.size(); ++s) total += job.outs[s].bytes.size();
+  rec.reserve(total);
+  for (size_t s = 0; s < job.outs.size(); ++s) rec.insert(rec.end(), job.outs[s].bytes.begin(), job.outs[s].bytes.end());
+  const uint64_t len = rec.size() - 6;
+  for (int i = 0; i < 6; ++i) rec[i] = static_cast<uint8_t>(len >> (8 * (5 - i)));
+  if (job.user_out && rec.size() <= job.user_cap) std::memcpy(job.user_out, rec.data(), rec.size());
+  job.t_finished = std::chrono::steady_clock::now();
+  { std::lock_guard<std::mutex> g(job.mu); job.done = true; }
+  job.cv.notify_all();
+}
+
+void HostPipeline::finish(WaveletJob& job) {
+  --clock.unfinished;
+  finishNow(job);
+}
+
+// Every group of the block is modelled: its sections' range coders.
+void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
+  jobp->t_modelled = std::chrono::steady_clock::now();
+  std::vector<std::function<void()> > next;
+  const size_t engines = std::max<size_t>(1, std::min<size_t>(coder_tasks_, (jobp->coder->sectionTasks() + 1) / 2));
+  for (size_t q = 0; q < engines; ++q) {
+    next.push_back([this, jobp] {
+      WaveletJob& j = *jobp;
+      const auto t0 = std::chrono::steady_clock::now();
+      const size_t did = j.coder->codeSectionsPaired(&j.section_cursor, j.prob.data(), &j.outs);
+      clock.coder_ns += since(t0);
+      bool fin;
+      { std::lock_guard<std::mutex> g(j.mu); j.sections_left -= did; fin = did > 0 && j.sections_left == 0; }
+      if (fin) finish(j);
+    });
+  }
+  pool_.submit(jobp->rank, next);
+}
+
+uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t fsm8_state, char model) {
+  WaveletJob& job = *jobp;
+  job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes, fsm8_state, model));
+  const uint32_t next_state = job.coder->endState();
+  job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());
+  job.t_queued = std::chrono::steady_clock::now();
+  job.models_left = job.coder->modelTasks();
+  job.sections_left = job.coder->sectionTasks();
+  ++clock.blocks;
+  if (job.models_left == 0 || job.sections_left == 0) { finishNow(job); return next_state; }
+  ++clock.unfinished;
+  if (model == 'B' && bwtc::wavelet::simdModelsAvailable()) {
+    // Sixteen groups per thread at a time, lanes refilled across blocks (wavelet_simd.hpp,
+    // BlockGroupSource).  The block's few huge groups keep scalar tasks of their own, two groups
+    // stepped alternately per task: a lane would hold the block's range coders back for as long
+    // as the largest of them takes at a lane's pace.
+    size_t huge = 0;
+    while (huge < job.coder->modelTasks() && job.coder->taskElements(huge) >= huge_) ++huge;
+    std::vector<std::function<void()> > own;
+    for (size_t k = 0; k < huge; k += 2) {
+      const size_t k2 = k + 1 < huge ? k + 1 : k;
+      own.push_back([this, jobp, k, k2] {
+        WaveletJob& j = *jobp;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (k2 != k) j.coder->modelPair(k, k2, j.prob.data()); else j.coder->model(k, j.prob.data());
+        clock.model_ns += since(t0);
+        bool last;
+        { std::lock_guard<std::mutex> g(j.mu); j.models_left -= (k2 != k ? 2 : 1); last = j.models_left == 0; }
+        if (last) submitSections(jobp);
+      });
+    }
+    pool_.submit(job.rank, own);
+    const int prefer = huge < job.coder->modelTasks() ? groups_.add(jobp, huge, max_engines_) : 0;
+    if (prefer) {
+      pool_.submit(0, [this, prefer] {
+        const auto t0 = std::chrono::steady_clock::now();
+        bwtc::wavelet::runModelLanes(groups_, prefer);
+        clock.model_ns += since(t0);
+      });
+    }
+  } else {
+    for (size_t k = 0; k < job.coder->modelTasks(); ++k) {
+      pool_.submit(job.rank, [this, jobp, k] {
+        WaveletJob& j = *jobp;
+        const auto t0 = std::chrono::steady_clock::now();
+        j.coder->model(k, j.prob.data());
+        clock.model_ns += since(t0);
+        bool last;
+        { std::lock_guard<std::mutex> g(j.mu); last = --j.models_left == 0; }
+        if (last) submitSections(jobp);
+      });
+    }
+  }
+  return next_state;
+}
+
+}  // namespace bwtc_hip

@@ -20,7 +20,6 @@
 #include <thread>
 #include <vector>
 
-#include <hip/hip_runtime.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -110,32 +109,6 @@ class RawBuffer {
   size_t n_;
 };
 
-// Page-locked host bytes: the packed streams are copied from the device straight into the
-// block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
-class PinnedBytes {
- public:
-  PinnedBytes() : p_(nullptr), n_(0) {}
-  ~PinnedBytes() { if (p_) (void)hipHostFree(p_); }
-  PinnedBytes(const PinnedBytes&) = delete;
-  PinnedBytes& operator=(const PinnedBytes&) = delete;
-  void swap(PinnedBytes& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); }
-  bool reserve(size_t n) {
-    if (n <= n_) return true;
-    if (p_) (void)hipHostFree(p_);
-    p_ = nullptr; n_ = 0;
-    void* q = nullptr;
-    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) != hipSuccess) return false;
-    p_ = static_cast<uint8_t*>(q);
-    n_ = n + n / 8;
-    return true;
-  }
-  uint8_t* data() { return p_; }
-  size_t size() const { return n_; }
- private:
-  uint8_t* p_;
-  size_t n_;
-};
-
 struct WaveletJob;
 
 // The groups of all blocks under way, oldest block first and largest group first within a
@@ -174,10 +147,12 @@ class BlockGroupSource : public bwtc::wavelet::GroupSource {
 
 // One block between bwtc_hip_wavelet_encode_device_begin and ..._end.
 struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
+  virtual ~WaveletJob() {}
   std::vector<uint8_t> record;                       // header + section sizes, then the sections, finished in place
   bwtc::wavelet::StreamPlan plan;
   std::vector<uint32_t> coded_pos;
-  PinnedBytes codes;                                 // packed streams, copied here straight from the device
+  const uint8_t* codes = nullptr;                    // packed streams (2 bits per coded element); the owner of the
+                                                     //   bytes is whoever made the job (see DeviceWaveletJob)
   RawBuffer<uint16_t> prob;                          // probability of every coded element
   std::unique_ptr<bwtc::wavelet::StreamCoder> coder;
   std::vector<bwtc::wavelet::SectionOutput> outs;
@@ -195,6 +170,33 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
 }  // namespace bwtc_hip
 
 namespace bwtc_hip {
+
+// Everything that happens to a block on the host once its streams exist: models (lane engines
+// fed across blocks, scalar tasks for the huge groups), range coders (two chains per task), the
+// record.  Host code only -- the device side (wavelet_encoder.hip) and the CPU tests
+// (tests/cpp/host_pipeline_test.cpp) drive the same object.
+class HostPipeline {
+ public:
+  HostPipeline(unsigned threads, uint64_t huge_group_elements);
+  ~HostPipeline();                                   // joins the workers; every queued block must be finished
+  // job: record (header part), plan, coded_pos, codes, prob (room for the coded elements), rank and
+  // user_out/user_cap set.  Builds the block's coder from the carried model state and queues its
+  // work; returns the state to carry into the next block.
+  uint32_t queue(const std::shared_ptr<WaveletJob>& job, uint32_t fsm8_state, char model);
+  static void wait(WaveletJob& job);
+  // a block without coded elements (or coded elsewhere): closes the record right away
+  static void finishNow(WaveletJob& job);
+  unsigned threads() const { return pool_.size(); }
+  StageClock clock;
+ private:
+  void submitSections(const std::shared_ptr<WaveletJob>& job);
+  void finish(WaveletJob& job);
+  BlockGroupSource groups_;                          // before the pool: the workers are joined first
+  WorkerPool pool_;
+  uint64_t huge_;
+  unsigned max_engines_;
+  size_t coder_tasks_;
+};
 
 inline int BlockGroupSource::add(const std::shared_ptr<WaveletJob>& job, size_t first_group, unsigned max_engines) {
   Entry e;
