@@ -272,3 +272,18 @@ def test_wavelet_stream_route_random_sweep(oracle):
         assert got == want[skip:], ("tree route", case, kind, n)
         checked += 1
     assert checked > 150
+
+
+def test_host_pipeline_program(oracle):
+    """The host side of the 'B' block pipeline on its own (tests/cpp/host_pipeline_test.cpp):
+    several blocks under way at once, against the oracle's sequential encoder; run with the lane
+    engines and with the scalar models."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "host_pipeline_test")
+    r = subprocess.run(["make", "-C", os.path.join(root, "bwtc_amd", "host"), "../../tests/cpp/host_pipeline_test"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for simd in ("1", "0"):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, BWTC_HIP_SIMD=simd))
+        assert r.returncode == 0 and "all tests passed" in r.stdout, (simd, r.stdout + r.stderr)
