@@ -1091,6 +1091,12 @@ uint32_t StreamCoder::stateBefore(size_t s, uint32_t group) const {
 
 uint64_t StreamCoder::elements() const { return pos_[plan_.group_type.size()]; }
 
+uint64_t StreamCoder::largestSectionElements() const {
+  if (sections_.empty()) return 0;
+  const StreamPlan::Section& sec = plan_.sections[sections_[0]];          // sorted largest first
+  return pos_[sec.group_base + sec.level_first.back()] - pos_[sec.group_base];
+}
+
 void StreamCoder::model(size_t k, uint16_t* prob) const {
   const Task& t = tasks_[k];
   if (t.type == kInteger) { modelGroup<kInteger>(model_, codes_, t.begin, t.end, 0, prob); return; }

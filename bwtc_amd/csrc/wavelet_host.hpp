@@ -112,6 +112,7 @@ class StreamCoder {
   uint64_t taskElements(size_t k) const { return tasks_[k].end - tasks_[k].begin; }
   bool taskIsInteger(size_t k) const { return tasks_[k].type == kInteger; }
   size_t sectionTasks() const { return sections_.size(); }
+  uint64_t largestSectionElements() const;                // coded elements of the longest range-coder chain
   void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
   // the same for sections taken from a shared cursor, two chains at a time in one thread;
   // returns how many sections this call finished

@@ -65,7 +65,11 @@ void HostPipeline::finish(WaveletJob& job) {
 void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
   jobp->t_modelled = std::chrono::steady_clock::now();
   std::vector<std::function<void()> > next;
-  const size_t engines = std::max<size_t>(1, std::min<size_t>(coder_tasks_, (jobp->coder->sectionTasks() + 1) / 2));
+  // ... and more of them when no section dominates (256 equal sections of a block of random
+  // bytes): as many as the block's elements are multiples of its longest chain
+  const uint64_t longest = std::max<uint64_t>(1, jobp->coder->largestSectionElements());
+  const size_t balanced = static_cast<size_t>(std::min<uint64_t>(pool_.size(), jobp->coder->elements() / longest));
+  const size_t engines = std::max<size_t>(1, std::min<size_t>(std::max(coder_tasks_, balanced), (jobp->coder->sectionTasks() + 1) / 2));
   for (size_t q = 0; q < engines; ++q) {
     next.push_back([this, jobp] {
       WaveletJob& j = *jobp;
