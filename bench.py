@@ -9,6 +9,12 @@ built, see config.stages) over one synthetic block that is already resident in H
 are independent (PrecompressorBlock::sliceIntoBlocks), so rank r works on its own block
 (C4: generator seed 30 + r) and no data-path collective exists; torch.distributed is used
 only for the barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+
+The default coder is the reference's default, 'B' (BASELINE config: "Wavelet coder"): the
+device half of a step (transform, run scanner, stream kernels) takes 80 ms, the host half
+(adaptive models + range coders, serial by format) 1.6 core-seconds, so the K steps overlap --
+every block is completely encoded inside the timed region (drain() collects the last ones).
+`single_block_ms` is one block alone; `other_coder` is the all-GPU 'H' route on the same block.
 """
 import argparse
 import ctypes
