@@ -311,6 +311,7 @@ int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
   return 0;
 }
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }
+uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx) { return ctx ? ctx->eng.max_inflight : 0u; }
 
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                          const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,

@@ -100,15 +100,24 @@ __global__ __launch_bounds__(kInvTPB) void k_inv_lf(const u8* __restrict__ bwt, 
 }
 
 // splitter s = row s * kSplit.  Walk to the next splitter: nxt[s] = its index, len[s] = steps.
+// LF as computed by k_inv_lf is a permutation of the rows whatever the input, so the walk from
+// a splitter always ends (at the latest back at itself).  max_len = longest sublist: the bound
+// k_inv_check_lf uses for its own walk.
 __global__ __launch_bounds__(256) void k_inv_walk1(const u64* __restrict__ lfl, u32 n_split,
-                                                   u32* __restrict__ nxt, u32* __restrict__ len) {
+                                                   u32* __restrict__ nxt, u32* __restrict__ len,
+                                                   u32* __restrict__ max_len) {
   const u32 s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= n_split) return;
-  u32 row = (u32)lfl[(u64)s * kSplit];
-  u32 steps = 1;
-  while (row % kSplit != 0u) { row = (u32)lfl[row]; ++steps; }
-  nxt[s] = row / kSplit;
-  len[s] = steps;
+  u32 steps = 0;
+  if (s < n_split) {
+    u32 row = (u32)lfl[(u64)s * kSplit];
+    steps = 1;
+    while (row % kSplit != 0u) { row = (u32)lfl[row]; ++steps; }
+    nxt[s] = row / kSplit;
+    len[s] = steps;
+  }
+  const u32 lane = lane_id();
+  const u32 m = wave_scan_max(steps, lane);
+  if (lane == kWave - 1 && m) atomicMax(max_len, m);
 }
 
 // Pointer jumping over the splitter list.  The list is the cycle 0 -> nxt[0] -> ... -> 0; the
@@ -152,17 +161,24 @@ __global__ __launch_bounds__(256) void k_inv_walk2(const u64* __restrict__ lfl,
 // checks LF powers against the ranking: row lf[k] must sit k * (n / n_lf) steps before the end
 // of the cycle's walk from the EOB, i.e. at distance (n - k*x) from row 0 ... done on the
 // splitter level only when the row is a splitter; otherwise by a short walk.
+// A healthy block's LF is ONE cycle through all n rows: splitter 0 is then n rows from the end
+// of the walk (bad |= 2 otherwise), and any row reaches a splitter within max_len steps (a row
+// that does not lies on a cycle of its own: bad |= 1, and the walk stops there instead of
+// circling for ever).
 __global__ void k_inv_check_lf(const u64* __restrict__ lfl, const u32* __restrict__ dist,
                                const u32* __restrict__ lf, u32 n_lf, u32 n,
-                               u32* __restrict__ bad) {
+                               const u32* __restrict__ max_len, u32* __restrict__ bad) {
   const u32 k = threadIdx.x;
-  if (k == 0 || k >= n_lf) return;
+  if (k == 0) { if (dist[0] != n) atomicOr(bad, 2u); return; }
+  if (k >= n_lf) return;
   const u32 x = n / n_lf;
   // LF^j(eob) is the row of suffix n - j, which is row number (j) on the walk from row 0
   // counted as p_{j-1}: p_0 = row 0 = LF(eob).  So row lf[k] must be p_{k*x - 1}.
   u32 row = lf[k];
   u32 steps = 0;
-  while (row % kSplit != 0u) { row = (u32)lfl[row]; ++steps; }
+  const u32 limit = *max_len;
+  while (row % kSplit != 0u && steps <= limit) { row = (u32)lfl[row]; ++steps; }
+  if (row % kSplit != 0u) { atomicOr(bad, 1u); return; }
   const u32 at = n - dist[row / kSplit];          // index of that splitter on the walk
   const u32 idx = at >= steps ? at - steps : at + n - steps;
   if (idx != k * x - 1u) atomicOr(bad, 1u);
@@ -176,6 +192,7 @@ int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const
   const u32 n = size + 1u;
   const u32 eob = lf[0];
   if (eob > size) return -1;
+  for (u32 k = 1; k < n_lf; ++k) if (lf[k] > size) return -4;   // not a row of this block
   BWTC_HIP_TRY(hipSetDevice(e.device));
   BWTC_HIP_TRY(hipEventRecord(e.ev_begin, st));
 
@@ -188,7 +205,9 @@ int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const
   const u32 n_split = (n + kSplit - 1u) / kSplit;
   u32 *nxtA = e.d_V0, *nxtB = e.d_V1, *distA = e.d_G0, *distB = e.d_G1, *len = e.d_GRP;
   const u32 sblocks = ceil_div(n_split, 256);
-  hipLaunchKernelGGL(k_inv_walk1, dim3(sblocks), dim3(256), 0, st, lfl, n_split, nxtA, len);
+  BWTC_HIP_TRY(hipMemsetAsync(e.d_small, 0, 1024 * 4, st));
+  u32* d_maxlen = e.d_small + 601;
+  hipLaunchKernelGGL(k_inv_walk1, dim3(sblocks), dim3(256), 0, st, lfl, n_split, nxtA, len, d_maxlen);
   BWTC_HIP_TRY(hipMemcpyAsync(distA, len, (u64)n_split * 4, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_inv_jump_init, dim3(sblocks), dim3(256), 0, st, nxtA, n_split);
   for (u32 span = 1; span < n_split; span *= 2) {
@@ -196,12 +215,10 @@ int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const
     { u32* t = nxtA; nxtA = nxtB; nxtB = t; }
     { u32* t = distA; distA = distB; distB = t; }
   }
-  BWTC_HIP_TRY(hipMemsetAsync(e.d_small, 0, 1024 * 4, st));
-  if (n_lf > 1) {
-    BWTC_HIP_TRY(hipMemcpyAsync(e.d_small + 256, lf, n_lf * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_inv_check_lf, dim3(1), dim3(256), 0, st, lfl, distA, e.d_small + 256, n_lf, n,
-                       e.d_small + 600);
-  }
+  for (u32 k = 0; k < n_lf; ++k) e.h_small[256 + k] = lf[k];   // pinned: the async copy reads it later
+  BWTC_HIP_TRY(hipMemcpyAsync(e.d_small + 256, e.h_small + 256, n_lf * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_inv_check_lf, dim3(1), dim3(256), 0, st, lfl, distA, e.d_small + 256, n_lf, n,
+                     d_maxlen, e.d_small + 600);
   hipLaunchKernelGGL(k_inv_walk2, dim3(sblocks), dim3(256), 0, st, lfl, distA, len, n_split, n, size, e.d_out);
   BWTC_HIP_TRY(hipMemcpyAsync(d_out, e.d_out, size, hipMemcpyDeviceToDevice, st));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 600, e.d_small + 600, 4, hipMemcpyDeviceToHost, st));

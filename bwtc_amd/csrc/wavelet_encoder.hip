@@ -24,13 +24,8 @@ namespace bwtc_hip {
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
-  // bounded number of blocks under way: wait for the oldest one (its result stays collectable)
-  while (e.jobs.size() >= e.max_inflight) {
-    WaveletJob& oldest = *e.jobs.begin()->second;
-    std::unique_lock<std::mutex> g(oldest.mu);
-    if (oldest.done) return -6;                     // finished blocks must be collected with ..._end first
-    oldest.cv.wait(g, [&] { return oldest.done; });
-  }
+  // bounded number of blocks under way; only ..._end frees a place, so waiting here could never help
+  if (e.jobs.size() >= e.max_inflight) return -6;
   std::shared_ptr<DeviceWaveletJob> jobp(new DeviceWaveletJob());
   DeviceWaveletJob& job = *jobp;
   job.rank = e.next_ticket;

@@ -350,6 +350,12 @@ class WaveletEncoder : public EntropyEncoder {
  public:
   explicit WaveletEncoder(char encoder = 'B') : m_letter(encoder), m_fresh(true), m_ctx(0), m_dev(0), m_devBytes(0), m_next(0) {}
   ~WaveletEncoder() {
+    // blocks still under way write into the slots: let them finish before the slots go
+    while (m_ctx && !m_order.empty()) {
+      uint64_t n = 0;
+      (void)bwtc_hip_wavelet_encode_end(m_ctx, m_slots[m_order.front()].ticket, &n);
+      m_order.erase(m_order.begin());
+    }
     if (m_ctx && m_dev) bwtc_hip_free(m_ctx, m_dev);
     for (size_t i = 0; i < m_slots.size(); ++i) std::free(m_slots[i].rec);
   }
@@ -368,7 +374,11 @@ class WaveletEncoder : public EntropyEncoder {
     return (size_t)n;
   }
   bool overlapsBlocks() const { return true; }
-  size_t depth() const { return kDepth; }
+  // never more than the context allows (BWTC_HIP_WAVELET_DEPTH), or _begin would refuse with -6
+  size_t depth() const {
+    const size_t lim = m_ctx ? bwtc_hip_wavelet_depth(m_ctx) : (size_t)kDepth;
+    return std::max<size_t>(1, std::min<size_t>(kDepth, lim));
+  }
   size_t pending() const { return m_order.size(); }
   // device half: upload, transform on the device, run scanner + stream kernels; the models and
   // range coders of the block are queued on the context's worker threads.  The block's bytes

@@ -178,8 +178,8 @@ int bwtc_hip_wavelet_encode_device(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint
  * the CPUs the process may use -- affinity and cgroup quota -- up to 64); it returns as soon as the GPU is free for the next block.  _end waits
  * for that block; the record is then in the `out` given to _begin, *out_bytes long.  Records
  * are those of a strictly sequential encoder whatever the overlap.  At most
- * BWTC_HIP_WAVELET_DEPTH (default 16) blocks are under way; a further _begin waits for the
- * oldest, and returns -6 if that one is finished but not collected.  `out` must stay valid
+ * bwtc_hip_wavelet_depth(ctx) blocks (BWTC_HIP_WAVELET_DEPTH, default 16) are under way; a
+ * further _begin returns -6 at once: collect the oldest with _end first.  `out` must stay valid
  * until _end (or until bwtc_hip_destroy returns: it lets blocks under way finish);
  * _begin/_end of one context are called from one thread. */
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
@@ -187,6 +187,8 @@ int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt
                                          uint32_t threads, uint8_t* out, uint64_t out_cap,
                                          uint64_t* ticket);
 int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes);
+/* Blocks that may be between _begin and _end at once on this context. */
+uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 /* A new wavelet stream with the main probability model of coder letter `coder`
  * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,
