@@ -74,6 +74,21 @@ size_t orc_wavelet_encode_block_with(char coder, const uint8_t *bwt, uint32_t si
 size_t orc_compress_wavelet(char coder, const uint8_t *in, size_t size, size_t block_size,
                             uint32_t starting_points, uint8_t *out, size_t out_cap);
 
+/* Decompressor::decompress over a stream made by a wavelet coder ('B', 'b', 'u'): a literal
+ * restatement of WaveletDecoder::decodeBlock, WaveletTree::readShape / decodeTreeBF / message and
+ * BitDecoder (wavelet_oracle.c, second half).  Returns the decoded size or (size_t)-1 on
+ * malformed input; bwt_out (may be NULL) receives the transformed bytes of the blocks. */
+size_t orc_decompress_wavelet(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_cap,
+                              uint8_t *bwt_out);
+
+/* restatements of what test/WaveletTest.cpp pins with known answers (see wavelet_oracle.c) */
+void   orc_min_heap_order(const int *values, const uint64_t *weights, size_t n, int *out);
+size_t orc_create_huffman_shape(const uint64_t run_freqs[256], uint32_t *symbols, uint32_t *depths,
+                                uint8_t *code_bits, uint32_t code_len[256]);
+size_t orc_gamma_code(size_t integer, uint8_t *bits);
+size_t orc_fixed_integer_code(uint32_t x, uint32_t w, uint8_t *bits);
+void   orc_wavelet_symbol_codes(const uint64_t run_freqs[256], uint8_t *code_bits, uint32_t code_len[256]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -729,3 +729,592 @@ size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_
 {
     return orc_compress_wavelet('B', in, size, block_size, starting_points, out, out_cap);
 }
+
+/* ============================================================================================
+ * DECODER.  Literal restatement of WaveletDecoder::decodeBlock / readBlockHeader
+ * (WaveletCoders.cpp:231-306), WaveletTree::readShape (WaveletTree.hpp:403-500),
+ * decodeTreeBF (:857-1165, OPTIMIZED_INTEGER_CODE + SEMI_FIXED_CODE branches), message
+ * (:1277-1378), BitDecoder (BitCoders.cpp:115-148), the InStream bit reads (Streams.hpp:120-137)
+ * and Decompressor::decompress (Decompressor.cpp:57-100, no grammar).  It shares NOTHING with
+ * the encoder above except the models, the node pool and assignPrefixCodes -- the same things
+ * the reference's decoder shares with its encoder -- so product streams that this function
+ * decodes back to the input are streams the reference's algorithm accepts.
+ * ========================================================================================== */
+typedef struct { const uint8_t *p; size_t n, pos; uint16_t buffer; uint8_t bits_in_buffer; int overrun; } instream;
+static unsigned in_fetch(instream *s) { if (s->pos < s->n) return s->p[s->pos++]; s->overrun = 1; ++s->pos; return 0; }
+static int in_read_bit(instream *s)                                /* Streams.hpp:120-126 */
+{
+    if (s->bits_in_buffer == 0) { s->buffer = (uint16_t)in_fetch(s); s->bits_in_buffer = 8; }
+    return (s->buffer >> --s->bits_in_buffer) & 1;
+}
+static unsigned in_read_byte(instream *s)                          /* Streams.hpp:128-133 */
+{
+    const unsigned next = in_fetch(s);
+    s->buffer = (uint16_t)((s->buffer << 8) | next);
+    return (s->buffer >> s->bits_in_buffer) & 0xffu;
+}
+static void in_flush(instream *s) { s->bits_in_buffer = 0; }       /* Streams.hpp:135-137 */
+static uint64_t in_read48(instream *s) { uint64_t r = 0; int i; for (i = 0; i < 6; ++i) r = (r << 8) | in_fetch(s); return r; }   /* Streams.cpp:119-126 */
+
+/* utils::readPackedIntegerRev, Utils.hpp:148-162 */
+static size_t read_packed_rev(instream *in, size_t *bytes_read)
+{
+    size_t read = 0xff, result = 0, j = 0, i;
+    *bytes_read = 0;
+    while (read & 0x80) {
+        read = 0;
+        for (i = 0; i < 8; ++i) read |= ((size_t)in_read_bit(in) << i);
+        result |= ((read & 0x7f) << j);
+        j += 7;
+        ++*bytes_read;
+        if (in->overrun) break;
+    }
+    return result;
+}
+/* utils::readPackedInteger, Utils.hpp:164-178 (MSB-first bits) */
+static size_t read_packed(instream *in)
+{
+    size_t read = 0xff, result = 0, j = 0; int i;
+    while (read & 0x80) {
+        read = 0;
+        for (i = 7; i >= 0; --i) read |= ((size_t)in_read_bit(in) << i);
+        result |= ((read & 0x7f) << j);
+        j += 7;
+        if (in->overrun) break;
+    }
+    return result;
+}
+static unsigned log_ceiling(size_t n) { unsigned l = 0; size_t v = 1; while (v < n) { v <<= 1; ++l; } return l; }   /* utils::logCeiling */
+/* utils::binaryDecode(input, lo, hi, bitsRead), Utils.hpp:321-341 */
+static size_t binary_decode(instream *in, size_t lo, size_t hi)
+{
+    const size_t range_len = hi - lo + 1;
+    unsigned code_length; size_t short_cw, long_cw2, result = 0; int i;
+    if (range_len == 1) return lo;
+    code_length = log_ceiling(range_len);
+    short_cw = ((size_t)1 << code_length) - range_len;
+    long_cw2 = (range_len - short_cw) / 2;
+    for (i = 0; i < (int)code_length - 1; ++i) result = (result << 1) | (size_t)in_read_bit(in);
+    if (result >= long_cw2) return result + lo;
+    result = (result << 1) | (size_t)in_read_bit(in);
+    if (result < long_cw2) return result + lo;
+    return result + lo + short_cw;
+}
+/* utils::binaryInterpolativeDecode(list, input, lo, hi, elements), Utils.hpp:343-362 */
+static void interp_decode(uint32_t *list, size_t *n_list, instream *in, size_t lo, size_t hi, size_t elements)
+{
+    size_t h, r, mid;
+    if (elements == 0 || in->overrun) return;
+    if (elements == hi - lo + 1) { size_t i; for (i = lo; i <= hi; ++i) list[(*n_list)++] = (uint32_t)i; return; }
+    h = (elements - 1) / 2;
+    r = elements / 2 - h;
+    mid = binary_decode(in, lo + h, hi - h - r);
+    interp_decode(list, n_list, in, lo, mid - 1, h);
+    list[(*n_list)++] = (uint32_t)mid;
+    interp_decode(list, n_list, in, mid + 1, hi, elements - h - 1);
+}
+static size_t unary_decode(instream *in) { size_t n = 1; while (!in_read_bit(in)) { ++n; if (in->overrun) break; } return n; }   /* Utils.hpp:411-416 */
+
+/* the decoder's tree: main pool (m_root...) + the integer code tree (m_integerCodeTree) in a pool of its own */
+typedef struct {
+    nodepool pool; int root;
+    nodepool ipool; int iroot;            /* m_integerCodeTree */
+    size_t n_integer_codes;               /* m_integerCodes.size() */
+    uint32_t W;
+} dtree;
+
+static size_t count_leaves(const nodepool *p, int nd)
+{
+    size_t c = 0;
+    if (p->v[nd].left < 0 && p->v[nd].right < 0) return 1;
+    if (p->v[nd].left >= 0) c += count_leaves(p, p->v[nd].left);
+    if (p->v[nd].right >= 0) c += count_leaves(p, p->v[nd].right);
+    return c;
+}
+
+/* WaveletTree::readShape, WaveletTree.hpp:403-500.  Returns 0 on malformed input. */
+static int read_shape(dtree *t, instream *in)
+{
+    size_t max_sym = in_read_byte(in), symbols = in_read_byte(in), bytes_read = 0, max_len, i, na = 0;
+    uint32_t alphabet[257];
+    pair cl[256];
+    if (symbols == 0) symbols = 256;
+    max_len = read_packed_rev(in, &bytes_read);
+    if (symbols > max_sym + 1) return 0;
+    interp_decode(alphabet, &na, in, 0, max_sym, symbols);
+    if (na != symbols || in->overrun) return 0;
+    for (i = 0; i < symbols; ++i) {
+        const size_t n = unary_decode(in);
+        if (n > max_len) return 0;
+        cl[i].first = max_len - n + 1; cl[i].second = alphabet[i];
+    }
+    qsort(cl, symbols, sizeof(pair), cmp_pair);                    /* assignPrefixCodes(lengths) sorts, :1440-1444 */
+    t->root = np_new(&t->pool, 0, 0);
+    assign_prefix_codes(&t->pool, cl, symbols, t->root, 0, 0);
+    {
+        const size_t longest_run = read_packed_rev(in, &bytes_read);
+        if (longest_run > 0) {
+            uint32_t *integers; pair *icl; size_t ni = 0;
+            symbols = read_packed_rev(in, &bytes_read);
+            max_len = read_packed_rev(in, &bytes_read);
+            if (in->overrun || symbols == 0 || symbols > longest_run + 1) return 0;
+            integers = (uint32_t *)malloc((symbols + 1) * sizeof(uint32_t));
+            icl = (pair *)malloc((symbols + 1) * sizeof(pair));
+            interp_decode(integers, &ni, in, 0, longest_run, symbols);
+            if (ni != symbols || in->overrun) { free(integers); free(icl); return 0; }
+            for (i = 0; i < symbols; ++i) {
+                const size_t n = unary_decode(in);
+                if (n > max_len) { free(integers); free(icl); return 0; }
+                icl[i].first = max_len + 1 - n; icl[i].second = integers[i];
+            }
+            qsort(icl, symbols, sizeof(pair), cmp_pair);
+            t->iroot = np_new(&t->ipool, 0, 0);
+            assign_prefix_codes(&t->ipool, icl, symbols, t->iroot, 0, 0);
+            t->n_integer_codes = count_leaves(&t->ipool, t->iroot);   /* collectCodes: one map entry per leaf symbol */
+            free(integers); free(icl);
+        } else {
+            t->iroot = np_new(&t->ipool, 1, 0);                    /* new TreeNode(0): a leaf with symbol 0 */
+            t->n_integer_codes = 1;
+        }
+        t->W = 0;
+        for (i = 0; i < 4; ++i) t->W = (t->W << 1) | (uint32_t)in_read_bit(in);
+    }
+    return !in->overrun;
+}
+
+/* BitDecoder, BitCoders.cpp:115-148 */
+typedef struct { uint32_t low, high, next; instream *in; } rdecoder;
+static void rd_start(rdecoder *d)
+{
+    d->low = 0; d->high = 0xFFFFFFFFu;
+    d->next = in_read_byte(d->in);
+    d->next = (d->next << 8) + in_read_byte(d->in);
+    d->next = (d->next << 8) + in_read_byte(d->in);
+    d->next = (d->next << 8) + in_read_byte(d->in);
+}
+static int rd_decode(rdecoder *d, uint16_t p1)
+{
+    const uint32_t range_size = d->high - d->low - 1;              /* Split(), BitCoders.cpp:40-57 */
+    const uint32_t high_bits = range_size >> 12, low_bits = range_size & 4095u;
+    const uint32_t split = d->low + high_bits * p1 + ((low_bits * p1 + 2048u) >> 12);
+    const int bit = d->next <= split;
+    if (bit) d->high = split; else d->low = split + 1;
+    while (((d->low ^ d->high) & 0xFF000000u) == 0) {
+        d->low <<= 8;
+        d->high = (d->high << 8) + 255;
+        d->next = (d->next << 8) + in_read_byte(d->in);
+    }
+    return bit;
+}
+
+/* IntegerNode (SEMI_FIXED_CODE form), WaveletTree.hpp:838-850.  int_node = -1 is the null pointer. */
+typedef struct { int nd; int int_node; size_t bits; uint32_t leading_ones; uint8_t code_status; } intnode;
+typedef struct { intnode *v; size_t n, cap, head; } intlist;
+static void il_push(intlist *l, intnode x)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 64; l->v = (intnode *)realloc(l->v, l->cap * sizeof(intnode)); }
+    l->v[l->n++] = x;
+}
+static intnode mk_intnode(int nd, int int_node, size_t bits, uint32_t lo, uint8_t st)
+{
+    intnode x; x.nd = nd; x.int_node = int_node; x.bits = bits; x.leading_ones = lo; x.code_status = st; return x;
+}
+
+/* decodeTreeBF, WaveletTree.hpp:857-1165 */
+static int decode_tree_bf(dtree *t, size_t root_size, rdecoder *dec, model *pm, model *gm, model *gapm)
+{
+    nodepool *p = &t->pool;
+    const nodepool *ip = &t->ipool;
+    inode *queue = NULL; size_t qh = 0, qt = 0, qcap = 0;
+    intlist icn = {0, 0, 0, 0};
+    size_t i;
+#define QPUSH(x) do { if (qt == qcap) { qcap = qcap ? qcap * 2 : 64; queue = (inode *)realloc(queue, qcap * sizeof(inode)); } queue[qt++] = (x); } while (0)
+    if (root_size == 0) return 0;
+    {   /* root, :874-924 */
+        inode left, right;
+        int prev;
+        memset(&left, 0, sizeof left); memset(&right, 0, sizeof right);
+        prev = rd_decode(dec, model_p1(pm));
+        model_update(pm, prev);
+        bv_push(&p->v[t->root].bv, prev);
+        if (prev) bv_push(&right.gaps, 1); else bv_push(&left.gaps, 1);
+        for (i = 1; i < root_size; ++i) {
+            const int bit = rd_decode(dec, model_p1(pm));
+            model_update(pm, bit);
+            bv_push(&p->v[t->root].bv, bit);
+            bv_push(bit ? &right.gaps : &left.gaps, prev != bit);
+            prev = bit;
+            if (dec->in->overrun) return 0;
+        }
+        if (p->v[t->root].left < 0) return 0;                      /* "Left node has to always exist" */
+        if (p->v[p->v[t->root].left].has_symbol) { il_push(&icn, mk_intnode(p->v[t->root].left, t->iroot, left.gaps.n, 0, 0)); bv_free(&left.gaps); }
+        else { left.nd = p->v[t->root].left; QPUSH(left); }
+        if (right.gaps.n > 0) {
+            if (p->v[t->root].right < 0) return 0;
+            if (p->v[p->v[t->root].right].has_symbol) { il_push(&icn, mk_intnode(p->v[t->root].right, t->iroot, right.gaps.n, 0, 0)); bv_free(&right.gaps); }
+            else { right.nd = p->v[t->root].right; QPUSH(right); }
+        } else bv_free(&right.gaps);
+    }
+    while (qh < qt) {                                              /* internal nodes, :927-1021 */
+        inode left, right, node = queue[qh];
+        const int nl = p->v[node.nd].left, nr = p->v[node.nd].right;
+        memset(&left, 0, sizeof left); memset(&right, 0, sizeof right);
+        model_reset(pm); model_reset(gapm);
+        if (nl < 0 || nr < 0) return 0;                            /* "Node must have both left and right child" */
+        if (p->v[nl].has_symbol || p->v[nr].has_symbol) {
+            if (p->v[nl].has_symbol && p->v[nr].has_symbol) {
+                size_t ones = 0; int prev = 1;
+                for (i = 0; i < node.gaps.n; ++i) {
+                    if (!node.gaps.b[i]) prev = !prev;
+                    else { prev = rd_decode(dec, model_p1(gapm)); model_update(gapm, prev); }
+                    bv_push(&p->v[node.nd].bv, prev);
+                    if (prev) ++ones;
+                }
+                il_push(&icn, mk_intnode(nl, t->iroot, node.gaps.n - ones, 0, 0));
+                il_push(&icn, mk_intnode(nr, t->iroot, ones, 0, 0));
+            } else {
+                int prev = 1;
+                if (p->v[nr].has_symbol) return 0;                 /* assert(!node.first->m_right->m_hasSymbol) */
+                for (i = 0; i < node.gaps.n; ++i) {
+                    int bit;
+                    if (!node.gaps.b[i] && !prev) bit = 1;
+                    else if (node.gaps.b[i]) { bit = rd_decode(dec, model_p1(gapm)); model_update(gapm, bit); model_update_state(pm, bit); }
+                    else { bit = rd_decode(dec, model_p1(pm)); model_update(pm, bit); }
+                    bv_push(&p->v[node.nd].bv, bit);
+                    if (bit) bv_push(&right.gaps, prev != bit || node.gaps.b[i]);
+                    prev = bit;
+                }
+                il_push(&icn, mk_intnode(nl, t->iroot, node.gaps.n - right.gaps.n, 0, 0));
+                right.nd = nr; QPUSH(right);
+            }
+        } else {
+            int prev = 1;
+            for (i = 0; i < node.gaps.n; ++i) {
+                int bit;
+                if (node.gaps.b[i]) { bit = rd_decode(dec, model_p1(gapm)); model_update(gapm, bit); model_update_state(pm, bit); }
+                else { bit = rd_decode(dec, model_p1(pm)); model_update(pm, bit); }
+                bv_push(&p->v[node.nd].bv, bit);
+                bv_push(bit ? &right.gaps : &left.gaps, prev != bit || node.gaps.b[i]);
+                prev = bit;
+            }
+            left.nd = nl; QPUSH(left);
+            right.nd = nr; QPUSH(right);
+        }
+        bv_free(&queue[qh].gaps);
+        ++qh;
+        if (dec->in->overrun) return 0;
+    }
+    {   /* integer-code nodes, :1024-1163 */
+        intlist lefts = {0, 0, 0, 0}, rights = {0, 0, 0, 0};
+        while (icn.head < icn.n || lefts.n || rights.n) {
+            model_reset(gm);
+            while (icn.head < icn.n) {
+                intnode node = icn.v[icn.head++];
+                size_t ones = 0;
+                if (node.int_node >= 0 && ip->v[node.int_node].has_symbol) {
+                    p->v[node.nd].has_symbol = 1;
+                    if (t->n_integer_codes > 1) p->v[node.nd].symbol = ip->v[node.int_node].symbol;
+                    if (ip->v[node.int_node].symbol != 0) continue;
+                }
+                for (i = 0; i < node.bits; ++i) {
+                    const int bit = rd_decode(dec, model_p1(gm));
+                    model_update(gm, bit);
+                    if (bit) ++ones;
+                    bv_push(&p->v[node.nd].bv, bit);
+                }
+                if (dec->in->overrun) return 0;
+                if (node.bits > ones) {
+                    intnode ln;
+                    const int il = node.int_node >= 0 ? ip->v[node.int_node].left : -1;
+                    if (p->v[node.nd].left < 0) { int c = np_new(p, 0, 0); p->v[node.nd].left = c; }
+                    ln = mk_intnode(p->v[node.nd].left, il, node.bits - ones, node.leading_ones, node.code_status);
+                    if (node.int_node < 0 || il < 0) {
+                        if (node.code_status == 0) { ln.code_status = 2; ln.leading_ones = t->W; }
+                        else if (node.code_status == 1) { ln.code_status = 2; ln.leading_ones += t->W; }
+                        else --ln.leading_ones;
+                    }
+                    if (ln.code_status != 2 || ln.leading_ones > 0) il_push(&lefts, ln);
+                }
+                if (ones > 0) {
+                    intnode rn;
+                    const int ir = node.int_node >= 0 ? ip->v[node.int_node].right : -1;
+                    if (p->v[node.nd].right < 0) { int c = np_new(p, 0, 0); p->v[node.nd].right = c; }
+                    rn = mk_intnode(p->v[node.nd].right, ir, ones, node.leading_ones, node.code_status);
+                    if (node.int_node < 0 || ir < 0) {
+                        if (node.code_status == 0) { rn.code_status = 1; ++rn.leading_ones; }
+                        else if (node.code_status == 1) ++rn.leading_ones;
+                        else --rn.leading_ones;
+                    }
+                    if (rn.code_status != 2 || rn.leading_ones > 0) il_push(&rights, rn);
+                }
+            }
+            for (i = 0; i < lefts.n; ++i) il_push(&icn, lefts.v[i]);    /* splice(end, left); splice(end, right) */
+            for (i = 0; i < rights.n; ++i) il_push(&icn, rights.v[i]);
+            lefts.n = rights.n = 0;
+        }
+        free(lefts.v); free(rights.v);
+    }
+    free(icn.v); free(queue);
+#undef QPUSH
+    return 1;
+}
+
+/* message, WaveletTree.hpp:1277-1378.  bitsSeen (a std::map keyed by node) is an array over the
+ * pool.  Returns the bytes written, or (size_t)-1 when the tree does not describe `cap` bytes. */
+static size_t tree_message(const dtree *t, uint8_t *out, size_t cap)
+{
+    const nodepool *p = &t->pool;
+    size_t *seen = (size_t *)calloc((size_t)p->n + 1, sizeof(size_t));
+    const size_t msg_size = p->v[t->root].bv.n;
+    size_t len = 0, j, k;
+#define BITAT(nd, i) ((nd) < 0 || (i) >= p->v[nd].bv.n ? (bad = 1, 0) : p->v[nd].bv.b[i])
+    int bad = 0;
+    for (j = 0; j < msg_size && !bad; ++j) {
+        int bit, nd = t->root;
+        size_t i = j, run_length = 0;
+        uint8_t symbol;
+        do {
+            bit = BITAT(nd, i);
+            if (bit) i = seen[nd]++; else i = i - seen[nd];
+            nd = bit ? p->v[nd].right : p->v[nd].left;
+        } while (!bad && nd >= 0 && !p->v[nd].has_symbol);
+        if (bad || nd < 0) { bad = 1; break; }
+        symbol = (uint8_t)p->v[nd].symbol;
+        if (!t->ipool.v[t->iroot].has_symbol) {                    /* not plain gamma codes */
+            do {
+                bit = BITAT(nd, i);
+                if (bit) { i = seen[nd]++; nd = p->v[nd].right; }
+                else { i = i - seen[nd]; nd = p->v[nd].left; }
+            } while (!bad && nd >= 0 && !p->v[nd].has_symbol);
+            if (bad || nd < 0) { bad = 1; break; }
+            run_length = p->v[nd].symbol;
+        }
+        if (run_length == 0) {
+            size_t leading_ones = 0;
+            bit = BITAT(nd, i);
+            while (bit && !bad) {
+                ++leading_ones;
+                i = seen[nd]++;
+                nd = bit ? p->v[nd].right : p->v[nd].left;
+                bit = BITAT(nd, i);
+            }
+            for (k = 0; k < leading_ones + t->W && !bad; ++k) {
+                run_length <<= 1;
+                if (bit) i = seen[nd]++; else i = i - seen[nd];
+                nd = bit ? p->v[nd].right : p->v[nd].left;
+                bit = BITAT(nd, i);
+                run_length |= (size_t)(bit ? 1 : 0);
+            }
+            run_length += 1 + ((((size_t)1 << leading_ones) - 1) << t->W);   /* fixedIntegerCodeTranslation */
+        }
+        if (bad || len + run_length > cap) { bad = 1; break; }
+        memset(out + len, symbol, run_length);
+        len += run_length;
+    }
+#undef BITAT
+    free(seen);
+    return bad ? (size_t)-1 : len;
+}
+
+static void dtree_free(dtree *t)
+{
+    int i;
+    for (i = 0; i < t->pool.n; ++i) bv_free(&t->pool.v[i].bv);
+    free(t->pool.v);
+    for (i = 0; i < t->ipool.n; ++i) bv_free(&t->ipool.v[i].bv);
+    free(t->ipool.v);
+}
+
+/* WaveletDecoder::readPackedInteger + utils::unpackInteger, WaveletCoders.cpp:290-306, Utils.cpp:103-118 */
+static uint64_t read_packed_bytes(instream *in)
+{
+    uint64_t v = 0; int shift = 0, more = 1;
+    while (more && !in->overrun) {
+        const unsigned b = in_read_byte(in);
+        more = (b & 0x80) != 0;
+        v |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+    }
+    return v;
+}
+
+/* Decompressor::decompress (Decompressor.cpp:57-100) over a stream made by a wavelet coder: global
+ * header letter -> model (giveEntropyDecoder / giveProbabilityModel), precompressor block headers
+ * with an empty grammar, WaveletDecoder::decodeBlock per slice, inverse transform.  Returns the
+ * decoded size, or (size_t)-1 on malformed input.  If bwt_out is not NULL the transformed bytes
+ * of the blocks (before the inverse transform) are copied there as well. */
+size_t orc_decompress_wavelet(const uint8_t *in_bytes, size_t in_size, uint8_t *out, size_t out_cap, uint8_t *bwt_out)
+{
+    instream in;
+    model pm, gm, gapm;
+    rdecoder dec;
+    size_t opos = 0;
+    memset(&in, 0, sizeof in);
+    in.p = in_bytes; in.n = in_size;
+    if (in_size < 2) return (size_t)-1;
+    if (!model_init((char)in_read_byte(&in), &pm, &gm, &gapm)) return (size_t)-1;
+    dec.in = &in;
+    for (;;) {
+        const size_t orig = read_packed(&in);
+        size_t slices, s;
+        if (in.overrun) return (size_t)-1;
+        if (orig == 0) break;
+        slices = read_packed(&in);
+        if (in_read_byte(&in) != 0) return (size_t)-1;            /* grammar with rules: not on this path */
+        for (s = 0; s < slices; ++s) {
+            const uint64_t clen48 = in_read48(&in);                /* readBlockHeader, :231-244 */
+            const size_t start = in.pos;
+            uint32_t n_lf = in_read_byte(&in) + 1, lf[256], i, nsec, j;
+            uint64_t sect[256];
+            size_t bsize = 0, len = 0;
+            uint8_t *blk = out + opos;
+            for (i = 0; i < n_lf; ++i) { uint32_t pos = 0; for (j = 0; j < 31; ++j) pos = (pos << 1) | (uint32_t)in_read_bit(&in); lf[i] = pos; }
+            in_flush(&in);                                         /* BWTBlock::readHeader, BWTBlock.cpp:88-102 */
+            nsec = in_read_byte(&in); if (nsec == 0) nsec = 256;
+            for (i = 0; i < nsec; ++i) { sect[i] = read_packed_bytes(&in); bsize += sect[i]; }
+            if (in.overrun || opos + bsize > out_cap) return (size_t)-1;
+            for (i = 0; i < nsec; ++i) {                           /* decodeBlock, :246-288 */
+                dtree t;
+                size_t root_size, clen;
+                int ok;
+                if (sect[i] == 0) continue;
+                root_size = (size_t)read_packed_bytes(&in);
+                memset(&t, 0, sizeof t);
+                ok = read_shape(&t, &in);
+                if (ok) {
+                    in_flush(&in);
+                    rd_start(&dec);
+                    ok = decode_tree_bf(&t, root_size, &dec, &pm, &gm, &gapm);
+                }
+                clen = ok ? tree_message(&t, blk + len, bsize - len) : (size_t)-1;
+                dtree_free(&t);
+                if (clen == (size_t)-1 || clen != sect[i]) return (size_t)-1;
+                len += clen;
+                model_reset(&pm); model_reset(&gm); model_reset(&gapm);   /* endContextBlock, :70-75 */
+            }
+            if (len != bsize || in.pos - start != clen48) return (size_t)-1;
+            if (bwt_out) memcpy(bwt_out + opos, blk, bsize);
+            if (orc_inverse_bwt_block(blk, (uint32_t)bsize, lf, n_lf) != 0) return (size_t)-1;
+            opos += bsize;
+        }
+    }
+    return opos;
+}
+
+/* ============================================================================================
+ * Pieces the reference's own unit tests pin with known answers (test/WaveletTest.cpp:46-74
+ * HeapTest1-2, :116-198 HuffmanShape1-4, :427-449 GammaCodes), restated so that those answers
+ * (tests/golden/wavelet_known_answers.json) can be checked here.  createHuffmanShape is NOT what
+ * the WaveletTree constructor uses (that is calculateHuffmanLengths + assignPrefixCodes, above);
+ * the shapes' DEPTHS are what both must agree on, and tests/test_oracle.py checks exactly that.
+ * ========================================================================================== */
+/* MinimumHeap<T>, WaveletTree.hpp:1386-1438: (value, weight) pairs, sift-up on insert with a
+ * strict '>' test, heapify preferring the RIGHT child on equal weights ((wl < wr) ? left : right) */
+typedef struct { int value; size_t weight; } hpair;
+typedef struct { hpair *v; size_t n, cap; } minheap;
+static void mh_insert(minheap *h, int value, size_t weight)
+{
+    size_t index = h->n;
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 16; h->v = (hpair *)realloc(h->v, h->cap * sizeof(hpair)); }
+    ++h->n;
+    while (index > 0 && h->v[(index - 1) / 2].weight > weight) { h->v[index] = h->v[(index - 1) / 2]; index = (index - 1) / 2; }
+    h->v[index].value = value; h->v[index].weight = weight;
+}
+static void mh_heapify(minheap *h, size_t index)
+{
+    const size_t l = 2 * index + 1, r = 2 * index + 2;
+    if (h->n > r) {
+        const size_t smaller = (h->v[l].weight < h->v[r].weight) ? l : r;
+        if (h->v[smaller].weight < h->v[index].weight) { hpair t = h->v[index]; h->v[index] = h->v[smaller]; h->v[smaller] = t; mh_heapify(h, smaller); }
+    } else if (h->n == r && h->v[l].weight < h->v[index].weight) {
+        hpair t = h->v[index]; h->v[index] = h->v[l]; h->v[l] = t;
+    }
+}
+static hpair mh_delete_min(minheap *h)
+{
+    hpair min = h->v[0];
+    h->v[0] = h->v[h->n - 1];
+    --h->n;
+    mh_heapify(h, 0);
+    return min;
+}
+/* inserts (values[i], weights[i]) in order, then deletes everything: out[] = values in deletion order */
+void orc_min_heap_order(const int *values, const uint64_t *weights, size_t n, int *out)
+{
+    minheap h = {0, 0, 0}; size_t i;
+    for (i = 0; i < n; ++i) mh_insert(&h, values[i], (size_t)weights[i]);
+    for (i = 0; i < n; ++i) out[i] = mh_delete_min(&h).value;
+    free(h.v);
+}
+static void shape_walk(const nodepool *p, int nd, int depth, uint8_t *path, uint32_t *symbols, uint32_t *depths,
+                       uint8_t *code_bits, uint32_t *code_len, size_t *n)
+{                                                                  /* checkHuffmanShape / collectCodes order: left first */
+    if (p->v[nd].left < 0 && p->v[nd].right < 0) {
+        symbols[*n] = p->v[nd].symbol; depths[*n] = (uint32_t)depth;
+        memcpy(code_bits + 64 * p->v[nd].symbol, path, (size_t)depth); code_len[p->v[nd].symbol] = (uint32_t)depth;
+        ++*n; return;
+    }
+    if (p->v[nd].left >= 0) { path[depth] = 0; shape_walk(p, p->v[nd].left, depth + 1, path, symbols, depths, code_bits, code_len, n); }
+    if (p->v[nd].right >= 0) { path[depth] = 1; shape_walk(p, p->v[nd].right, depth + 1, path, symbols, depths, code_bits, code_len, n); }
+}
+/* createHuffmanShape(runFreqs) + collectCodes, WaveletTree.hpp:1496-1550: leaves left to right
+ * (symbols[], depths[]), and code_bits[64 * symbol + i] / code_len[symbol].  Returns the leaves. */
+size_t orc_create_huffman_shape(const uint64_t run_freqs[256], uint32_t *symbols, uint32_t *depths,
+                                uint8_t *code_bits, uint32_t code_len[256])
+{
+    nodepool p = {0, 0, 0}; minheap h = {0, 0, 0};
+    uint8_t path[300]; size_t n = 0; int b, root;
+    memset(code_len, 0, 256 * sizeof(uint32_t));
+    for (b = 0; b < 256; ++b) if (run_freqs[b] != 0) mh_insert(&h, np_new(&p, 1, (uint32_t)b), (size_t)run_freqs[b]);
+    if (h.n == 0) { free(p.v); free(h.v); return 0; }
+    if (h.n == 1) {                                                /* TreeNode(left = the only leaf, right = 0) */
+        const int leaf = mh_delete_min(&h).value, r = np_new(&p, 0, 0);
+        p.v[r].left = leaf;
+        mh_insert(&h, r, 1);
+    }
+    while (h.n > 1) {
+        const hpair p1 = mh_delete_min(&h), p2 = mh_delete_min(&h);
+        const int nd = np_new(&p, 0, 0);
+        p.v[nd].left = p2.value; p.v[nd].right = p1.value;        /* TreeNode(p2.first, p1.first) */
+        mh_insert(&h, nd, p1.weight + p2.weight);
+    }
+    root = mh_delete_min(&h).value;
+    shape_walk(&p, root, 0, path, symbols, depths, code_bits, code_len, &n);
+    free(p.v); free(h.v);
+    return n;
+}
+/* gammaCode, WaveletTree.hpp:541-551 (one bit per byte) */
+size_t orc_gamma_code(size_t integer, uint8_t *bits)
+{
+    const int lg = (int)log_floor64(integer); size_t n = 0; int i;
+    for (i = 0; i < lg; ++i) bits[n++] = 1;
+    bits[n++] = 0;
+    for (i = lg - 1; i >= 0; --i) bits[n++] = (uint8_t)((integer >> i) & 1);
+    return n;
+}
+/* fixedIntegerCode(bits, x, w), the code the SEMI_FIXED_CODE path actually pushes (:514-526);
+ * "when W=0, the code is standard gamma-code" (:512) */
+size_t orc_fixed_integer_code(uint32_t x, uint32_t w, uint8_t *bits)
+{
+    bitvec v = {0, 0, 0}; size_t n;
+    fixed_integer_code(&v, x, w);
+    n = v.n; memcpy(bits, v.b, n); bv_free(&v);
+    return n;
+}
+/* the code lengths the WaveletTree constructor gives the symbols (calculateHuffmanLengths +
+ * assignPrefixCodes, :302-307): code_bits[64 * symbol + i] / code_len[symbol] */
+void orc_wavelet_symbol_codes(const uint64_t run_freqs[256], uint8_t *code_bits, uint32_t code_len[256])
+{
+    pair cl[256]; size_t n_sym = 0, i; nodepool p = {0, 0, 0}; int root;
+    bitvec codes[256], path = {0, 0, 0};
+    memset(codes, 0, sizeof codes); memset(code_len, 0, 256 * sizeof(uint32_t));
+    for (i = 0; i < 256; ++i) if (run_freqs[i]) { cl[n_sym].first = run_freqs[i]; cl[n_sym].second = (uint32_t)i; ++n_sym; }
+    if (!n_sym) return;
+    calculate_code_lengths(cl, n_sym, 0);
+    qsort(cl, n_sym, sizeof(pair), cmp_pair);
+    root = np_new(&p, 0, 0);
+    assign_prefix_codes(&p, cl, n_sym, root, 0, 0);
+    collect_codes_sym(&p, root, &path, codes);
+    for (i = 0; i < 256; ++i) { code_len[i] = (uint32_t)codes[i].n; if (codes[i].n) memcpy(code_bits + 64 * i, codes[i].b, codes[i].n); bv_free(&codes[i]); }
+    bv_free(&path); free(p.v);
+}

@@ -118,6 +118,57 @@ int main() {
       CHECK(off == data.size(), "coder '%c' stream length (input %zu)", *letter, k);
     }
   }
+  // The matrix of test/CompressorAndDecompressorTest.cpp:61-160 across the boundary, reference
+  // algorithm -> product: streams written by the oracle's literal encoder (sizes 100..100 000,
+  // repetitions 0 / 2 / 50, one and several blocks, 1..30 starting points) through the product's
+  // decoder; and each of them through the oracle's literal decoder as well.
+  {
+    struct Case { size_t length, reps, block; uint32 sp; };
+    std::vector<Case> cases;
+    const size_t lengths[4] = {100, 1000, 10000, 100000}, repss[3] = {0, 2, 50};
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 3; ++b) {
+        Case c1 = {lengths[a], repss[b], (size_t)(lengths[a] * 100 * 0.185), 1};
+        Case c2 = {lengths[a], repss[b], std::max<size_t>((size_t)(lengths[a] * (repss[b] != 2 ? 10 : 1) * 0.185), 18), 1};
+        cases.push_back(c1); cases.push_back(c2);
+      }
+    for (uint32 sp = 1; sp <= 30; ++sp) { Case c = {10000, 0, (size_t)(100000 * 0.185), sp}; cases.push_back(c); }
+    for (size_t ci = 0; ci < cases.size(); ++ci) {
+      const Case& c = cases[ci];
+      std::vector<byte> data;
+      const size_t unit = c.reps ? c.length / c.reps : c.length;
+      for (size_t i = 0; i < unit; ++i) data.push_back((byte)rng());
+      for (size_t r = 1; r < c.reps; ++r) for (size_t i = 0; i < unit; ++i) data.push_back(data[i]);
+      std::vector<byte> whole(orc_compress_bound(data.size()) + 8192 * (data.size() / c.block + 2));
+      const size_t sn = orc_compress_B(&data[0], data.size(), c.block, c.sp, &whole[0], whole.size());
+      std::vector<byte> viaOracle(data.size() + 16);
+      CHECK(orc_decompress_wavelet(&whole[0], sn, &viaOracle[0], viaOracle.size(), 0) == data.size() &&
+            std::memcmp(&viaOracle[0], &data[0], data.size()) == 0, "oracle decoder, case %zu", ci);
+      MemoryBitReader in(&whole[0], sn);
+      CHECK(in.readByte() == 'B', "global header");
+      WaveletDecoder dec('B');
+      size_t off = 0;
+      for (;;) {
+        const uint64 n = in.readPackedInteger();
+        if (n == 0) break;
+        CHECK(in.readPackedInteger() == 1 && in.readByte() == 0, "block prefix");
+        std::vector<byte> t(data.begin() + off, data.begin() + off + n);
+        t.push_back(0);
+        std::vector<uint32> lf(256);
+        uint32 n_lf = 0, freqs[256];
+        std::memset(freqs, 0, sizeof freqs);
+        orc_bwt_block(&t[0], (uint32)n, c.sp, &lf[0], &n_lf, freqs);
+        std::vector<byte> out(n + 16);
+        BWTBlock block(&out[0], 0, true);
+        dec.decodeBlock(block, in, n);
+        CHECK(block.size() == n && std::memcmp(&out[0], &t[0], n) == 0, "matrix case %zu (len %zu reps %zu block %zu sp %u), block at %zu",
+              ci, c.length, c.reps, c.block, c.sp, off);
+        CHECK(block.LFpowers().size() == n_lf && std::memcmp(&block.LFpowers()[0], &lf[0], n_lf * 4) == 0, "matrix case %zu LF powers", ci);
+        off += n;
+      }
+      CHECK(off == data.size(), "matrix case %zu stream length", ci);
+    }
+  }
   std::printf(failures ? "%d FAILURES\n" : "wavelet decoder: all tests passed\n", failures);
   return failures ? 1 : 0;
 }

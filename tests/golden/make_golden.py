@@ -59,10 +59,11 @@ def main():
     add("dna4k", synth.gen_dna(4000, 2), 8)
     add("size256", rng.integers(0, 256, 256).astype(np.uint8), 8)
     add("size257", rng.integers(0, 256, 257).astype(np.uint8), 8)
-    with open(os.path.join(HERE, "bwt_small.json"), "w") as f:
-        json.dump({"generator": "tests/golden/make_golden.py (reference libdivsufsort via oracle/_ref)",
-                   "cases": cases}, f, indent=0)
-    print("wrote %d cases" % len(cases))
+    if "--large-only" not in sys.argv:
+        with open(os.path.join(HERE, "bwt_small.json"), "w") as f:
+            json.dump({"generator": "tests/golden/make_golden.py (reference libdivsufsort via oracle/_ref)",
+                       "cases": cases}, f, indent=0)
+        print("wrote %d cases" % len(cases))
 
     # Larger blocks: checksum only.
     import hashlib
@@ -71,13 +72,19 @@ def main():
                                       ("C2_dna_4MiB", synth.gen_dna, 4 << 20, 2, 8),
                                       ("C3_text_4MiB", synth.gen_text, 4 << 20, 3, 8),
                                       ("C3_text_16MiB", synth.gen_text, 16 << 20, 3, 8),
-                                      ("C2_dna_64MiB", synth.gen_dna, 64 << 20, 2, 8)]:
+                                      ("C2_dna_64MiB", synth.gen_dna, 64 << 20, 2, 8),
+                                      ("C3_text_256MiB", synth.gen_text, 256 << 20, 3, 8)]:
         d = gen(size, seed)
         bwt, lf, freqs = oracle_lib.ref_bwt_block(d, sp)
         # 'H' record of the block: the oracle's encoder (pinned by the reference's golden
         # stream in streams.json) over the reference's BWT output
         rec = oracle_lib.oracle_huffman_encode_block(bwt, lf, freqs)
+        # 'B' record (the default coder, BASELINE config 3): the oracle's literal WaveletEncoder
+        # over the reference's BWT output, a fresh encoder per block
+        brec = oracle_lib.oracle_wavelet_encode_block(bwt, lf, freqs)
         big.append({"name": name, "gen": gen.__name__, "size": size, "seed": seed, "sp": sp,
+                    "b_record_bytes": int(brec.size),
+                    "b_record_sha256": hashlib.sha256(brec.tobytes()).hexdigest(),
                     "input_sha256": hashlib.sha256(d.tobytes()).hexdigest(),
                     "bwt_sha256": hashlib.sha256(bwt.tobytes()).hexdigest(),
                     "lf": [int(x) for x in lf],

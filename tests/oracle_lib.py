@@ -77,6 +77,18 @@ def lib():
         L.orc_wavelet_encode_block.argtypes = [_vp, _u32, _vp, _u32, _vp, _vp, _sz]
         L.orc_compress_bound.restype = _sz
         L.orc_compress_bound.argtypes = [_sz]
+        L.orc_decompress_wavelet.restype = _sz
+        L.orc_decompress_wavelet.argtypes = [_vp, _sz, _vp, _sz, _vp]
+        L.orc_min_heap_order.restype = None
+        L.orc_min_heap_order.argtypes = [_vp, _vp, _sz, _vp]
+        L.orc_create_huffman_shape.restype = _sz
+        L.orc_create_huffman_shape.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        L.orc_gamma_code.restype = _sz
+        L.orc_gamma_code.argtypes = [_sz, _vp]
+        L.orc_fixed_integer_code.restype = _sz
+        L.orc_fixed_integer_code.argtypes = [_u32, _u32, _vp]
+        L.orc_wavelet_symbol_codes.restype = None
+        L.orc_wavelet_symbol_codes.argtypes = [_vp, _vp, _vp]
         _lib = L
     return _lib
 
@@ -222,3 +234,16 @@ def oracle_decompress_H(stream, max_size):
     if n == ctypes.c_size_t(-1).value:
         return None
     return out[:n].copy()
+
+
+def oracle_decompress_wavelet(stream, max_size, want_bwt=False):
+    """Decompressor::decompress over a 'B' / 'b' / 'u' stream by the oracle's literal decoder;
+    None on malformed input.  want_bwt: also return the blocks' transformed bytes."""
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    out = np.zeros(max(max_size, 1), np.uint8)
+    bwt = np.zeros(max(max_size, 1), np.uint8) if want_bwt else None
+    n = lib().orc_decompress_wavelet(_ptr(stream), stream.size, _ptr(out), out.size,
+                                     _ptr(bwt) if want_bwt else None)
+    if n == ctypes.c_size_t(-1).value:
+        return (None, None) if want_bwt else None
+    return (out[:n].copy(), bwt[:n].copy()) if want_bwt else out[:n].copy()

@@ -90,6 +90,8 @@ def test_bwt_block_small_goldens(hip_ctx):
 
 def test_bwt_block_large_goldens(hip_ctx):
     for c in _load("bwt_large.json")["cases"]:
+        if c["size"] > (64 << 20):
+            continue                      # C3_text_256MiB: test_baseline_full_size_256MiB_text* below
         d = getattr(synth, c["gen"])(c["size"], c["seed"])
         assert hashlib.sha256(d.tobytes()).hexdigest() == c["input_sha256"]
         bwt, lf, freqs = hip_ctx.bwt_block(d, c["sp"])
@@ -169,6 +171,8 @@ def test_baseline_full_size_256MiB_text(oracle):
         st = ctx.stats()
     assert lf.size == 8
     assert (freqs == np.bincount(d, minlength=256)).all()
+    pin = [c for c in _load("bwt_large.json")["cases"] if c["name"] == "C3_text_256MiB"][0]
+    assert hashlib.sha256(bwt.tobytes()).hexdigest() == pin["bwt_sha256"] and [int(x) for x in lf] == pin["lf"]
     rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
     assert rc == 0
     assert hashlib.sha256(inv.tobytes()).digest() == hashlib.sha256(d.tobytes()).digest()
@@ -178,6 +182,34 @@ def test_baseline_full_size_256MiB_text(oracle):
         assert hashlib.sha256(rb.tobytes()).digest() == hashlib.sha256(bwt.tobytes()).digest()
         assert (rlf == lf).all() and (rfr == freqs).all()
     print("256MiB text: %.1f ms device, rounds %d, R_eff %.2f" % (st.ms_total, st.rounds, st.active_sum / st.n))
+
+
+def test_baseline_full_size_256MiB_text_B_record_equals_oracle(oracle):
+    """BASELINE.json config 3 through the default coder at FULL size: the 'B' record of the
+    256 MiB text block (544 M steps through the stream kernels, the huge-group scalar tasks at
+    their real threshold) byte for byte against the oracle's literal WaveletEncoder, and against
+    the SHA-256 committed in tests/golden/bwt_large.json.  The oracle encodes the transformed
+    block in about half a minute on one core."""
+    import json
+    from bwtc_amd import hip
+    size = 256 << 20
+    d = synth.gen_text(size, 3)
+    with hip.Context(0, size) as ctx:
+        ctx.wavelet_reset()
+        rec, bwt = ctx.transform_and_encode_wavelet(d, 8)
+        lf, freqs = None, np.bincount(d, minlength=256).astype(np.uint32)
+        bwt2, lf, freqs2 = ctx.bwt_block(d, 8)
+    assert (bwt == bwt2).all() and (freqs == freqs2).all()
+    del bwt2, d
+    want = oracle.oracle_wavelet_encode_block(bwt, lf, freqs)
+    assert rec.size == want.size, (rec.size, want.size)
+    assert rec.tobytes() == want.tobytes()
+    sha = hashlib.sha256(rec.tobytes()).hexdigest()
+    print("256MiB text 'B' record: %d bytes, sha256 %s" % (rec.size, sha))
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bwt_large.json")))
+    pins = [c for c in g["cases"] if c["name"] == "C3_text_256MiB"]
+    assert pins, "C3_text_256MiB missing from bwt_large.json"
+    assert pins[0]["b_record_bytes"] == rec.size and pins[0]["b_record_sha256"] == sha
 
 
 def test_baseline_1GiB_single_block_round_trip():

@@ -86,11 +86,18 @@ def test_baseline_configs_bwt_and_H_record(hip_ctx):
     cases = json.load(open(os.path.join(G, "bwt_large.json")))["cases"]
     assert any(c["name"] == "C2_dna_64MiB" for c in cases)
     for c in cases:
+        if c["size"] > (64 << 20):
+            continue                      # the 256 MiB block has tests of its own (test_gpu_bwt.py)
         d = getattr(synth, c["gen"])(c["size"], c["seed"])
         rec, bwt = hip_ctx.transform_and_encode(d, c["sp"])
         assert hashlib.sha256(bwt.tobytes()).hexdigest() == c["bwt_sha256"], c["name"]
         assert rec.size == c["h_record_bytes"], c["name"]
         assert hashlib.sha256(rec.tobytes()).hexdigest() == c["h_record_sha256"], c["name"]
+        # the default coder's record: the oracle's literal WaveletEncoder over the reference's BWT
+        hip_ctx.wavelet_reset()
+        brec, _ = hip_ctx.transform_and_encode_wavelet(d, c["sp"])
+        assert brec.size == c["b_record_bytes"], c["name"]
+        assert hashlib.sha256(brec.tobytes()).hexdigest() == c["b_record_sha256"], c["name"]
 
 
 def test_wavelet_run_scanner_matches_oracle(hip_ctx, oracle):
@@ -338,3 +345,38 @@ def test_wavelet_B_huge_group_tasks_at_test_size(oracle):
         assert _frame(b"B", rec.tobytes(), data.size) == oracle.oracle_compress_B(data, data.size, 8).tobytes()
     finally:
         ctx.close()
+
+
+def test_wavelet_streams_cross_decode_with_the_oracle_decoder(hip_ctx, oracle):
+    """test/CompressorAndDecompressorTest.cpp:61-160 run across the boundary: streams written by
+    the product (GPU transform + stream kernels + host models / range coder) are decoded by the
+    oracle's LITERAL restatement of the reference decoder (readShape, decodeTreeBF, message,
+    BitDecoder) -- sizes 100..100 000, repetitions 0 / 2 / 50, one and several blocks, 1..30
+    starting points.  (The other direction -- oracle-encoded, product-decoded -- is
+    tests/cpp/wavelet_decoder_test.cpp in the CPU suite.)"""
+    rng = np.random.default_rng(99)
+
+    def make(length, reps):
+        if reps == 0:
+            return rng.integers(0, 256, length, dtype=np.uint8)
+        return np.tile(rng.integers(0, 256, length // reps, dtype=np.uint8), reps)
+
+    cases = []
+    for length in (100, 1000, 10000, 100000):
+        for reps in (0, 2, 50):
+            cases.append((length, reps, int(length * 100 * 0.185), 1))
+            cases.append((length, reps, max(int(length * (10 if reps != 2 else 1) * 0.185), 18), 1))
+    for sp in range(1, 31):
+        cases.append((10000, 0, int(100000 * 0.185), sp))
+    for length, reps, block, sp in cases:
+        d = make(length, reps)
+        hip_ctx.wavelet_reset()
+        out = b"B"
+        for off in range(0, d.size, block):
+            blk = d[off:off + block]
+            rec, _ = hip_ctx.transform_and_encode_wavelet(blk, sp)
+            out += _packed(blk.size) + _packed(1) + b"\x00" + rec.tobytes()
+        out += b"\x00"
+        back = oracle.oracle_decompress_wavelet(np.frombuffer(out, np.uint8), d.size + 8)
+        assert back is not None and back.tobytes() == d.tobytes(), (length, reps, block, sp)
+        assert out == oracle.oracle_compress_B(d, block, sp).tobytes(), (length, reps, block, sp)

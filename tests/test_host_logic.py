@@ -197,6 +197,54 @@ def test_wavelet_other_model_letters(oracle):
     assert len(set(s.values())) == 3
 
 
+def test_product_wavelet_streams_decode_with_the_oracle_decoder(oracle):
+    """Cross-decoding, product -> reference algorithm: whole 'B' / 'b' / 'u' streams assembled
+    from the product's own pieces (block header, section table, both host routes of the coder)
+    are decoded by the oracle's LITERAL restatement of WaveletDecoder / readShape / decodeTreeBF /
+    message / BitDecoder, over the matrix of test/CompressorAndDecompressorTest.cpp:61-160
+    (sizes 100..100 000, repetitions 0 / 2 / 50, several blocks, 1..30 starting points).  The
+    transform of each block comes from the oracle here (no GPU in this suite); the GPU suite runs
+    the same matrix with the device transform and stream kernels."""
+    import ctypes
+    H = _host()
+    rng = np.random.default_rng(4242)
+
+    def make(length, reps):
+        if reps == 0:
+            return rng.integers(0, 256, length, dtype=np.uint8)
+        return np.tile(rng.integers(0, 256, length // reps, dtype=np.uint8), reps)
+
+    cases = []
+    for length in (100, 1000, 10000, 100000):
+        for reps in (0, 2, 50):
+            cases.append((length, reps, int(length * 100 * 0.185), 1, "B"))
+            cases.append((length, reps, max(int(length * (10 if reps != 2 else 1) * 0.185), 18), 1, "B"))
+    for sp in range(1, 31):
+        cases.append((10000, 0, int(100000 * 0.185), sp, "B"))
+    cases += [(100000, 0, 30000, 3, "b"), (100000, 50, 30000, 3, "u")]
+    entries = ("bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams")
+    for idx, (length, reps, block, sp, letter) in enumerate(cases):
+        d = make(length, reps)
+        entry = entries[idx % 2]
+        stream = letter.encode()
+        state = 4
+        for off in range(0, d.size, block):
+            blk = d[off:off + block]
+            bwt, lf, freqs = oracle.oracle_bwt_block(blk, sp)
+            sect = np.zeros(256, np.uint32)
+            ns = H.bwtc_hip_host_sections(_p(freqs), _p(sect))
+            hdr = np.zeros(2048, np.uint8)
+            lfa = np.ascontiguousarray(lf, np.uint32)
+            k = H.bwtc_hip_host_bwtblock_header(_p(lfa), lfa.size, _p(hdr), hdr.size)
+            payload, state = _host_wavelet_payload(H, bwt, sect[:ns], state, 2, entry, letter.encode())
+            body = hdr[:k].tobytes() + bytes([0 if ns == 256 else ns]) + b"".join(_packed(int(x)) for x in sect[:ns]) + payload
+            stream += _packed(blk.size) + _packed(1) + b"\x00" + len(body).to_bytes(6, "big") + body
+        stream += b"\x00"
+        back = oracle.oracle_decompress_wavelet(np.frombuffer(stream, np.uint8), d.size + 8)
+        assert back is not None and back.tobytes() == d.tobytes(), (length, reps, block, sp, letter, entry)
+        assert stream == oracle.oracle_compress_wavelet(letter, d, block, sp).tobytes()
+
+
 def _packed(v):
     b = bytearray()
     while True:

@@ -151,3 +151,107 @@ def test_runs_and_characters_known_answers(oracle):
         assert sum(l * n for l, n in dist.items()) == len(c["input"])
     rf, runs, dist = oracle.oracle_runs_and_characters(np.frombuffer(b"abdbcarraaa", np.uint8))
     assert runs == 8 and dist == {1: 6, 2: 1, 3: 1}
+
+
+def _bits(arr, n):
+    return "".join(str(int(b)) for b in arr[:n])
+
+
+def test_wavelet_known_answers(oracle):
+    """test/WaveletTest.cpp's known answers against the oracle's restatements: MinimumHeap,
+    createHuffmanShape + collectCodes, gammaCode; and the two things the hot path shares with
+    them -- the symbol code LENGTHS of the WaveletTree constructor equal the shapes' depths, and
+    fixedIntegerCode with W = 0 is the gamma code (WaveletTree.hpp:512)."""
+    ka = _load("wavelet_known_answers.json")
+    L = oracle.lib()
+    for c in ka["heap"]:
+        vals = np.array([v for v, _ in c["inserts"]], np.int32)
+        wts = np.array([w for _, w in c["inserts"]], np.uint64)
+        out = np.zeros(vals.size, np.int32)
+        L.orc_min_heap_order(oracle._ptr(vals), oracle._ptr(wts), vals.size, oracle._ptr(out))
+        assert out.tolist() == c["delete_order"], c["ref"]
+    for c in ka["huffman_shape"]:
+        fr = np.zeros(256, np.uint64)
+        if "freqs" in c:
+            for k, v in c["freqs"].items():
+                fr[ord(k)] = v
+        else:
+            src = np.frombuffer(c["run_string"].encode(), np.uint8)
+            L.orc_run_frequencies(oracle._ptr(fr), oracle._ptr(src), src.size)
+        syms = np.zeros(256, np.uint32)
+        deps = np.zeros(256, np.uint32)
+        bits = np.zeros(64 * 256, np.uint8)
+        clen = np.zeros(256, np.uint32)
+        n = L.orc_create_huffman_shape(oracle._ptr(fr), oracle._ptr(syms), oracle._ptr(deps),
+                                       oracle._ptr(bits), oracle._ptr(clen))
+        assert "".join(chr(s) for s in syms[:n]) == c["leaves"], c["ref"]
+        assert deps[:n].tolist() == c["depths"], c["ref"]
+        for k, code in c["codes"].items():
+            assert _bits(bits[64 * ord(k):], clen[ord(k)]) == code, c["ref"]
+        # the constructor's own codes (canonical, longest rightmost): same depth per symbol
+        bits2 = np.zeros(64 * 256, np.uint8)
+        clen2 = np.zeros(256, np.uint32)
+        L.orc_wavelet_symbol_codes(oracle._ptr(fr), oracle._ptr(bits2), oracle._ptr(clen2))
+        for s, d in zip(c["leaves"], c["depths"]):
+            assert clen2[ord(s)] == d, c["ref"]
+        # prefix-free and complete (Kraft sum 1) unless there is a single symbol
+        if n > 1:
+            assert sum(2.0 ** -int(clen2[ord(s)]) for s in c["leaves"]) == 1.0
+    bits = np.zeros(128, np.uint8)
+    for x, want in ka["gamma_codes"]["cases"]:
+        assert _bits(bits, L.orc_gamma_code(x, oracle._ptr(bits))) == want
+        assert _bits(bits, L.orc_fixed_integer_code(x, 0, oracle._ptr(bits))) == want
+
+
+def _wavelet_strings():
+    ka = _load("wavelet_known_answers.json")["whole_construction"]
+    out = [s.encode() for s in ka["strings"]]
+    c7 = ka["construction7"]
+    out.append(b"abc" * c7["abc_repeats"] + c7["tail"].encode())
+    return out
+
+
+def test_oracle_wavelet_decoder_round_trips(oracle):
+    """The oracle's literal decoder (readShape / decodeTreeBF / message / BitDecoder) against
+    the oracle's literal encoder: test/WaveletTest.cpp's WholeConstruction inputs, and the
+    matrix of test/CompressorAndDecompressorTest.cpp:61-160 (sizes 100..100 000, repetitions
+    0 / 2 / 50, one and several blocks, 1..30 starting points), all three wavelet letters."""
+    for s in _wavelet_strings():
+        d = np.frombuffer(s, np.uint8)
+        for sp in (1, 8):
+            st = oracle.oracle_compress_B(d, d.size, sp)
+            back = oracle.oracle_decompress_wavelet(st, d.size + 8)
+            assert back is not None and back.tobytes() == s
+    rng = np.random.default_rng(2024)
+
+    def make(length, reps):
+        if reps == 0:
+            return rng.integers(0, 256, length, dtype=np.uint8)
+        return np.tile(rng.integers(0, 256, length // reps, dtype=np.uint8), reps)
+
+    cases = []
+    for length in (100, 1000, 10000, 100000):
+        for reps in (0, 2, 50):
+            cases.append((length, reps, int(length * 100 * 0.185), 1))      # single block
+            cases.append((length, reps, max(int(length * (10 if reps != 2 else 1) * 0.185), 18), 1))
+    for sp in range(1, 31):
+        cases.append((10000, 0, int(100000 * 0.185), sp))
+    for length, reps, block, sp in cases:
+        d = make(length, reps)
+        for letter in ("B",) if sp > 1 else ("B", "b", "u"):
+            st = oracle.oracle_compress_wavelet(letter, d, block, sp)
+            back, bwt = oracle.oracle_decompress_wavelet(st, d.size + 8, want_bwt=True)
+            assert back is not None and back.tobytes() == d.tobytes(), (length, reps, block, sp, letter)
+    # the reference-recorded 36-byte stream decodes to its input
+    for c in _load("streams.json")["cases"]:
+        if c["coder"] == "B":
+            st = np.frombuffer(bytes.fromhex(c["stream_hex"].replace(" ", "")), np.uint8)
+            back, bwt = oracle.oracle_decompress_wavelet(st, 64, want_bwt=True)
+            assert back.tobytes() == c["input_ascii"].encode() and bwt.tobytes() == b"abdbcarraaa"
+
+
+def test_oracle_wavelet_decoder_rejects_damage(oracle):
+    d = np.frombuffer(b"abracadabra" * 50, np.uint8)
+    st = oracle.oracle_compress_B(d, d.size, 1)
+    assert oracle.oracle_decompress_wavelet(st, d.size + 8).tobytes() == d.tobytes()
+    assert oracle.oracle_decompress_wavelet(st[: st.size // 2], d.size + 8) is None
