@@ -147,24 +147,27 @@ template <typename K, bool INIT>
 struct RrMasks {
   u64 head[kRrE], act[kRrE], valid[kRrE];
   u32 sfx[kRrE];       // idx[p] of this lane's slot in iteration e
+  u32 chr[kRrE];       // bits 56..63 of its key (the carried character, when there is one)
 };
 
 // Masks of one wave chunk starting at list slot wbase.
 template <typename K, bool INIT>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
-                                         u32 m, u32 n, u32 short_len, u32 wbase, u32 lane,
+                                         u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
                                          RrMasks<K, INIT>& f) {
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
     const u32 p = wbase + e * kWave + lane;
     const bool ok = p < m;
-    const K kc = ok ? key[p] : (K)0;
+    const K kraw = ok ? key[p] : (K)0;
+    const K kc = kraw & kmask;
     const u32 ic = ok ? idx[p] : 0u;
     K kp = shfl_up1(kc);
     K kn = shfl_down1(kc);
     u32 ip = shfl_up1(ic);
-    if (lane == 0) { kp = (ok && p > 0) ? key[p - 1] : (K)0; if (INIT) ip = (ok && p > 0) ? idx[p - 1] : 0u; }
-    if (lane == kWave - 1) kn = (p + 1 < m) ? key[p + 1] : (K)0;
+    if (lane == 0) { kp = (ok && p > 0) ? (key[p - 1] & kmask) : (K)0; if (INIT) ip = (ok && p > 0) ? idx[p - 1] : 0u; }
+    if (lane == kWave - 1) kn = (p + 1 < m) ? (key[p + 1] & kmask) : (K)0;
+    f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw >> 56) : 0u;
     bool h = ok && (p == 0 || kc != kp);
     if (INIT) h = h || (ok && p > 0 && (u64)ip + short_len >= (u64)n);
     bool hn = (p + 1 >= m) || kn != kc;           // is p+1 a head (or past the end)?
@@ -181,7 +184,7 @@ __device__ __forceinline__ u32 top_bit(u64 v) { return 63u - (u32)__clzll((unsig
 template <typename K, bool INIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
                                                           const u32* __restrict__ idx, u32 m,
-                                                          u32 n, u32 short_len,
+                                                          u32 n, u32 short_len, K kmask,
                                                           u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
                                                           u32* __restrict__ aggC) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, wbase, lane, f);
+  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
   u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
@@ -252,19 +255,42 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
 // each costing a whole HBM sector), emit (s, nr) in list order; the caller partitions the
 // pairs by the high bits of s and k_scatter_pairs then writes into one small window of
 // rank[] at a time.
-template <typename K, bool INIT, bool PAIRS>
+//
+// MODE: how the new ranks reach rank[] and how the next round gets its list.
+//   0  rank[s] = nr written from here (short lists); active list compacted (aidx/aglob/agrp)
+//   1  (s, nr) pairs in list order for scatter_rank_pairs; active list compacted
+//   2  "dense" (most of the list stays active): one record per slot for the window-ordered
+//      route -- tri_key[p] = s << 32 | nr, tri_val[p] = new dense group number, or all ones for
+//      a finished suffix -- and only aglob of the active list is compacted.  The records are
+//      partitioned by the high bits of s; k_scatter_dense then updates rank[] one window at a
+//      time and k_gather_dense builds the next round's sort keys from the same records, reading
+//      rank[s+h] (and T[s-1]) inside one window instead of at random (bwt_engine.hip, host side).
+//
+// EMIT: the transform's bytes leave from here instead of from a gather over the finished
+// suffix array.  1: the character rides in bits 56..63 of the round's key (k_gather_key2 /
+// k_gather_dense put it there: a round's key has at most 56 bits, can_carry()); 2 (initial
+// ranking: its keys have no room): it is read from T[s-1] here.  A suffix that becomes final
+// writes out[slot] (slot out_n, which only exists in block mode, goes to *last_char; the slot
+// of suffix 0 is the end-of-block row, *pidx); one that stays active hands its character on in
+// achr_out (not in MODE 2: k_gather_dense reads it again, inside a window).  SA is only
+// written when somebody wants it (SA != nullptr).
+struct RrEmit {
+  u8* out; u32 out_n; u32* last_char; u32* pidx; const u8* T; u8* achr_out;
+};
+
+template <typename K, bool INIT, int MODE, int EMIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
-    u32 n, u32 short_len, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
+    u32 n, u32 short_len, K kmask, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
     u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out,
-    u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+    u32* __restrict__ pair_s, u32* __restrict__ pair_r, RrEmit em) {
   __shared__ u32 s_tot[3][kRrWaves];
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, wbase, lane, f);
+  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
   {
     u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
@@ -294,15 +320,30 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       const u32 s = f.sfx[e];
       const u32 g = INIT ? p : aglob[p];
       const u32 nr = INIT ? hp1 - 1u : aglob[hp1 - 1u];
-      if (PAIRS) { pair_s[p] = s; pair_r[p] = nr; }
+      const u32 grp = g_run + (u32)__popcll(ac & hd & le) - 1u;   // dense number of p's group (if active)
+      if (MODE == 2) {
+        reinterpret_cast<u64*>(pair_s)[p] = ((u64)s << 32) | (u64)nr;
+        pair_r[p] = a ? grp : 0xFFFFFFFFu;
+      } else if (MODE == 1) { pair_s[p] = s; pair_r[p] = nr; }
       else rank[s] = nr;
+      u32 c = 0;
+      if (EMIT == 1) c = f.chr[e];
+      if (EMIT == 2 && (!a || MODE != 2)) c = s ? em.T[s - 1u] : 0u;
       if (a) {
         const u32 q = q_run + (u32)__popcll(ac & lt);
-        aidx_out[q] = s;
         aglob_out[q] = g;
-        agrp_out[q] = g_run + (u32)__popcll(ac & hd & le) - 1u;
+        if (MODE != 2) {
+          aidx_out[q] = s;
+          agrp_out[q] = grp;
+          if (EMIT) em.achr_out[q] = (u8)c;
+        }
       } else {
-        SA[g] = s;
+        if (SA) SA[g] = s;
+        if (EMIT) {
+          if (s == 0u) *em.pidx = g;
+          if (g < em.out_n) em.out[g] = (u8)c;
+          else *em.last_char = c;
+        }
       }
     }
     q_run += (u32)__popcll(ac);
@@ -335,13 +376,71 @@ __global__ __launch_bounds__(256) void k_scatter_pairs(u32* __restrict__ dst,
     if (p0 + e * 256u < m) dst[w[e]] = v[e];
 }
 
+// Dense route, step 2: rank[s] = nr for records (s << 32 | nr) partitioned by the high bits of
+// s, so that consecutive records write into one window of rank[] (same chunking as above).
+__global__ __launch_bounds__(256) void k_scatter_dense(u32* __restrict__ rank,
+                                                       const u64* __restrict__ rec, u32 m) {
+  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
+  const u32 per_xcd = (nblk + 7u) / 8u;
+  const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (blk >= nblk) return;
+  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
+  u64 r[kSimpleE];
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) { const u32 p = p0 + e * 256u; r[e] = p < m ? rec[p] : 0ull; }
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e)
+    if (p0 + e * 256u < m) rank[(u32)(r[e] >> 32)] = (u32)r[e];
+}
+
+// Dense route, step 3 (after ALL of rank[] is updated): the next round's sort input, written
+// over the records.  Record p of suffix s with dense group number grp (all ones: finished)
+// becomes key = grp << b2 | rank[s+h]+1 (0 when s+h is past the end) | T[s-1] << 56 (emit),
+// value = s; finished suffixes become the all-ones key, which the sort's first pass drops.
+// The records are in window order of s and h is small against a window at the dense stage, so
+// rank[s+h] and T[s-1] are read from the window being swept, not at random.
+__global__ __launch_bounds__(256) void k_gather_dense(u64* __restrict__ rec, u32* __restrict__ val,
+                                                      const u32* __restrict__ rank,
+                                                      const u8* __restrict__ T, u32 m, u32 n, u32 h,
+                                                      int b2, int emit) {
+  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
+  const u32 per_xcd = (nblk + 7u) / 8u;
+  const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (blk >= nblk) return;
+  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
+  u32 s[kSimpleE], g[kSimpleE], r[kSimpleE], c[kSimpleE];
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u32 p = p0 + e * 256u;
+    s[e] = p < m ? (u32)(rec[p] >> 32) : 0u;
+    g[e] = p < m ? val[p] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u64 t = (u64)s[e] + (u64)h;
+    const bool live = g[e] != 0xFFFFFFFFu;
+    r[e] = (live && t < (u64)n) ? rank[t] + 1u : 0u;
+    c[e] = (live && emit && s[e]) ? T[s[e] - 1u] : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < kSimpleE; ++e) {
+    const u32 p = p0 + e * 256u;
+    if (p < m) {
+      rec[p] = g[e] != 0xFFFFFFFFu ? (((u64)g[e] << b2) | (u64)r[e] | ((u64)c[e] << 56)) : ~0ull;
+      val[p] = s[e];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // K5  second sort key of a doubling round:  (group << b2) | key2,  key2 = rank[s+h] + 1,
 //     or 0 for the one suffix whose h-successor is the empty suffix.
 // ---------------------------------------------------------------------------------------
+//     achr (may be null): the suffix's carried character, put into bits 56..63 of the key.
 __global__ __launch_bounds__(256) void k_gather_key2(const u32* __restrict__ aidx,
                                                      const u32* __restrict__ agrp,
                                                      const u32* __restrict__ rank,
+                                                     const u8* __restrict__ achr,
                                                      u64* __restrict__ key, u32 m, u32 n, u32 h,
                                                      int b2) {
   const u32 p0 = blockIdx.x * (256u * kSimpleE) + threadIdx.x;
@@ -358,7 +457,7 @@ __global__ __launch_bounds__(256) void k_gather_key2(const u32* __restrict__ aid
 #pragma unroll
   for (int e = 0; e < kSimpleE; ++e) {
     const u32 p = p0 + e * 256u;
-    if (p < m) key[p] = ((u64)g[e] << b2) | (u64)r[e];
+    if (p < m) key[p] = ((u64)g[e] << b2) | (u64)r[e] | (achr ? (u64)achr[p] << 56 : 0ull);
   }
 }
 
@@ -390,13 +489,15 @@ __global__ __launch_bounds__(256) void k_bwt_gather(const u32* __restrict__ SA,
 // End-of-block patch + LF powers.  block mode: out[pidx] = out[n-1] (BWTransform.cpp:60);
 // raw mode: out[pidx] = the input byte at pidx (divsufsort.c:507-511 leaves it untouched).
 // LF[0] = pidx, LF[k] = ISA[n - k*(n/nLF)] (divsufsort.c:337-338,350,381,390).
+// last_char (emitting rankers): the character of row n-1, which has no slot in a block's output.
 __global__ void k_finalize(u8* __restrict__ out, const u8* __restrict__ T,
                            const u32* __restrict__ rank, u32* __restrict__ lf, u32 n_lf, u32 n,
-                           const u32* __restrict__ pidx, int raw) {
+                           const u32* __restrict__ pidx, int raw, const u32* __restrict__ last_char) {
   const u32 p = *pidx;
   const u32 k = threadIdx.x;
   if (k == 0) {
-    out[p] = raw ? T[p] : out[n - 1];
+    if (raw) out[p] = T[p];
+    else if (p + 1u < n) out[p] = last_char ? (u8)*last_char : out[n - 1];
     lf[0] = p;
   } else if (k < n_lf) {
     const u32 x = n / n_lf;
@@ -411,7 +512,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
+      off_GRP, off_C0, off_C1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -430,6 +531,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_G0 = take(cap * 4);
   a.off_G1 = take(cap * 4);
   a.off_GRP = take(cap * 4);
+  a.off_C0 = take(cap + 64);
+  a.off_C1 = take(cap + 64);
   a.off_table = take(radix_table_words(cap) * 4);
   a.off_partial = take(radix_partial_words(cap) * 4);
   const u64 rr_tiles = (cap + kRrTile - 1) / kRrTile + 1;
@@ -473,6 +576,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_G0 = reinterpret_cast<u32*>(base + a.off_G0);
   d_G1 = reinterpret_cast<u32*>(base + a.off_G1);
   d_GRP = reinterpret_cast<u32*>(base + a.off_GRP);
+  d_C0 = base + a.off_C0;
+  d_C1 = base + a.off_C1;
   d_table = reinterpret_cast<u32*>(base + a.off_table);
   d_partial = reinterpret_cast<u32*>(base + a.off_partial);
   d_aggA = reinterpret_cast<u32*>(base + a.off_aggA);
@@ -489,6 +594,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     wavelet_on_host = w && std::strcmp(w, "host") == 0;
     const char* d = std::getenv("BWTC_HIP_WAVELET_DEPTH");
     if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
+    dense_route = !(std::getenv("BWTC_HIP_DENSE") && std::getenv("BWTC_HIP_DENSE")[0] == '0');
+    no_emit = std::getenv("BWTC_HIP_NO_EMIT") != nullptr;
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -587,11 +694,17 @@ static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
 }
 
 static constexpr int kSmallError = 522;   // sticky error word of the chained sort
+static constexpr int kSmallLastChar = 524; // character of row n-1 (emitting rankers, block mode)
+
+// Blocks for which a round's sort key (group bits + rank bits) leaves bits 56..63 free for the
+// carried character in every round: groups <= n/2, ranks <= n.
+static int rank_bits(u32 n) { return bit_width_u64((u64)n + 1); }   // rank + 1 <= n, and never all ones
+static bool can_carry(u32 n) { return rank_bits(n) + bit_width_u64(n / 2 ? n / 2 - 1 : 0) <= 56; }
 
 template <typename K>
 void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                           bool probe_it, int bit_lo) {
-  if (use_sweep) {
+                           bool probe_it, int bit_lo, u64 n_holes) {
+  if (use_sweep && n_holes == 0) {
     SweepWs ws;
     ws.hist_all = d_sweep;
     ws.bases = d_sweep + kSweepMaxPasses * kChains * kRadixBins;
@@ -602,7 +715,7 @@ void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K**
                               bit_lo);
   } else {
     radix_sort_pairs<K>(k0, k1, v0, v1, n, nbits, d_table, d_partial, stream, ks, vs,
-                        probe_it ? &probe : nullptr, bit_lo);
+                        probe_it ? &probe : nullptr, bit_lo, false, false, n_holes);
   }
 }
 
@@ -623,7 +736,94 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
                      d_rank, ws, wr, m);
 }
 
-int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
+// One ranking step over a sorted list (INIT: all suffixes by their initial key; rounds: the
+// active list by (group, rank[s+h])): new ranks into rank[], finished suffixes out, and -- when
+// anything stays active -- the next round's list, sorted.  Buffers: `rec_free` / `v_free` are
+// an 8*cap-byte region and a 4*cap-byte array nobody uses; `rec_keys` / `v_keys` are the ones
+// that hold ks / vs (free once the apply kernel has run).
+template <typename K, bool INIT>
+int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
+                         RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res) {
+  hipStream_t st = stream;
+  u32* counts = d_small + kSmallCounts;
+  const u32 tiles = ceil_div(m, kRrTile);
+  hipLaunchKernelGGL((k_rerank_reduce<K, INIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                     short_len, kmask, d_aggA, d_aggB, d_aggC);
+  hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, counts);
+  // how much stays active decides the route, so the counts are read before the apply kernel
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(wait());
+  if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
+  const u32 m_next = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
+  res->m = m_next;
+  res->groups = groups;
+  const int b2 = rank_bits(n);
+  const int b1 = bit_width_u64(groups ? groups - 1 : 0);
+  const int nbits = b1 + b2;
+  if (emit && m_next && nbits > 56) return -3;         // can_carry() promised this cannot happen
+  const bool dense = dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
+  u32* sa_out = emit ? nullptr : d_SA;
+  constexpr int kEmitKind = INIT ? 2 : 1;               // where the character comes from (see RrEmit)
+  u64* recA = static_cast<u64*>(rb.rec_free);
+  u64* recB = static_cast<u64*>(rb.rec_keys);
+
+#define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
+  hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,      \
+                     (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out, \
+                     AIDX, rb.aglob_next, d_GRP, PS, PR, re)
+  if (dense) {
+    u32* tri_key = reinterpret_cast<u32*>(recA);
+    if (emit) BWTC_APPLY(2, kEmitKind, tri_key, rb.v_free, (u32*)nullptr);
+    else BWTC_APPLY(2, 0, tri_key, rb.v_free, (u32*)nullptr);
+    // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
+    const int bits = bit_width_u64(n ? n - 1 : 0);
+    const int lo = bits > 16 ? bits - 16 : 0;
+    u64* ws = nullptr; u32* wv = nullptr;
+    sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo);
+    u64* ws_other = ws == recA ? recB : recA;
+    u32* wv_other = wv == rb.v_free ? rb.v_keys : rb.v_free;
+    const u32 grid = (ceil_div(m, 256 * kSimpleE) + 7u) / 8u * 8u;
+    hipLaunchKernelGGL(k_scatter_dense, dim3(grid), dim3(256), 0, st, d_rank, (const u64*)ws, m);
+    hipLaunchKernelGGL(k_gather_dense, dim3(grid), dim3(256), 0, st, ws, wv, (const u32*)d_rank,
+                       (const u8*)d_T, m, n, (u32)(h_next > 0xFFFFFFFFull ? 0xFFFFFFFFu : h_next), b2,
+                       emit ? 1 : 0);
+    const bool timed = n_sort_events + 2 <= kMaxSortEvents;
+    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    sort_pairs<u64>(ws, ws_other, wv, wv_other, m_next, nbits, &res->ks, &res->vs, true, 0, (u64)(m - m_next));
+    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+    stats.sort_pass_items += (u64)m + (u64)m_next * (u64)std::max(0, (nbits + kRadixBits - 1) / kRadixBits - 1);
+    res->rec_other = res->ks == recA ? recB : recA;
+    res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
+    return 0;
+  }
+  u32* pairs = reinterpret_cast<u32*>(recA);
+  if (m >= kPairsMin || INIT) {
+    if (emit) BWTC_APPLY(1, kEmitKind, pairs, pairs + cap, rb.v_free);
+    else BWTC_APPLY(1, 0, pairs, pairs + cap, rb.v_free);
+    scatter_rank_pairs(pairs, reinterpret_cast<u32*>(recB), m, n);
+  } else {
+    if (emit) BWTC_APPLY(0, kEmitKind, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    else BWTC_APPLY(0, 0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+  }
+#undef BWTC_APPLY
+  if (m_next == 0) return 0;
+  hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m_next, 256 * kSimpleE)), dim3(256), 0, st,
+                     (const u32*)rb.v_free, (const u32*)d_GRP, (const u32*)d_rank,
+                     emit ? (const u8*)re.achr_out : (const u8*)nullptr, recA, m_next, n,
+                     (u32)(h_next > 0xFFFFFFFFull ? 0xFFFFFFFFu : h_next), b2);
+  const bool timed = n_sort_events + 2 <= kMaxSortEvents;
+  if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m_next, nbits, &res->ks, &res->vs, true);
+  if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  stats.sort_pass_items += (u64)m_next * (u64)((nbits + kRadixBits - 1) / kRadixBits);
+  res->rec_other = res->ks == recA ? recB : recA;
+  res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
+  return 0;
+}
+
+// em != nullptr: the rankers emit the transform's bytes (see RrEmit) and the suffix array itself
+// is not stored; em == nullptr: d_SA is filled and nothing is emitted.
+int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const EmitTarget* em) {
   hipStream_t st = stream;
   n_sort_events = 0;
   stats.rounds = 0;
@@ -631,6 +831,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   stats.sort_pass_items = 0;
   if (n == 0) return 0;
 
+  const bool emit = em != nullptr;
   const KeyPlan plan = plan_keys(hist, n, lone_sentinel);
   std::memcpy(h_small + kSmallLut, plan.lut, 256);
   BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallLut, h_small + kSmallLut, 256, hipMemcpyHostToDevice, st));
@@ -640,15 +841,25 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
   // k is a proper prefix of every other suffix with the same key)
   const u32 short_len = (u32)plan.k;
 
-  // initial sort + ranking.  The sorted suffixes end in one V buffer; the other one
-  // receives the active list.
-  u32* aidx = nullptr;
-  u32* aidx_other = nullptr;
-  u32* aglob = d_G0;
-  u32* aglob_other = d_G1;
-  u32* counts = d_small + kSmallCounts;
-  const u32 tiles0 = ceil_div(n, kRrTile);
+  RrEmit re;
+  re.out = emit ? em->out : nullptr;
+  re.out_n = emit ? em->out_n : 0u;
+  re.last_char = d_small + kSmallLastChar;
+  re.pidx = d_small + kSmallPidx;
+  re.T = d_T;
+  re.achr_out = d_C0;
+  u8* achr_other = d_C1;
+
+  RankBuffers rb;
+  rb.aglob = nullptr;
+  rb.aglob_next = d_G0;
+  u32* aglob_spare = d_G1;
+  RankResult res;
+  u64 h = (u64)plan.k;                    // the next round compares rank[s + h]
+
+  // initial sort + ranking
   BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+  int rc;
   if (plan.wide) {
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
@@ -659,17 +870,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     u64* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    aidx = (vs == d_V0) ? d_V1 : d_V0;
-    aidx_other = vs;
-    hipLaunchKernelGGL((k_rerank_reduce<u64, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs, n,
-                       n, short_len, d_aggA, d_aggB, d_aggC);
-    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
-                       tiles0, counts);
-    u32* pairs = reinterpret_cast<u32*>(ks == ka ? kb : ka);
-    hipLaunchKernelGGL((k_rerank_apply<u64, true, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
-                       (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
-                       aidx, aglob, d_GRP, pairs, pairs + cap);
-    scatter_rank_pairs(pairs, reinterpret_cast<u32*>(ks), n, n);
+    rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
+    rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
+    rc = rank_step<u64, true>(ks, vs, n, n, short_len, ~0ull, rb, re, emit, h, &res);
   } else {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
@@ -680,71 +883,35 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel) {
     u32* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    aidx = (vs == d_V0) ? d_V1 : d_V0;
-    aidx_other = vs;
-    hipLaunchKernelGGL((k_rerank_reduce<u32, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs, n,
-                       n, short_len, d_aggA, d_aggB, d_aggC);
-    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
-                       tiles0, counts);
-    u32* pairs = static_cast<u32*>(d_R2);
-    hipLaunchKernelGGL((k_rerank_apply<u32, true, true>), dim3(tiles0), dim3(kRrTPB), 0, st, ks, vs,
-                       (const u32*)nullptr, n, n, short_len, d_aggA, d_aggB, d_aggC, d_rank, d_SA,
-                       aidx, aglob, d_GRP, pairs, pairs + cap);
-    scatter_rank_pairs(pairs, static_cast<u32*>(d_R1), n, n);
+    rb.rec_keys = d_R1; rb.rec_free = d_R2;             // both 32-bit key arrays live in R1
+    rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
+    rc = rank_step<u32, true>(ks, vs, n, n, short_len, ~0u, rb, re, emit, h, &res);
   }
+  if (rc) return rc;
   stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
-  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(wait());
-  if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
-  u32 m = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
 
-  u64* K64a = static_cast<u64*>(d_R1);
-  u64* K64b = static_cast<u64*>(d_R2);
-  const int b2 = bit_width_u64(n);    // key2 <= n
-  u64 h = (u64)plan.k;
+  const u64 round_mask = emit ? ((1ull << 56) - 1ull) : ~0ull;
+  u32 m = res.m;
   while (m > 0) {
     if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
     ++stats.rounds;
     stats.active_sum += m;
-    const int b1 = bit_width_u64(groups ? groups - 1 : 0);
-    hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m, 256 * kSimpleE)), dim3(256), 0, st, aidx, d_GRP,
-                       d_rank, K64a, m, n, (u32)(h > 0xFFFFFFFFull ? 0xFFFFFFFFu : h), b2);
-    u64* k64s = nullptr;
-    u32* v64s = nullptr;
-    const int nbits = b1 + b2;
-    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u: h=%llu m=%u groups=%u b1=%d b2=%d\n", stats.rounds, (unsigned long long)h, m, groups, b1, b2);
-    const bool timed = n_sort_events + 2 <= kMaxSortEvents;
-    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    sort_pairs<u64>(K64a, K64b, aidx, aidx_other, m, nbits, &k64s, &v64s, true);
-    if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    stats.sort_pass_items += (u64)m * (u64)((nbits + kRadixBits - 1) / kRadixBits);
-    u32* next_aidx = (v64s == aidx) ? aidx_other : aidx;
-    const u32 tiles = ceil_div(m, kRrTile);
-    hipLaunchKernelGGL((k_rerank_reduce<u64, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
-                       v64s, m, n, 0u, d_aggA, d_aggB, d_aggC);
-    hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC,
-                       tiles, counts);
-    if (m >= kPairsMin) {
-      u32* pairs = reinterpret_cast<u32*>(k64s == K64a ? K64b : K64a);
-      hipLaunchKernelGGL((k_rerank_apply<u64, false, true>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
-                         v64s, aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx,
-                         aglob_other, d_GRP, pairs, pairs + cap);
-      scatter_rank_pairs(pairs, reinterpret_cast<u32*>(k64s), m, n);
-    } else {
-      hipLaunchKernelGGL((k_rerank_apply<u64, false, false>), dim3(tiles), dim3(kRrTPB), 0, st, k64s,
-                         v64s, aglob, m, n, 0u, d_aggA, d_aggB, d_aggC, d_rank, d_SA, next_aidx,
-                         aglob_other, d_GRP, (u32*)nullptr, (u32*)nullptr);
-    }
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(wait());
-    if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
-    m = h_small[kSmallCounts];
-    groups = h_small[kSmallCounts + 1];
-    aidx_other = v64s;
-    aidx = next_aidx;
-    { u32* t = aglob; aglob = aglob_other; aglob_other = t; }
+    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u: h=%llu m=%u groups=%u\n", stats.rounds, (unsigned long long)h, m, res.groups);
     h *= 2;
+    // the list just sorted: positions are the active list's, aglob gives their global slots
+    rb.aglob = rb.aglob_next;
+    rb.aglob_next = aglob_spare;
+    aglob_spare = rb.aglob;
+    { u8* t = re.achr_out; re.achr_out = achr_other; achr_other = t; }
+    rb.rec_keys = res.ks; rb.rec_free = res.rec_other;
+    rb.v_keys = res.vs; rb.v_free = res.v_other;
+    const u64* ks = res.ks;
+    const u32* vs = res.vs;
+    rc = rank_step<u64, false>(ks, vs, m, n, 0u, round_mask, rb, re, emit, h, &res);
+    if (rc) return rc;
+    m = res.m;
   }
+  BWTC_HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -780,14 +947,30 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   int rc = load_text(d_src, nsrc, n, !raw, hist_T);
   if (rc) return rc;
   if (freqs) for (int c = 0; c < 256; ++c) freqs[c] += h_small[kSmallFreqs + c];
-  rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_bwt_gather, dim3(ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, st, d_SA,
-                     d_T, d_out, n, d_small + kSmallPidx);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d_out, d_T, d_rank,
-                     d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0);
-  if (raw ? n : size)
-    BWTC_HIP_TRY(hipMemcpyAsync(d_dst, d_out, raw ? n : size, hipMemcpyDeviceToDevice, st));
+  // Blocks up to 256 MiB: the transform's bytes are written by the ranking kernels, straight
+  // into the caller's buffer (d_src was consumed by load_text, so d_dst may alias it).
+  // Larger blocks (a round's key then needs the character's bits): suffix array + gather.
+  const bool emit = can_carry(n) && !no_emit;
+  if (emit) {
+    EmitTarget em;
+    em.out = d_dst;
+    em.out_n = raw ? n : size;
+    rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0, &em);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d_dst, d_T, d_rank,
+                       d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0,
+                       d_small + kSmallLastChar);
+  } else {
+    rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bwt_gather, dim3(ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, st, d_SA,
+                       d_T, d_out, n, d_small + kSmallPidx);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d_out, d_T, d_rank,
+                       d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0,
+                       (const u32*)nullptr);
+    if (raw ? n : size)
+      BWTC_HIP_TRY(hipMemcpyAsync(d_dst, d_out, raw ? n : size, hipMemcpyDeviceToDevice, st));
+  }
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallLf, d_small + kSmallLf, 264 * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipEventRecord(ev_end, st));
   BWTC_HIP_TRY(wait());
@@ -795,11 +978,11 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
   probe.harvest();
   stats.n = n;
-  (void)hipEventElapsedTime(&stats.ms_total, ev_begin, ev_end);
+  BWTC_HIP_TRY(hipEventElapsedTime(&stats.ms_total, ev_begin, ev_end));
   stats.ms_sort = 0.f;
   for (int i = 0; i + 1 < n_sort_events; i += 2) {
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ev_sort[i], ev_sort[i + 1]);
+    BWTC_HIP_TRY(hipEventElapsedTime(&ms, ev_sort[i], ev_sort[i + 1]));
     stats.ms_sort += ms;
   }
   return 0;

@@ -27,6 +27,8 @@
 
 namespace bwtc_hip {
 
+struct RrEmit;
+
 // ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
 // Page-locked host bytes: the packed streams are copied from the device straight into the
 // block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
@@ -80,6 +82,8 @@ struct BwtEngine {
   u32* d_G0 = nullptr;     // cap
   u32* d_G1 = nullptr;     // cap
   u32* d_GRP = nullptr;    // cap
+  u8* d_C0 = nullptr;      // cap : carried characters of the active list (ping-pong)
+  u8* d_C1 = nullptr;
   u32* d_table = nullptr;  // radix tables
   u32* d_partial = nullptr;
   u32* d_aggA = nullptr;   // rerank tile aggregates
@@ -133,11 +137,23 @@ struct BwtEngine {
   // Sorts the suffixes of d_T[0..n-1]; on return d_SA holds the suffix array and d_rank
   // its inverse.  d_T must be followed by >= 8 zero bytes.
   // hist = byte histogram of d_T[0..n-1] (drives the width of the initial sort key).
-  int suffix_sort(u32 n, const u32* hist, bool lone_sentinel);
+  // em != nullptr: instead of storing the suffix array the ranking kernels write the
+  // transform's bytes, out[slot] = T[SA[slot]-1] for slot < out_n, as suffixes become final
+  // (blocks for which can_carry() holds only; see k_rerank_apply).
+  struct EmitTarget { u8* out; u32 out_n; };
+  int suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const EmitTarget* em = nullptr);
   // radix sort front door: picks the chained single-read passes or the classic ones
   template <typename K>
   void sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                  bool probe_it, int bit_lo = 0);
+                  bool probe_it, int bit_lo = 0, u64 n_holes = 0);
+  // one ranking step of the suffix sorter (bwt_engine.hip)
+  struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
+  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; };
+  template <typename K, bool INIT>
+  int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
+                struct RrEmit re, bool emit, u64 h_next, RankResult* res);
+  bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
+  bool no_emit = false;      // BWTC_HIP_NO_EMIT: suffix array + gather even for blocks that could carry
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
   // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).

@@ -33,7 +33,9 @@ __device__ __forceinline__ u32 radix_digit(K k, int shift) {
   return (u32)(k >> shift) & (kRadixBins - 1);
 }
 
-template <typename K>
+// skip: items whose key is all ones do not exist (first pass of a sort whose input was written
+// with holes, see k_gather_dense): they are neither counted nor moved, so the pass compacts.
+template <typename K, bool SKIP>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ keys,
                                                           u32* __restrict__ table, u64 n,
                                                           int shift, u32 ntiles) {
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     u64 i = wbase + (u64)e * kWave;
-    if (i < n) atomicAdd(&hist[radix_digit(k[e], shift) * 16u + copy], 1u);
+    if (i < n && !(SKIP && k[e] == ~(K)0)) atomicAdd(&hist[radix_digit(k[e], shift) * 16u + copy], 1u);
   }
   __syncthreads();
   if (threadIdx.x < kRadixBins) {
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
   }
 }
 
-template <typename K>
+template <typename K, bool SKIP>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
     u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode) {
@@ -106,14 +108,19 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   K k[E];
   u32 v[E];
   u32 r[E];
+  u32 okm = 0;                                     // SKIP: bit e = this thread's item e exists
+  // does item e of this thread exist?  (without holes that is a compare, no register)
+#define BWTC_EXISTS(e) (SKIP ? (bool)((okm >> (e)) & 1u) : (wslot + (e) * kWave) < tile_n)
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     u32 slot = wslot + e * kWave;
     bool ok = slot < tile_n;
     k[e] = ok ? kin[tile_base + slot] : (K)0;
+    if (SKIP && k[e] == ~(K)0) ok = false;
     // values_mode 1: first pass of a sort whose values are the items' own positions, nothing to
     // read; 2: keys only
     v[e] = (!ok || values_mode == 2) ? 0u : values_mode == 1 ? (u32)(tile_base + slot) : vin[tile_base + slot];
+    if (SKIP) okm |= (ok ? 1u : 0u) << e;
   }
   __syncthreads();
 
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   const u64 lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const bool ok = (wslot + e * kWave) < tile_n;
+    const bool ok = BWTC_EXISTS(e);
     const u32 d = radix_digit(k[e], shift);
     const u64 m = match_any<kRadixBits>(d, ok);
     u32 prev = 0;
@@ -144,8 +151,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
       dig_total += c;
     }
   }
-  u32 unused;
-  u32 dig_base = block_scan_excl_add<kRadixTPB>(tid < kRadixBins ? dig_total : 0u, s_scr, &unused);
+  u32 tile_valid;                                   // items of the tile that exist
+  u32 dig_base = block_scan_excl_add<kRadixTPB>(tid < kRadixBins ? dig_total : 0u, s_scr, &tile_valid);
   if (tid < kRadixBins) {
     s_base[tid] = dig_base;
     s_gofs[tid] = table[(u64)tid * ntiles + tile] - dig_base;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    if ((wslot + e * kWave) < tile_n) {
+    if (BWTC_EXISTS(e)) {
       const u32 d = radix_digit(k[e], shift);
       r[e] += s_base[d] + s_cnt[wave][d];          // final tile slot
     }
@@ -162,14 +169,16 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   __syncthreads();                                  // counters are dead from here on
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    if ((wslot + e * kWave) < tile_n) {
+    if (BWTC_EXISTS(e)) {
       s_key[r[e]] = k[e];
       if (values_mode != 2) s_val[r[e]] = v[e];
     }
   }
+#undef BWTC_EXISTS
   __syncthreads();
 
-  for (u32 i = tid; i < tile_n; i += kRadixTPB) {
+  const u32 tile_out = SKIP ? tile_valid : tile_n;
+  for (u32 i = tid; i < tile_out; i += kRadixTPB) {
     const K kk = s_key[i];
     const u32 dst = s_gofs[radix_digit(kk, shift)] + i;
     // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
@@ -222,26 +231,34 @@ struct ScatterProbe {
 // point at whichever of (k0,v0)/(k1,v1) holds the result.  values_are_positions: v0 need not be
 // filled, item i's value is i (the first pass makes them up instead of reading them).  keys_only:
 // v0/v1 are not touched at all.
+// n_holes > 0: the input holds n + n_holes slots of which n_holes carry the all-ones key and do
+// not exist; the first pass drops them (at least one pass is then made, even for nbits == 0).
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
                                     K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
-                                    int bit_lo = 0, bool values_are_positions = false, bool keys_only = false) {
+                                    int bit_lo = 0, bool values_are_positions = false, bool keys_only = false,
+                                    u64 n_holes = 0) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
-  if (n > 1) {
-    const u32 ntiles = ceil_div(n, radix_tile<K>());
-    for (int shift = bit_lo; shift < nbits; shift += kRadixBits) {
-      hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n,
-                         shift, ntiles);
+  if (n > 1 || n_holes) {
+    bool first = true;
+    for (int shift = bit_lo; shift < nbits || (first && n_holes); shift += kRadixBits) {
+      const u64 n_in = first ? n + n_holes : n;
+      const int skip = first && n_holes ? 1 : 0;
+      const u32 ntiles = ceil_div(n_in, radix_tile<K>());
+      const int vmode = keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0;
+      const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
+      if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
+      else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-      hipLaunchKernelGGL(k_radix_scatter<K>, dim3(((ntiles + 7u) / 8u) * 8u), dim3(kRadixTPB), 0,
-                         st, kin, vin, kout, vout, table, n, shift, ntiles,
-                         keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0);
-      if (timed) probe->end(st, n * 2 * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
+      if (skip) hipLaunchKernelGGL((k_radix_scatter<K, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode);
+      else hipLaunchKernelGGL((k_radix_scatter<K, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode);
+      if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
       K* tk = kin; kin = kout; kout = tk;
       u32* tv = vin; vin = vout; vout = tv;
+      first = false;
     }
   }
   *k_sorted = kin;
