@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MB/s compressed (BWT + encode) on a 256 MiB block, one block per GPU.
+"""Headline benchmark: MB/s compressed (BWT + encode) on 256 MiB blocks, one GPU per rank.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path (BWTManager::doTransform + the entropy front-end that is
-built, see config.stages) over one synthetic block that is already resident in HBM.  Blocks
-are independent (PrecompressorBlock::sliceIntoBlocks), so rank r works on its own block
-(C4: generator seed 30 + r) and no data-path collective exists; torch.distributed is used
-only for the barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
-
-The default coder is the reference's default, 'B' (BASELINE config: "Wavelet coder"): the
-device half of a step (transform, run scanner, stream kernels) takes 80 ms, the host half
-(adaptive models + range coders, serial by format) 1.6 core-seconds, so the K steps overlap --
-every block is completely encoded inside the timed region (drain() collects the last ones).
-`single_block_ms` is one block alone; `other_coder` is the all-GPU 'H' route on the same block.
+A step = one pass of the hot path over one synthetic block, measured as SURVEY.md 8(d) defines
+it: from the block resident in page-locked HOST memory to its compressed record in host memory.
+  * Every step takes a different block (C3 generator, seeds 3, 4, ... cycled over --blocks
+    distinct blocks; C4 seeds 30 + rank + 8 j when there are several ranks).
+  * The upload of block i+1 (copy stream) overlaps the kernels of block i (compute stream), two
+    device input buffers.
+  * 'B' (the reference's default coder, BASELINE config 3): the device half of a block (BWT, run
+    scanner, stream kernels) is followed by a host half (adaptive models + range coders, serial
+    by format) on the context's worker threads, so blocks are pipelined `--depth` deep.  The
+    timed region is the STEADY STATE of that pipeline: the pipeline is filled before the clock
+    starts (max(W, depth) untimed blocks), every timed step begins one block and collects the
+    finished record of the oldest one, and what is still under way after step K is collected
+    after the clock stops.  K blocks enter and K records leave inside the region; fill and drain
+    times are reported separately (`fill_ms`, `drain_ms`).  The model state runs on from block
+    to block (one stream, no reset).
+  * 'H': everything on the GPU, the record is copied to host memory inside the step.
+  * --bwt-only: the transform alone (output stays in HBM); with --size-mib 1024 this is
+    BASELINE config 5.
+Blocks are independent, so rank r works on its own blocks and no data-path collective exists;
+torch.distributed is used only for the barrier and the max-over-ranks of the elapsed time.
+Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -43,55 +54,62 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(size_mib_sample, seed, coder):
-    """Times the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
-    BWT = the reference's own divbwtf when oracle/_ref was built ("reference"), else the
-    oracle's restatement ("port"); the entropy stage is the oracle's port either way."""
+def cpu_baseline(size_mib, seed, coder, runs):
+    """The CPU path on the same block, one thread (the reference cannot use more,
+    Compressor.cpp:67-70): BWT = the reference's own divbwtf when oracle/_ref was built
+    ("reference"), else the oracle's restatement ("port"); the entropy stage is the oracle's
+    literal restatement of the reference coder either way.  Rank 0, N=1 only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    from bwtc_amd import synth
-    d = synth.gen_text(size_mib_sample << 20, seed)
+    from bwtc_amd import hip
+    d = hip.synth_into("t", seed, np.empty(size_mib << 20, np.uint8))
     use_ref = oracle_lib.ref() is not None
-    t0 = time.perf_counter()
-    bwt, lf, fr = (oracle_lib.ref_bwt_block if use_ref else oracle_lib.oracle_bwt_block)(d, 8)
-    t_bwt = time.perf_counter() - t0
-    t_enc = 0.0
-    if coder in ("H", "B"):
+    bwt_s, enc_s = [], []
+    for _ in range(max(1, runs)):
+        t0 = time.perf_counter()
+        bwt, lf, fr = (oracle_lib.ref_bwt_block if use_ref else oracle_lib.oracle_bwt_block)(d, 8)
+        bwt_s.append(time.perf_counter() - t0)
         t1 = time.perf_counter()
         if coder == "H":
             oracle_lib.oracle_huffman_encode_block(bwt, lf, fr)
-        else:
+        elif coder == "B":
             oracle_lib.oracle_wavelet_encode_block(bwt, lf, fr)
-        t_enc = time.perf_counter() - t1
+        enc_s.append(time.perf_counter() - t1)
     mb = d.size / 1e6
+    tot = [a + b for a, b in zip(bwt_s, enc_s)]
     return {
-        "value": round(mb / (t_bwt + t_enc), 3), "unit": "MB/s", "cores": 1,
+        "value": round(mb / min(tot), 3), "unit": "MB/s", "cores": 1,
         "kind": "reference" if use_ref else "port",
-        "bwt_only_MBps": round(mb / t_bwt, 3),
-        "sample": "%d MiB of the same text generator (seed %d), 8 starting points: BWT by %s, "
-                  "1 thread%s" % (size_mib_sample, seed,
-                                  "the reference's divbwtf (oracle/_ref)" if use_ref
-                                  else "oracle/bwtc_oracle.c",
-                                  "; '%s' encode by the oracle port" % coder if coder else ""),
+        "median_MBps": round(mb / statistics.median(tot), 3), "runs": len(tot),
+        "bwt_only_MBps": round(mb / min(bwt_s), 3),
+        "bwt_only_median_MBps": round(mb / statistics.median(bwt_s), 3),
+        "sample": "the whole %d MiB block of the same generator (seed %d), 8 starting points, %d run(s), best "
+                  "(median beside it): BWT by %s, 1 thread%s"
+                  % (size_mib, seed, len(tot),
+                     "the reference's divbwtf (oracle/_ref)" if use_ref else "oracle/bwtc_oracle.c",
+                     "; '%s' encode by the oracle's restatement of the reference coder" % coder if coder in "HB" else ""),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--coder", choices=["B", "H"], default="B",
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
-    ap.add_argument("--depth", type=int, default=16,
-                    help="'B': blocks under way at once (device half of block i+1 overlaps the host half of block i)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--bwt-only", action="store_true", help="the transform alone (config 5 with --size-mib 1024)")
+    ap.add_argument("--depth", type=int, default=16, help="'B': blocks under way at once")
+    ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
+    ap.add_argument("--cpu-runs", type=int, default=1, help="runs of the one-thread CPU baseline (median and best reported)")
+    ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    coder = None if args.bwt_only else args.coder
 
     import torch
-    from bwtc_amd import hip, synth
+    from bwtc_amd import hip
     from bwtc_amd.farm import Farm
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # one GPU per rank; the modulo only matters when ranks are rehearsed on a smaller box
@@ -103,130 +121,172 @@ def main():
     rank, world = farm.rank, farm.world
 
     size = args.size_mib << 20
-    # one block per GPU: rank r owns block r of the job (C3 at N=1, C4 seeds 30.. otherwise)
-    assert farm.my_blocks(world) == [rank]
-    seed = 3 if world == 1 else 30 + rank
-    host = synth.gen_text(size, seed)
-    d_in = torch.from_numpy(host).to(dev)
-    d_out = torch.empty_like(d_in)
-    os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(max(1, args.depth)))
-    ctx = hip.Context(gpu, size)
-    d_comp = torch.empty(ctx.compress_bound(size), dtype=torch.uint8, device=dev)
-    h_comp = np.empty(ctx.compress_bound(size), np.uint8)      # the 'B' coder runs on host threads
+    depth = max(1, args.depth) if coder == "B" else 1
+    os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
     threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits
-    torch.cuda.synchronize()
-    comp = [0]
+    ctx = hip.Context(gpu, size)
 
-    # 'B': the device work of a block takes a tenth of the time its range coder needs on the
-    # host, so the steps overlap -- a step does the device half of its block and queues the
-    # host half on the context's worker threads (bwtc_hip_wavelet_encode_device_begin); every
-    # block is finished (..._end) inside the timed region, at the latest by drain().
-    depth = max(1, args.depth)
-    ring = [np.empty(ctx.compress_bound(size), np.uint8) for _ in range(depth)] if args.coder == "B" else []
-    pending = []
+    # distinct blocks in page-locked host memory: C3 seeds 3, 4, ... (one rank) / C4 seeds 30 + rank + 8 j
+    nblk = max(1, args.blocks)
+    seeds = [(3 + j) if world == 1 else (30 + rank + 8 * j) for j in range(nblk)]
+    pool = [hip.synth_into("t", s, ctx.host_alloc(size)) for s in seeds]
+    d_in = [ctx.dmalloc(size + 64), ctx.dmalloc(size + 64)]
+    d_out = ctx.dmalloc(size + 64)
+    bound = ctx.compress_bound(size)
+    d_comp = ctx.dmalloc(bound) if coder == "H" else None
+    ring = [np.empty(bound, np.uint8) for _ in range(depth + 1)] if coder == "B" else []
+    h_rec = np.empty(bound, np.uint8) if coder == "H" else None
+
+    pending = []                 # tickets of blocks under way ('B')
+    comp = [0]
+    issued = [0]
+    clock = {"gpu_s": 0.0, "collect_s": 0.0}
 
     def collect():
+        t = time.perf_counter()
         comp[0] = ctx.wavelet_encode_end(pending.pop(0))
+        clock["collect_s"] += time.perf_counter() - t
 
     def drain():
         while pending:
             collect()
 
-    issued = [0]
+    def upload(i):
+        ctx.to_device_async(d_in[i % 2], pool[i % nblk])
 
-    def step_for(coder):
-        def step():
-            lf, freqs = ctx.bwt_block_device(d_in.data_ptr(), d_out.data_ptr(), size, 8)
-            if coder == "H":
-                comp[0] = ctx.huffman_encode_device(d_out.data_ptr(), size, lf, freqs, d_comp.data_ptr())
-            elif not ring:
-                ctx.wavelet_reset()
-                comp[0] = ctx.wavelet_encode_device(d_out.data_ptr(), size, lf, freqs, h_comp, threads)
-            else:
-                if len(pending) >= depth:
-                    collect()
-                ctx.wavelet_reset()
-                pending.append(ctx.wavelet_encode_device_begin(d_out.data_ptr(), size, lf, freqs,
-                                                               ring[issued[0] % depth], threads))
-                issued[0] += 1
-        return step
+    def step():
+        i = issued[0]
+        if coder == "B" and len(pending) >= depth:
+            collect()                                    # the oldest block's record (host memory)
+        t = time.perf_counter()
+        ctx.copy_wait()                                  # block i has landed (its copy ran under block i-1's kernels)
+        upload(i + 1)                                    # block i+1 goes up while block i is transformed
+        lf, freqs = ctx.bwt_block_device(d_in[i % 2], d_out, size, 8)
+        if coder == "H":
+            comp[0] = ctx.huffman_encode_device(d_out, size, lf, freqs, d_comp)
+            ctx.lib.bwtc_hip_memcpy_to_host(ctx.handle, h_rec.ctypes.data, d_comp, comp[0])
+        elif coder == "B":
+            pending.append(ctx.wavelet_encode_device_begin(d_out, size, lf, freqs, ring[i % (depth + 1)], threads))
+        clock["gpu_s"] += time.perf_counter() - t
+        issued[0] += 1
 
-    step = step_for(args.coder)
-
-    # one block alone, start to finish (untimed): the latency a single block sees
-    single_ms = None
-    if args.coder == "B":
-        step(); drain()
-        t1 = time.perf_counter()
-        step(); drain()
-        single_ms = 1e3 * (time.perf_counter() - t1)
-    for _ in range(args.warmup):
-        step()
-    drain()
+    # ---- untimed: H2D alone, one block alone, pipeline fill ---------------------------------
+    t0 = time.perf_counter()
+    upload(0)
+    ctx.copy_wait()
+    h2d_ms = 1e3 * (time.perf_counter() - t0)
+    step(); drain()                                      # first use: allocations, worker pool
+    issued[0] = 0
+    upload(0)
+    t0 = time.perf_counter()
+    step(); drain()
+    single_ms = 1e3 * (time.perf_counter() - t0)
+    ctx.wavelet_reset()
+    issued[0] = 0
+    upload(0)
+    t0 = time.perf_counter()
+    for _ in range(max(args.warmup, depth if coder == "B" else 0)):
+        step()                                           # nothing is collected here: the pipeline fills
+    fill_ms = 1e3 * (time.perf_counter() - t0)
     ctx.reset_kernel_timers()
-    elapsed = farm.timed(step, args.steps, 0, drain)
+    clock["gpu_s"] = clock["collect_s"] = 0.0
+    m0, c0, b0 = ctx.wavelet_host_clock()
+    dev_ms = []
+
+    def timed_step():
+        step()
+        dev_ms.append(ctx.stats().ms_total)
+
+    # ---- timed: K steps, each begins one block and (B) collects one ------------------------------
+    elapsed = farm.timed(timed_step, args.steps, 0, None)
+    m1, c1, b1 = ctx.wavelet_host_clock()
+    t0 = time.perf_counter()
+    drain()
+    drain_ms = 1e3 * (time.perf_counter() - t0)
     comp_bytes = comp[0]
 
     if rank == 0:
         kt = ctx.kernel_timers()
         st = ctx.stats()
         total_mb = world * args.steps * size / 1e6
+        r_eff = st.active_sum / max(st.n, 1)
         roof = None
         # HBM bytes per launch of the same kernel on the same workload, from the committed PMC
         # passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 runs, gfx950 correction applied
         # by scripts/pmc_summary.py).  Only quoted for the workload it was measured on.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_text256.json")
-        if args.size_mib == 256 and os.path.exists(pmc):
-            for name, v in json.load(open(pmc))["kernels"].items():
-                if "k_radix_scatter<unsigned long>" in name:
+        traffic, traffic_src = None, None
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_text256.json")))
+        if args.size_mib == 256 and pmcs:
+            for name, v in json.load(open(pmcs[-1]))["kernels"].items():
+                if "k_radix_scatter<unsigned long" in name and traffic is None:
                     traffic = int(v["hbm_bytes_per_launch_avg"])
+                    traffic_src = os.path.relpath(pmcs[-1], ROOT)
         if kt["scatter_launches"]:
             achieved = kt["scatter_bytes"] / (kt["scatter_ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_radix_scatter<u64> (+<u32> initial passes)",
+            bwt_ms = statistics.mean(dev_ms)
+            # the whole transform by SURVEY.md 8(d)'s counting rule: N (97 + 100 R_eff) bytes
+            whole_bytes = st.n * (97.0 + 100.0 * r_eff)
+            roof = {"bound": "hbm", "kernel": "k_radix_scatter<u64> (+<u32> passes of the suffix sorter)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_traffic_text256.json" if traffic else None,
+                    "traffic_source": traffic_src,
                     "launches": kt["scatter_launches"],
                     "avg_launch_us": round(1e3 * kt["scatter_ms"] / kt["scatter_launches"], 1),
-                    "algorithmic_bytes_per_launch": int(kt["scatter_bytes"] / kt["scatter_launches"])}
+                    "algorithmic_bytes_per_launch": int(kt["scatter_bytes"] / kt["scatter_launches"]),
+                    "whole_transform": {"algorithmic_bytes": int(whole_bytes), "device_ms": round(bwt_ms, 3),
+                                        "achieved": round(whole_bytes / (bwt_ms * 1e-3) / 1e9, 1),
+                                        "frac": round(whole_bytes / (bwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "rule": "SURVEY.md 8(d): N (97 + 100 R_eff) bytes / device time of the transform"}}
+        step_ms = 1e3 * elapsed / args.steps
+        gpu_ms = 1e3 * clock["gpu_s"] / args.steps
+        wait_ms = 1e3 * clock["collect_s"] / args.steps
+        blocks_done = max(1, b1 - b0)
+        what = ("BWT only" if coder is None else "BWT+encode")
         out = {
-            "metric": "MB/s compressed (BWT+encode) on 256 MiB block",
+            "metric": "MB/s compressed (%s) on %d MiB block" % (what, args.size_mib)
+                      if coder else "MB/s transformed (BWT only) on %d MiB block" % args.size_mib,
             "value": round(total_mb / elapsed, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
-            "config": {"workload": "C3: %d MiB enwik8-style synthetic text block per GPU "
-                                   "(splitmix64 token generator, seed %s), 8 starting points"
-                                   % (args.size_mib, "3" if world == 1 else "30+rank"),
-                       "stages": "BWT (suffix sort + BWT + LFpowers + freqs) on the GPU + " +
-                                 ("'B' wavelet coder: run scanner, tree bit vectors, traversal order and gap "
-                                  "flags on the GPU; adaptive models (parallel over tree nodes) and the range "
-                                  "coder (one serial chain per section, by the format) on %d host threads"
-                                  % threads if args.coder == "B" else
-                                  "'H' run-length/Huffman coder on the GPU"),
-                       "coder": args.coder,
-                       "blocks_per_gpu": 1, "parallelism": "block farm, no collective",
-                       "blocks_under_way": depth if args.coder == "B" else 1},
-            "device_ms_bwt": round(st.ms_total, 3), "rounds": st.rounds,
-            "R_eff": round(st.active_sum / max(st.n, 1), 3),
+            "config": {"workload": "%s: %d MiB enwik8-style synthetic text blocks (splitmix64 token generator, "
+                                   "seeds %s, %d distinct blocks cycled), 8 starting points, one block per step per GPU"
+                                   % ("C5" if coder is None and args.size_mib >= 1024 else "C3" if world == 1 else "C4",
+                                      args.size_mib, "3.." if world == 1 else "30+rank+8j", nblk),
+                       "timed_region": "block in page-locked host memory -> " +
+                                       ("transformed block in HBM" if coder is None else "record in host memory") +
+                                       "; upload of block i+1 overlaps the kernels of block i" +
+                                       ("; steady state of a %d-deep block pipeline (K blocks begun and K records "
+                                        "collected inside the region, fill and drain outside)" % depth if coder == "B" else ""),
+                       "stages": "BWT (suffix sort + BWT + LFpowers + freqs) on the GPU" +
+                                 (" + 'B' wavelet coder: run scanner, tree bit vectors, traversal order and gap "
+                                  "flags on the GPU; adaptive models and the range coder (one serial chain per "
+                                  "section, by the format) on %d host threads" % threads if coder == "B" else
+                                  " + 'H' run-length/Huffman coder on the GPU, record copied to the host" if coder == "H" else ""),
+                       "coder": coder, "blocks_per_gpu_per_step": 1, "parallelism": "block farm, no collective",
+                       "blocks_under_way": depth},
+            "single_block_ms": round(single_ms, 1), "h2d_ms": round(h2d_ms, 2),
+            "fill_ms": round(fill_ms, 1), "drain_ms": round(drain_ms, 1),
+            "gpu_ms_per_step": round(gpu_ms, 2), "collect_wait_ms_per_step": round(wait_ms, 2),
+            "host_bound": bool(coder == "B" and wait_ms > 0.1 * step_ms),
+            "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
+            "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,
+            "host_model_s_per_block": round((m1 - m0) / blocks_done, 3) if coder == "B" else 0.0,
+            "host_coder_s_per_block": round((c1 - c0) / blocks_done, 3) if coder == "B" else 0.0,
+            "device_ms_bwt": round(statistics.mean(dev_ms), 3), "rounds": st.rounds,
+            "R_eff": round(r_eff, 3),
             "compressed_bytes": int(comp_bytes),
-            "single_block_ms": round(single_ms, 1) if single_ms else None,
             "roofline": roof,
         }
+        if coder == "B" and cores // max(world, 1) < 16:
+            out["warning"] = ("only %d host threads per rank: the 'B' coder's host half needs about 16 per GPU "
+                              "to keep up with the device half" % threads)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_mib, seed, args.coder)
-        # the other coder on the same block, two untimed-region steps, for orientation
-        other = "H" if args.coder == "B" else "B"
-        ostep = step_for(other)
-        ostep(); drain()
-        t1 = time.perf_counter()
-        ostep(); drain()
-        out["other_coder"] = {"coder": other, "MBps": round(size / 1e6 / (time.perf_counter() - t1), 2),
-                              "compressed_bytes": int(comp[0])}
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size_mib or args.size_mib, seeds[0], coder or "", args.cpu_runs)
         print(json.dumps(out), flush=True)
     farm.close()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -512,7 +512,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -533,6 +533,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_GRP = take(cap * 4);
   a.off_C0 = take(cap + 64);
   a.off_C1 = take(cap + 64);
+  a.off_P0 = take(cap + 64);
+  a.off_P1 = take(cap + 64);
   a.off_table = take(radix_table_words(cap) * 4);
   a.off_partial = take(radix_partial_words(cap) * 4);
   const u64 rr_tiles = (cap + kRrTile - 1) / kRrTile + 1;
@@ -578,6 +580,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_GRP = reinterpret_cast<u32*>(base + a.off_GRP);
   d_C0 = base + a.off_C0;
   d_C1 = base + a.off_C1;
+  d_P0 = base + a.off_P0;
+  d_P1 = base + a.off_P1;
   d_table = reinterpret_cast<u32*>(base + a.off_table);
   d_partial = reinterpret_cast<u32*>(base + a.off_partial);
   d_aggA = reinterpret_cast<u32*>(base + a.off_aggA);
@@ -596,6 +600,9 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
     dense_route = !(std::getenv("BWTC_HIP_DENSE") && std::getenv("BWTC_HIP_DENSE")[0] == '0');
     no_emit = std::getenv("BWTC_HIP_NO_EMIT") != nullptr;
+    if (std::getenv("BWTC_HIP_WINDOW_BITS") && std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")) > 0)
+      window_bits = std::min(24, std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")));
+    digit_planes = !(std::getenv("BWTC_HIP_PLANES") && std::getenv("BWTC_HIP_PLANES")[0] == '0');
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -623,6 +630,8 @@ hipError_t BwtEngine::wait() {
 void BwtEngine::release() {
   wavelet_pipeline_release(*this);
   if (stream) (void)hipStreamSynchronize(stream);
+  if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+  if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);
   if (h_stage) (void)hipHostFree(h_stage);
@@ -715,7 +724,8 @@ void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K**
                               bit_lo);
   } else {
     radix_sort_pairs<K>(k0, k1, v0, v1, n, nbits, d_table, d_partial, stream, ks, vs,
-                        probe_it ? &probe : nullptr, bit_lo, false, false, n_holes);
+                        probe_it ? &probe : nullptr, bit_lo, false, false, n_holes,
+                        digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr);
   }
 }
 
@@ -728,7 +738,7 @@ constexpr u32 kPairsMin = 1u << 21;
 void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
   hipStream_t st = stream;
   const int bits = bit_width_u64(n ? n - 1 : 0);
-  const int lo = bits > 16 ? bits - 16 : 0;
+  const int lo = bits > window_bits ? bits - window_bits : 0;
   u32 *ws = pairs, *wr = pairs + cap;
   if (m >= kPairsMin && bits > 12)
     sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, &ws, &wr, false, lo);
@@ -777,7 +787,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     else BWTC_APPLY(2, 0, tri_key, rb.v_free, (u32*)nullptr);
     // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
     const int bits = bit_width_u64(n ? n - 1 : 0);
-    const int lo = bits > 16 ? bits - 16 : 0;
+    const int lo = bits > window_bits ? bits - window_bits : 0;
     u64* ws = nullptr; u32* wv = nullptr;
     sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo);
     u64* ws_other = ws == recA ? recB : recA;

@@ -64,6 +64,8 @@ struct DeviceWaveletJob : WaveletJob {
 struct BwtEngine {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // uploads that overlap the kernels (bwtc_hip_memcpy_to_device_async)
+  hipEvent_t ev_copy = nullptr;
   u32 max_block = 0;     // largest block size in bytes
   u64 cap = 0;           // suffix capacity = max_block + 1
 
@@ -84,6 +86,8 @@ struct BwtEngine {
   u32* d_GRP = nullptr;    // cap
   u8* d_C0 = nullptr;      // cap : carried characters of the active list (ping-pong)
   u8* d_C1 = nullptr;
+  u8* d_P0 = nullptr;      // cap : digit planes of the radix passes (radix_sort.hpp)
+  u8* d_P1 = nullptr;
   u32* d_table = nullptr;  // radix tables
   u32* d_partial = nullptr;
   u32* d_aggA = nullptr;   // rerank tile aggregates
@@ -153,6 +157,8 @@ struct BwtEngine {
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
                 struct RrEmit re, bool emit, u64 h_next, RankResult* res);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
+  bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
+  int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
   bool no_emit = false;      // BWTC_HIP_NO_EMIT: suffix array + gather even for blocks that could carry
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);

@@ -115,6 +115,36 @@ int bwtc_hip_memcpy_to_host(bwtc_hip_ctx* ctx, void* dst, const void* d_src, uin
   return 0;
 }
 
+void* bwtc_hip_host_alloc(bwtc_hip_ctx* ctx, uint64_t bytes) {
+  if (!ctx || hipSetDevice(ctx->eng.device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void bwtc_hip_host_free(bwtc_hip_ctx* ctx, void* p) {
+  if (ctx && p && hipSetDevice(ctx->eng.device) == hipSuccess) (void)hipHostFree(p);
+}
+int bwtc_hip_memcpy_to_device_async(bwtc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
+  if (!ctx || (!d_dst && bytes) || (!src && bytes)) return -1;
+  BwtEngine& e = ctx->eng;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  if (!e.copy_stream) {
+    BWTC_HIP_TRY(hipStreamCreateWithFlags(&e.copy_stream, hipStreamNonBlocking));
+    BWTC_HIP_TRY(hipEventCreateWithFlags(&e.ev_copy, hipEventBlockingSync | hipEventDisableTiming));
+  }
+  if (bytes) BWTC_HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, e.copy_stream));
+  return 0;
+}
+int bwtc_hip_copy_wait(bwtc_hip_ctx* ctx) {
+  if (!ctx) return -1;
+  BwtEngine& e = ctx->eng;
+  if (!e.copy_stream) return 0;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  BWTC_HIP_TRY(hipEventRecord(e.ev_copy, e.copy_stream));
+  BWTC_HIP_TRY(hipEventSynchronize(e.ev_copy));
+  return 0;
+}
+
 uint32_t bwtc_hip_n_lf(uint32_t size, uint32_t starting_points) {
   if (starting_points < 1) starting_points = 1;          // BWTManager.cpp:60-64
   else if (starting_points > 256) starting_points = 256;
@@ -312,6 +342,14 @@ int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
 }
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx) { return ctx ? ctx->eng.max_inflight : 0u; }
+int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds, uint64_t* blocks) {
+  if (!ctx) return -1;
+  const HostPipeline* p = ctx->eng.pipeline;
+  if (model_seconds) *model_seconds = p ? p->clock.model_ns.load() * 1e-9 : 0.0;
+  if (coder_seconds) *coder_seconds = p ? p->clock.coder_ns.load() * 1e-9 : 0.0;
+  if (blocks) *blocks = p ? p->clock.blocks.load() : 0;
+  return 0;
+}
 
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                          const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,

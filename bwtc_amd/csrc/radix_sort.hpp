@@ -70,10 +70,13 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
   }
 }
 
-template <typename K, bool SKIP>
+// PLANE: the pass also writes plane[dst] = the item's NEXT digit, one byte per item in output
+// order, so that the next pass's histogram kernel reads 1 byte per item instead of the key.
+template <typename K, bool SKIP, bool PLANE>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
-    u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode) {
+    u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
+    u8* __restrict__ plane) {
   constexpr int E = RadixCfg<K>::E;
   constexpr int TILE = kRadixTPB * E;
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
@@ -185,6 +188,36 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
     kout[dst] = kk;
     if (values_mode != 2) vout[dst] = s_val[i];
+    if (PLANE) plane[dst] = (u8)radix_digit(kk, shift + kRadixBits);
+  }
+}
+
+// Tile histogram from a digit plane (see PLANE above): same table as k_radix_hist<K, false>.
+template <typename K>
+__global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __restrict__ plane,
+                                                                u32* __restrict__ table, u64 n,
+                                                                u32 ntiles) {
+  constexpr int E = RadixCfg<K>::E;                 // bytes of the tile per thread
+  __shared__ u32 hist[kRadixBins * 16];
+  for (u32 i = threadIdx.x; i < kRadixBins * 16; i += kRadixTPB) hist[i] = 0;
+  __syncthreads();
+  const u64 base = (u64)blockIdx.x * (kRadixTPB * E) + (u64)threadIdx.x * E;
+  const u32 copy = threadIdx.x & 15u;
+  if (base + E <= n) {
+    u32 w[E / 4];
+    if (E == 8) { const uint2 t = *reinterpret_cast<const uint2*>(plane + base); w[0] = t.x; w[1] = t.y; }
+    else { const uint4 t = *reinterpret_cast<const uint4*>(plane + base); w[0] = t.x; w[1] = t.y; w[E / 4 - 2] = t.z; w[E / 4 - 1] = t.w; }
+#pragma unroll
+    for (int b = 0; b < E; ++b) atomicAdd(&hist[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+  } else {
+    for (int b = 0; b < E; ++b) if (base + b < n) atomicAdd(&hist[(u32)plane[base + b] * 16u + copy], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kRadixBins) {
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c += hist[threadIdx.x * 16u + r];
+    table[(u64)threadIdx.x * ntiles + blockIdx.x] = c;
   }
 }
 
@@ -233,12 +266,14 @@ struct ScatterProbe {
 // v0/v1 are not touched at all.
 // n_holes > 0: the input holds n + n_holes slots of which n_holes carry the all-ones key and do
 // not exist; the first pass drops them (at least one pass is then made, even for nbits == 0).
+// plane0 / plane1 (optional, n bytes each, 16-byte aligned): digit planes; every pass but the
+// last leaves the next pass's digits there and the next histogram is taken from them.
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
                                     K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
                                     int bit_lo = 0, bool values_are_positions = false, bool keys_only = false,
-                                    u64 n_holes = 0) {
+                                    u64 n_holes = 0, u8* plane0 = nullptr, u8* plane1 = nullptr) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1 || n_holes) {
@@ -249,12 +284,21 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       const u32 ntiles = ceil_div(n_in, radix_tile<K>());
       const int vmode = keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0;
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
-      if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
+      const bool have_plane = plane0 && !first;                             // the previous pass left this pass's digits
+      const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's
+      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles);
+      else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-      if (skip) hipLaunchKernelGGL((k_radix_scatter<K, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode);
-      else hipLaunchKernelGGL((k_radix_scatter<K, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode);
+      if (skip) {
+        if (make_plane) hipLaunchKernelGGL((k_radix_scatter<K, true, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, plane1);
+        else hipLaunchKernelGGL((k_radix_scatter<K, true, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, (u8*)nullptr);
+      } else {
+        if (make_plane) hipLaunchKernelGGL((k_radix_scatter<K, false, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, plane1);
+        else hipLaunchKernelGGL((k_radix_scatter<K, false, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, (u8*)nullptr);
+      }
+      { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
       if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
       K* tk = kin; kin = kout; kout = tk;
       u32* tv = vin; vin = vout; vout = tv;

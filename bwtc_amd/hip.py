@@ -33,14 +33,15 @@ EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
-    "bwtc_hip_memcpy_to_host", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_memcpy_to_host", "bwtc_hip_host_alloc", "bwtc_hip_host_free",
+    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
     "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
-    "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_suffix_array",
+    "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
 
@@ -75,6 +76,14 @@ def load():
     L.bwtc_hip_free.argtypes = [_vp, _vp]
     L.bwtc_hip_memcpy_to_device.argtypes = [_vp, _vp, _vp, _u64]
     L.bwtc_hip_memcpy_to_host.argtypes = [_vp, _vp, _vp, _u64]
+    L.bwtc_hip_host_alloc.restype = _vp
+    L.bwtc_hip_host_alloc.argtypes = [_vp, _u64]
+    L.bwtc_hip_host_free.restype = None
+    L.bwtc_hip_host_free.argtypes = [_vp, _vp]
+    L.bwtc_hip_memcpy_to_device_async.argtypes = [_vp, _vp, _vp, _u64]
+    L.bwtc_hip_copy_wait.argtypes = [_vp]
+    L.bwtc_hip_wavelet_host_clock.argtypes = [_vp, _vp, _vp, _vp]
+    L.bwtc_hip_synth.argtypes = [ctypes.c_char, _u64, _u64, _vp]
     L.bwtc_hip_n_lf.restype = _u32
     L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
     L.bwtc_hip_bwt.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp]
@@ -193,6 +202,38 @@ class Context:
         arr = np.ascontiguousarray(arr)
         _check(self.lib.bwtc_hip_memcpy_to_device(self.handle, _vp(d_ptr), _ptr(arr), arr.nbytes),
                "bwtc_hip_memcpy_to_device")
+
+    def host_alloc(self, nbytes):
+        """Page-locked host bytes as a numpy array (freed with host_free, or with the process)."""
+        p = self.lib.bwtc_hip_host_alloc(self.handle, nbytes)
+        if not p:
+            raise BwtcHipError("bwtc_hip_host_alloc(%d) failed" % nbytes)
+        arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.bwtc_hip_host_free(self.handle, _vp(p))
+
+    def to_device_async(self, d_ptr, arr):
+        """Upload on the context's copy stream; returns at once (arr must stay alive and unchanged
+        until copy_wait())."""
+        _check(self.lib.bwtc_hip_memcpy_to_device_async(self.handle, _vp(d_ptr), _ptr(arr), arr.nbytes),
+               "bwtc_hip_memcpy_to_device_async")
+
+    def copy_wait(self):
+        _check(self.lib.bwtc_hip_copy_wait(self.handle), "bwtc_hip_copy_wait")
+
+    def wavelet_host_clock(self):
+        """(seconds in the adaptive models, seconds in the range coders, blocks) of the 'B' coder's
+        worker threads, summed over threads since the context was made."""
+        m, c, b = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_uint64(0)
+        _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
+               "bwtc_hip_wavelet_host_clock")
+        return m.value, c.value, b.value
 
     def to_host(self, d_ptr, nbytes):
         out = np.empty(nbytes, np.uint8)
@@ -405,3 +446,10 @@ class Context:
         data = np.array(data, dtype=np.uint32, copy=True)
         _check(self.lib.bwtc_hip_test_scan_u32(self.handle, _ptr(data), data.size), "bwtc_hip_test_scan")
         return data
+
+
+def synth_into(kind, seed, out):
+    """Fills the uint8 array `out` with the synthetic block of `kind` ('r', 'd', 't') and `seed`:
+    the library's C++ generator, the same bytes as bwtc_amd.synth (tests/test_abi.py)."""
+    _check(load().bwtc_hip_synth(kind.encode(), seed, out.size, _ptr(out)), "bwtc_hip_synth")
+    return out

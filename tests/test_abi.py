@@ -58,3 +58,17 @@ def test_product_never_imports_the_oracle():
                 if "oracle" in t.lower():
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_synthetic_generator_matches_numpy_definition():
+    """bwtc_hip_synth (C++, used by bench.py and the host tools) produces the bytes of
+    bwtc_amd/synth.py (SURVEY.md 8d generators) for all three kinds, including ragged sizes."""
+    import numpy as np
+    from bwtc_amd import hip, synth
+    for kind, gen, seed in (("t", synth.gen_text, 3), ("d", synth.gen_dna, 2), ("r", synth.gen_random_bytes, 1),
+                            ("t", synth.gen_text, 37)):
+        for n in (1, 7, 33, 1000, (1 << 20) + 3):
+            a = hip.synth_into(kind, seed, np.empty(n, np.uint8))
+            assert (a == gen(n, seed)).all(), (kind, seed, n)
+    with pytest.raises(hip.BwtcHipError):
+        hip.synth_into("x", 1, np.empty(4, np.uint8))
