@@ -54,6 +54,16 @@ def usable_cpus():
     return n
 
 
+def mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(size_mib, seed, coder, runs):
     """The CPU path on the same block, one thread (the reference cannot use more,
     Compressor.cpp:67-70): BWT = the reference's own divbwtf when oracle/_ref was built
@@ -100,7 +110,10 @@ def main():
     ap.add_argument("--coder", choices=["B", "H"], default="B",
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
     ap.add_argument("--bwt-only", action="store_true", help="the transform alone (config 5 with --size-mib 1024)")
-    ap.add_argument("--depth", type=int, default=16, help="'B': blocks under way at once")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="'B': blocks under way at once (0 = 64 when the host has 128 GB of free memory per rank, "
+                         "else 16: a block under way holds 1.2 GB of host memory, and the 16-lane range-coder "
+                         "engines only pay in a deep pipeline)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
     ap.add_argument("--cpu-runs", type=int, default=1, help="runs of the one-thread CPU baseline (median and best reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
@@ -121,7 +134,9 @@ def main():
     rank, world = farm.rank, farm.world
 
     size = args.size_mib << 20
-    depth = max(1, args.depth) if coder == "B" else 1
+    world_hint = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    auto_depth = 64 if mem_available_gb() / world_hint >= 128 else 16
+    depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
     threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits

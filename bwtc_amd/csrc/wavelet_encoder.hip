@@ -76,7 +76,7 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
       const auto t2 = std::chrono::steady_clock::now();
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(e.wt_coded + 8)) return -2;
-      if (!e.pipeline) e.pipeline = new HostPipeline(threads, e.huge_group_elements);
+      if (!e.pipeline) e.pipeline = new HostPipeline(threads, e.huge_group_elements, e.max_inflight);
       if (debug) {
         uint64_t cnt[8] = {0}, el[8] = {0};
         const uint32_t* pos = job.coded_pos.data();

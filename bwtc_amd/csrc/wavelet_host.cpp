@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "entropy_host.hpp"
+#include "wavelet_rc.hpp"
 
 namespace bwtc {
 namespace wavelet {
@@ -651,101 +652,6 @@ namespace {
 
 inline uint32_t codeAt(const uint8_t* codes, uint64_t i) { return (codes[i >> 2] >> ((i & 3) * 2)) & 3u; }
 
-// Stage 2 of the stream coder: BitEncoder (BitCoders.cpp:59-113) over a section's elements with
-// their probabilities; the one chain of the coder that cannot be split.  The interval is kept
-// as (low, size = high - low - 1), all modulo 2^32 like the reference's high/low: with
-// t = (size * p + 2048) >> 12 (the reference's two-part product, exact in 64 bits) a one bit
-// gives size = t - 1 and a zero bit low += t + 1, size -= t + 1, so the loop-carried chain is
-// one multiply and a subtraction.
-struct CoderChain {
-  uint32_t lo, size;
-  uint64_t i, e;
-  std::vector<uint8_t>* out;
-  size_t used;
-  void start(uint64_t b, uint64_t end, std::vector<uint8_t>* o) { lo = 0; size = 0xFFFFFFFEu; i = b; e = end; out = o; used = o->size(); }
-  uint8_t* room(uint64_t elements) {                                   // at most four bytes leave the coder per bit
-    if (out->size() - used < 4 * elements + 8) out->resize(used + 4 * elements + 8 + out->size() / 2);
-    return out->data() + used;
-  }
-  void finish() {                                                      // BitEncoder::finish
-    out->resize(used + 4);
-    uint8_t* o = out->data() + used;
-    o[0] = static_cast<uint8_t>(lo >> 24); o[1] = 255; o[2] = 255; o[3] = 255;
-  }
-};
-
-// one chain on its own: the byte output is a (badly predictable) branch, but nothing is added
-// to the chain
-void runChain(CoderChain& c, const uint8_t* codes, const uint16_t* prob, uint64_t until) {
-  const uint64_t kChunk = 16384;
-  uint32_t lo = c.lo, size = c.size;
-  uint64_t b = c.i;
-  for (; b < until; b += kChunk) {
-    const uint64_t ce = std::min(until, b + kChunk);
-    uint8_t* o = c.room(kChunk);
-#define BWTC_RC_STEP(bit_, p_)                                                                          \
-    {                                                                                                    \
-      const uint32_t bit = (bit_);                                                                       \
-      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * (p_) + 2048u) >> 12);      \
-      lo = bit ? lo : lo + t + 1;                                                                        \
-      size = bit ? t - 1 : size - t - 1;                                                                 \
-      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; } \
-    }
-    uint64_t i = b;
-    for (; i < ce && (i & 3); ++i) BWTC_RC_STEP(codeAt(codes, i) & 1u, prob[i]);
-    for (; i + 4 <= ce; i += 4) {
-      const uint32_t four = codes[i >> 2];
-      BWTC_RC_STEP(four & 1u, prob[i]);
-      BWTC_RC_STEP((four >> 2) & 1u, prob[i + 1]);
-      BWTC_RC_STEP((four >> 4) & 1u, prob[i + 2]);
-      BWTC_RC_STEP((four >> 6) & 1u, prob[i + 3]);
-    }
-    for (; i < ce; ++i) BWTC_RC_STEP(codeAt(codes, i) & 1u, prob[i]);
-#undef BWTC_RC_STEP
-    c.used = static_cast<size_t>(o - c.out->data());
-  }
-  c.lo = lo; c.size = size; c.i = std::max(c.i, until);
-}
-
-// Two chains stepped alternately.  A chain alone is bound by its multiply latency and by the
-// mispredicted byte-output branch; with the first output byte written branch-free (a second
-// byte in the same step is rare and stays a branch) two independent chains overlap and the
-// pair costs 1.7 ns per element instead of 2.1-2.3 on the GPU box's EPYC
-// (scripts/dev/rcbench.cpp).  Runs until the shorter chain ends.
-void runChainPair(CoderChain& a, CoderChain& b, const uint8_t* codes, const uint16_t* prob) {
-  const uint64_t kChunk = 8192;
-  uint64_t left = std::min(a.e - a.i, b.e - b.i);
-  while (left > 0) {
-    const uint64_t n = std::min(left, kChunk);
-    uint8_t* oa = a.room(kChunk);
-    uint8_t* ob = b.room(kChunk);
-    uint32_t loa = a.lo, sa = a.size, lob = b.lo, sb = b.size;
-    uint64_t ia = a.i, ib = b.i;
-#define BWTC_RC_FREE(lo, size, o, i)                                                                      \
-    {                                                                                                      \
-      const uint32_t bit = codeAt(codes, i) & 1u;                                                          \
-      const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * prob[i] + 2048u) >> 12);     \
-      lo = bit ? lo : lo + t + 1;                                                                          \
-      size = bit ? t - 1 : size - t - 1;                                                                   \
-      const uint32_t same = ((lo ^ (lo + size + 1)) & 0xFF000000u) == 0;                                   \
-      *o = static_cast<uint8_t>(lo >> 24);                                                                 \
-      o += same;                                                                                           \
-      lo = same ? lo << 8 : lo;                                                                            \
-      size = same ? (size << 8) + 510u : size;                                                             \
-      while (__builtin_expect(same && ((lo ^ (lo + size + 1)) & 0xFF000000u) == 0, 0)) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; } \
-      ++i;                                                                                                 \
-    }
-    for (uint64_t k = 0; k < n; ++k) {
-      BWTC_RC_FREE(loa, sa, oa, ia)
-      BWTC_RC_FREE(lob, sb, ob, ib)
-    }
-#undef BWTC_RC_FREE
-    a.lo = loa; a.size = sa; a.i = ia; a.used = static_cast<size_t>(oa - a.out->data());
-    b.lo = lob; b.size = sb; b.i = ib; b.used = static_cast<size_t>(ob - b.out->data());
-    left -= n;
-  }
-}
-
 // union of the length codes of one section as a binary trie
 struct LengthTrie {
   struct N { int child[2]; bool terminal; uint32_t group; N() : terminal(false), group(0) { child[0] = child[1] = -1; } };
@@ -1097,6 +1003,11 @@ uint64_t StreamCoder::largestSectionElements() const {
   return pos_[sec.group_base + sec.level_first.back()] - pos_[sec.group_base];
 }
 
+uint64_t StreamCoder::sectionElements(size_t k) const {
+  const StreamPlan::Section& sec = plan_.sections[sections_[k]];
+  return pos_[sec.group_base + sec.level_first.back()] - pos_[sec.group_base];
+}
+
 void StreamCoder::model(size_t k, uint16_t* prob) const {
   const Task& t = tasks_[k];
   if (t.type == kInteger) { modelGroup<kInteger>(model_, codes_, t.begin, t.end, 0, prob); return; }
@@ -1136,6 +1047,20 @@ void StreamCoder::codeSection(size_t k, const uint16_t* prob, std::vector<Sectio
   startSection(k, out, &c);
   runChain(c, codes_, prob, c.e);
   c.finish();                                                          // endContextBlock, WaveletCoders.cpp:62-68
+}
+
+void StreamCoder::describeChain(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out, ChainDesc* d) const {
+  const size_t s = sections_[k];
+  const StreamPlan::Section& sec = plan_.sections[s];
+  std::vector<uint8_t>& bytes = (*out)[s].bytes;
+  bytes = sec.prefix;
+  const uint32_t* pos = pos_ + sec.group_base;
+  d->codes = codes_;
+  d->prob = prob;
+  d->begin = pos[0];
+  d->end = pos[sec.level_first.back()];
+  d->out = &bytes;
+  d->cookie = 0;
 }
 
 void StreamCoder::startSection(size_t k, std::vector<SectionOutput>* out, void* chain) const {
@@ -1202,8 +1127,25 @@ void codeStreams(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_
   const auto t1 = std::chrono::steady_clock::now();
   {
     std::atomic<size_t> cursor(0);
-    const unsigned engines = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>((coder.sectionTasks() + 1) / 2)));
-    parallelFor(engines, engines, 0, [&](size_t) { coder.codeSectionsPaired(&cursor, prob.data(), out); });
+    if (simdCoderAvailable() && coder.sectionTasks() >= 8) {
+      // sixteen sections per thread at a time (wavelet_rc.hpp); the engines share one cursor
+      struct Chains : ChainSource {
+        const StreamCoder* coder; const uint16_t* prob; std::vector<SectionOutput>* out; std::atomic<size_t>* cursor;
+        bool next(ChainDesc* d) {
+          const size_t k = cursor->fetch_add(1);
+          if (k >= coder->sectionTasks()) return false;
+          coder->describeChain(k, prob, out, d);
+          return true;
+        }
+        void done(void*) {}
+      } chains;
+      chains.coder = &coder; chains.prob = prob.data(); chains.out = out; chains.cursor = &cursor;
+      const unsigned engines = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>(coder.sectionTasks() / 16 + 1)));
+      parallelFor(engines, engines, 0, [&](size_t) { runCoderLanes(chains); });
+    } else {
+      const unsigned engines = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>((coder.sectionTasks() + 1) / 2)));
+      parallelFor(engines, engines, 0, [&](size_t) { coder.codeSectionsPaired(&cursor, prob.data(), out); });
+    }
   }
   if (debug) {
     const auto t2 = std::chrono::steady_clock::now();

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include "wavelet_rc.hpp"
 #include "wavelet_simd.hpp"
 
 namespace bwtc {
@@ -113,10 +114,14 @@ class StreamCoder {
   bool taskIsInteger(size_t k) const { return tasks_[k].type == kInteger; }
   size_t sectionTasks() const { return sections_.size(); }
   uint64_t largestSectionElements() const;                // coded elements of the longest range-coder chain
+  uint64_t sectionElements(size_t k) const;               // coded elements of section task k (tasks are sorted largest first)
   void codeSection(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out) const;   // out[section]
   // the same for sections taken from a shared cursor, two chains at a time in one thread;
   // returns how many sections this call finished
   size_t codeSectionsPaired(std::atomic<size_t>* cursor, const uint16_t* prob, std::vector<SectionOutput>* out) const;
+  // section task k as a chain for the 16-lane coder engine (wavelet_rc.hpp): puts the section's
+  // prefix into out[section] and describes the elements to code
+  void describeChain(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out, ChainDesc* d) const;
 
  private:
   struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };

@@ -18,19 +18,34 @@ uint64_t since(const std::chrono::steady_clock::time_point& t0) {
 }
 }  // namespace
 
-HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements)
+HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsigned depth)
     : groups_(), pool_(threads), huge_(huge_group_elements) {
   // a few lane engines keep up with the GPU; the range coders need the other threads
-  const unsigned share = envNumber("BWTC_HIP_ENGINE_SHARE", 4);
-  max_engines_ = std::max(1u, (pool_.size() + share - 1) / share);
+  const unsigned P = pool_.size();
+  const char* force = std::getenv("BWTC_HIP_CODER_LANES");
+  const bool lanes = bwtc::wavelet::simdCoderAvailable() && (force ? force[0] == '1' : depth >= kLaneDepth);
   // two tasks per block, each stepping two sections' chains at a time (StreamCoder::
   // codeSectionsPaired): the pair costs a quarter less host time than two chains run apart, and
   // with two tasks the block's longest chain is alone again (at its own full speed) as soon as
-  // the other sections are used up.  (One task -- the longest chain paired all the way -- costs a
-  // tenth less host time again but lengthens every block by 0.3 s: measured slower over 48
-  // blocks, equal over 96.)
+  // the other sections are used up.
   coder_tasks_ = envNumber("BWTC_HIP_CODER_TASKS", 2);
+  // Engines are long-running tasks, so their numbers split the threads between the stages.  With
+  // the lane coder a text block costs 0.5 core-seconds of models and 0.35 of range coding
+  // (measured on the GPU box's EPYC 9575F): 7 + 6 of 16 threads, the rest for the scalar tasks
+  // of the huge groups.  Without it the range coders are per-block tasks and the model engines
+  // get a quarter of the threads, as measured best in round 1.
+  max_engines_ = std::max(1u, envNumber("BWTC_HIP_MODEL_ENGINES", lanes ? (P * 7 + 15) / 16 : (P + 3) / 4));
+  max_coder_engines_ = lanes ? envNumber("BWTC_HIP_CODER_ENGINES", std::max(1u, (P * 6 + 15) / 16)) : 0u;
+  // Optional middle way (BWTC_HIP_LONG_CHAIN_MI=n, off by default): chains of n Mi elements and
+  // more go to scalar engines that step two such chains, of different blocks, alternately, the
+  // others to the lanes.  Measured no better than either pure route at any depth.
+  long_chain_ = static_cast<uint64_t>(std::getenv("BWTC_HIP_LONG_CHAIN_MI") ? std::atoi(std::getenv("BWTC_HIP_LONG_CHAIN_MI")) : 0) << 20;
+  if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests: small blocks
+  if (long_chain_ == 0) long_chain_ = ~static_cast<uint64_t>(0);
+  max_pair_engines_ = lanes && long_chain_ != ~static_cast<uint64_t>(0) ? envNumber("BWTC_HIP_PAIR_ENGINES", std::max(1u, (P * 3 + 7) / 8)) : 0u;
   groups_.on_block_modelled = [this](const std::shared_ptr<WaveletJob>& j) { submitSections(j); };
+  chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
+  long_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
 }
 
 HostPipeline::~HostPipeline() {}
@@ -52,8 +67,7 @@ void HostPipeline::finishNow(WaveletJob& job) {
   for (int i = 0; i < 6; ++i) rec[i] = static_cast<uint8_t>(len >> (8 * (5 - i)));
   if (job.user_out && rec.size() <= job.user_cap) std::memcpy(job.user_out, rec.data(), rec.size());
   job.t_finished = std::chrono::steady_clock::now();
-  { std::lock_guard<std::mutex> g(job.mu); job.done = true; }
-  job.cv.notify_all();
+  { std::lock_guard<std::mutex> g(job.mu); job.done = true; job.cv.notify_all(); }
 }
 
 void HostPipeline::finish(WaveletJob& job) {
@@ -64,6 +78,18 @@ void HostPipeline::finish(WaveletJob& job) {
 // Every group of the block is modelled: its sections' range coders.
 void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
   jobp->t_modelled = std::chrono::steady_clock::now();
+  if (max_coder_engines_) {
+    // section tasks are sorted largest first: [0, n_long) are the very long ones
+    size_t n_long = 0;
+    while (max_pair_engines_ && n_long < jobp->coder->sectionTasks() && jobp->coder->sectionElements(n_long) >= long_chain_) ++n_long;
+    if (long_chains_.add(jobp, 0, n_long, max_pair_engines_)) {
+      pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(long_chains_, static_cast<int>(envNumber("BWTC_HIP_LONG_LANES", 2)), &clock.coder_ns); });
+    }
+    if (chains_.add(jobp, n_long, jobp->coder->sectionTasks(), max_coder_engines_)) {
+      pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(chains_, 16, &clock.coder_ns); });
+    }
+    return;
+  }
   std::vector<std::function<void()> > next;
   // ... and more of them when no section dominates (256 equal sections of a block of random
   // bytes): as many as the block's elements are multiples of its longest chain

@@ -145,6 +145,31 @@ class BlockGroupSource : public bwtc::wavelet::GroupSource {
   unsigned engines_[3];
 };
 
+// The sections of all modelled blocks, oldest block first and largest section first within a
+// block, for the 16-lane coder engines (wavelet_rc.hpp): a block's one or two long chains share
+// vectors with the chains of the blocks behind it instead of running alone.
+class BlockChainSource : public bwtc::wavelet::ChainSource {
+ public:
+  BlockChainSource() : engines_(0) {}
+  // queues the section tasks [first, last) of a modelled block (largest first); true = the caller
+  // should start another engine
+  bool add(const std::shared_ptr<WaveletJob>& job, size_t first, size_t last, unsigned max_engines);
+  bool next(bwtc::wavelet::ChainDesc* d);
+  void done(void* cookie);
+  bool retire() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!queue_.empty()) return false;
+    --engines_;
+    return true;
+  }
+  std::function<void(WaveletJob&)> on_block_coded;     // set once: the block's last section is flushed
+ private:
+  struct Entry { std::shared_ptr<WaveletJob> job; size_t at, end; };
+  std::mutex mu_;
+  std::deque<Entry> queue_;
+  unsigned engines_;
+};
+
 // One block between bwtc_hip_wavelet_encode_device_begin and ..._end.
 struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   virtual ~WaveletJob() {}
@@ -177,7 +202,15 @@ namespace bwtc_hip {
 // (tests/cpp/host_pipeline_test.cpp) drive the same object.
 class HostPipeline {
  public:
-  HostPipeline(unsigned threads, uint64_t huge_group_elements);
+  // depth = how many blocks the caller keeps under way at most.  It picks the range-coder route:
+  // the 16-lane engines code sixteen sections at a time for a third of the scalar loop's host
+  // time, but a lane advances ITS chain four to five times slower than the scalar loop, so a
+  // block whose longest section holds half of its elements (the text blocks) stays under way for
+  // three seconds instead of one -- that only pays when the pipeline is deep enough to hide it
+  // (>= kLaneDepth blocks, 1.2 GB of host memory each).  Shallower pipelines keep the scalar
+  // chains, two per task (codeSectionsPaired).  BWTC_HIP_CODER_LANES=1 / 0 overrides.
+  HostPipeline(unsigned threads, uint64_t huge_group_elements, unsigned depth = 16);
+  static constexpr unsigned kLaneDepth = 48;
   ~HostPipeline();                                   // joins the workers; every queued block must be finished
   // job: record (header part), plan, coded_pos, codes, prob (room for the coded elements), rank and
   // user_out/user_cap set.  Builds the block's coder from the carried model state and queues its
@@ -192,9 +225,14 @@ class HostPipeline {
   void submitSections(const std::shared_ptr<WaveletJob>& job);
   void finish(WaveletJob& job);
   BlockGroupSource groups_;                          // before the pool: the workers are joined first
+  BlockChainSource chains_;                          // sections for the 16-lane coder engines
+  BlockChainSource long_chains_;                     // very long sections: scalar engines, two chains at a time
   WorkerPool pool_;
   uint64_t huge_;
   unsigned max_engines_;
+  unsigned max_coder_engines_;                       // 16-lane range-coder engines (0: scalar pairs per block)
+  unsigned max_pair_engines_;                        // scalar engines for the very long chains
+  uint64_t long_chain_;                              // elements from which a chain counts as very long
   size_t coder_tasks_;
 };
 
@@ -239,6 +277,42 @@ inline bool BlockGroupSource::next(bwtc::wavelet::ModelGroupDesc* d, int prefer)
   job->coder->describe(k, job->prob.data(), d);
   d->cookie = job.get();
   return true;
+}
+
+inline bool BlockChainSource::add(const std::shared_ptr<WaveletJob>& job, size_t first, size_t last, unsigned max_engines) {
+  if (first >= last) return false;
+  Entry e;
+  e.job = job;
+  e.at = first;
+  e.end = last;
+  std::lock_guard<std::mutex> g(mu_);
+  queue_.push_back(std::move(e));
+  if (engines_ >= max_engines) return false;
+  ++engines_;
+  return true;
+}
+
+inline bool BlockChainSource::next(bwtc::wavelet::ChainDesc* d) {
+  std::shared_ptr<WaveletJob> job;
+  size_t k = 0;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    while (!queue_.empty() && queue_.front().at >= queue_.front().end) queue_.pop_front();
+    if (queue_.empty()) return false;
+    job = queue_.front().job;
+    k = queue_.front().at++;
+  }
+  job->coder->describeChain(k, job->prob.data(), &job->outs, d);
+  d->cookie = job.get();
+  return true;
+}
+
+inline void BlockChainSource::done(void* cookie) {
+  WaveletJob* job = static_cast<WaveletJob*>(cookie);
+  const std::shared_ptr<WaveletJob> keep = job->shared_from_this();   // whoever waits for the block may drop it the moment it is done
+  bool last;
+  { std::lock_guard<std::mutex> g(job->mu); last = --job->sections_left == 0; }
+  if (last) on_block_coded(*job);
 }
 
 inline void BlockGroupSource::done(void* cookie) {

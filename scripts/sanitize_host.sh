@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/bwtc_amd/csrc
 OUT=${TMPDIR:-/tmp}/bwtc_sanitize
 mkdir -p "$OUT"
-HOSTSRC="$SRC/wavelet_pipeline.cpp $SRC/wavelet_host.cpp $SRC/wavelet_simd.cpp $SRC/entropy_host.cpp"
+HOSTSRC="$SRC/wavelet_pipeline.cpp $SRC/wavelet_host.cpp $SRC/wavelet_simd.cpp $SRC/wavelet_rc.cpp $SRC/entropy_host.cpp"
 LINK="-L$ROOT/oracle -loracle -lpthread -Wl,-rpath,$ROOT/oracle"
 for SAN in thread address,undefined; do
   g++ -O1 -g -std=c++17 -fsanitize=$SAN -fno-sanitize-recover=all -I"$ROOT/include" -I"$SRC" \

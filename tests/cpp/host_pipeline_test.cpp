@@ -7,6 +7,7 @@
 // TEST INFRASTRUCTURE: links the oracle (liboracle.so) as transform + reference encoder, and the
 // product library for its internal C++ classes.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -142,6 +143,16 @@ int main() {
   runStream(rng, 6, 400000, 3, 50000, 8);          // several huge groups per block: paired scalar tasks
   runStream(rng, 5, 200000, 1, 20000, 4);          // one worker thread does everything in turn
   runStream(rng, 12, 60000, 8, 1000, 1);           // many small blocks, nearly everything "huge"
+  // range-coder engines: a block's longest chains to the scalar pair engines (threshold lowered so
+  // that some qualify), the others to the 16-lane engines; then everything in lanes; then no lanes
+  setenv("BWTC_HIP_CODER_LANES", "1", 1);
+  setenv("BWTC_HIP_LONG_CHAIN_ELEMENTS", "20000", 1);
+  runStream(rng, 9, 250000, 6, 32u << 20, 8);
+  setenv("BWTC_HIP_LONG_CHAIN_ELEMENTS", "0", 1);
+  runStream(rng, 9, 250000, 6, 32u << 20, 8);
+  unsetenv("BWTC_HIP_LONG_CHAIN_ELEMENTS");
+  runStream(rng, 7, 300000, 5, 32u << 20, 8);
+  unsetenv("BWTC_HIP_CODER_LANES");
   std::printf(failures ? "%d FAILURES\n" : "host pipeline: all tests passed\n", failures);
   return failures ? 1 : 0;
 }
