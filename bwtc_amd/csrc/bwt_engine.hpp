@@ -57,8 +57,18 @@ class PinnedBytes {
 };
 
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
+struct WaveletSectionStats;
 struct DeviceWaveletJob : WaveletJob {
   PinnedBytes codes_owner;
+  // between wavelet_encode_prepare and wavelet_encode_queue
+  bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
+  bool host_route = false;             // coded by encodeSections at queue time instead
+  bool queued = false;
+  std::vector<bwtc::wavelet::SectionRuns> host_secs;
+  std::vector<u8> host_run_sym;
+  std::vector<u32> host_run_start;
+  std::shared_ptr<WaveletSectionStats> host_stats;
+  unsigned host_threads = 0;
 };
 
 struct BwtEngine {
@@ -201,6 +211,12 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket);
 int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes);
+// _begin in two halves, for a stream whose blocks are spread over several contexts: _prepare is
+// everything that does not depend on earlier blocks, _queue hands the block to the workers with
+// the carried model state after the previous block and reports the state after this one.
+int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket);
+int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out);
 void wavelet_pipeline_release(BwtEngine& e);
 
 // Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).

@@ -361,6 +361,21 @@ int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt
   return wavelet_encode_begin(e, d_bwt, size, lf, n_lf, freqs, pick_threads(threads), out, out_cap, ticket);
 }
 
+int bwtc_hip_wavelet_encode_device_prepare(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                           const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                           uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                           uint64_t* ticket) {
+  if (!ctx || (!d_bwt && size) || !lf || !freqs || !out || !ticket) return -1;
+  BwtEngine& e = ctx->eng;
+  if (size > e.max_block) return -1;
+  return wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, pick_threads(threads), out, out_cap, ticket);
+}
+
+int bwtc_hip_wavelet_encode_queue(bwtc_hip_ctx* ctx, uint64_t ticket, uint32_t state_in, uint32_t* state_out) {
+  if (!ctx || !state_out || state_in > 7) return -1;
+  return wavelet_encode_queue(ctx->eng, ticket, state_in, state_out);
+}
+
 int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes) {
   if (!ctx || !out_bytes) return -1;
   return wavelet_encode_end(ctx->eng, ticket, out_bytes);

@@ -23,6 +23,40 @@ namespace bwtc_hip {
 
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
+  int rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);
+  if (rc) return rc;
+  return wavelet_encode_queue(e, *ticket, e.wavelet_state, &e.wavelet_state);
+}
+
+// Second half of _begin: the block joins its stream.  state_in = the main model's carried state
+// after the previous block of the stream (whichever context coded that one), *state_out = the
+// state after this block.
+int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out) {
+  std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.find(ticket);
+  if (it == e.jobs.end() || !state_out) return -1;
+  std::shared_ptr<DeviceWaveletJob> jobp = it->second;
+  DeviceWaveletJob& job = *jobp;
+  if (job.queued) return -1;
+  job.queued = true;
+  if (job.host_route) {
+    // shapes the stream kernels do not take: the library's own tree builder, here and now
+    u32 st = state_in;
+    bwtc::wavelet::encodeSections(job.host_secs, job.host_threads, &st, &job.outs, e.wavelet_model);
+    *state_out = st;
+    job.host_run_sym.clear(); job.host_run_sym.shrink_to_fit();
+    job.host_run_start.clear(); job.host_run_start.shrink_to_fit();
+    HostPipeline::finishNow(job);
+    return 0;
+  }
+  if (!job.streams_ready) { *state_out = state_in; HostPipeline::finishNow(job); return 0; }
+  *state_out = e.pipeline->queue(jobp, state_in, e.wavelet_model);
+  return 0;
+}
+
+// First half of _begin: everything that does not depend on the blocks before this one (run
+// scanner, plan, stream kernels, copy of the streams to the host).
+int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
+                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
   // bounded number of blocks under way; only ..._end frees a place, so waiting here could never help
   if (e.jobs.size() >= e.max_inflight) return -6;
@@ -42,7 +76,6 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
   const u32 nsec = (u32)st.sections.size();
   rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
   for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
-  bool queued = false;
   if (size && nsec) {
     const u32 n_runs = st.first_run[nsec];
     std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
@@ -90,35 +123,39 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
         std::fprintf(stderr, "\n");
       }
       const auto t3 = std::chrono::steady_clock::now();
-      // nothing can fail from here on: the stream's carried model state moves on
-      e.wavelet_state = e.pipeline->queue(jobp, e.wavelet_state, e.wavelet_model);
       if (debug) {
-        const auto t4 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; run scanner %.1f ms, plan %.1f ms, "
-                     "device streams %.1f ms, hand-over %.1f ms, queueing %.1f ms on %u threads\n", n_runs,
+                     "device streams %.1f ms, hand-over %.1f ms, %u threads\n", n_runs,
                      (unsigned long long)e.wt_elements, (unsigned long long)e.wt_coded, job.plan.group_type.size(),
                      std::chrono::duration<double, std::milli>(t0 - t_begin).count(),
                      std::chrono::duration<double, std::milli>(t1 - t0).count(),
                      std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                     std::chrono::duration<double, std::milli>(t3 - t2).count(),
-                     std::chrono::duration<double, std::milli>(t4 - t3).count(), e.pipeline->threads());
+                     std::chrono::duration<double, std::milli>(t3 - t2).count(), e.pipeline->threads());
       }
-      queued = true;
+      job.streams_ready = true;
     } else {
-      // the runs themselves: symbols and start offsets, left in the workspace by the scanner
-      std::vector<u8> run_sym(n_runs);
-      std::vector<u32> run_start((size_t)n_runs + 1);
-      BWTC_HIP_TRY(hipMemcpyAsync(run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(hipMemcpyAsync(run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
+      // the runs themselves: symbols and start offsets, left in the workspace by the scanner; the
+      // statistics the sections point into move into the job with them
+      job.host_run_sym.resize(n_runs);
+      job.host_run_start.resize((size_t)n_runs + 1);
+      BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
+      BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
       BWTC_HIP_TRY(e.wait());
+      job.host_stats.reset(new WaveletSectionStats());
+      *job.host_stats = std::move(st);
+      const WaveletSectionStats& hs = *job.host_stats;
       for (u32 s = 0; s < nsec; ++s) {
-        secs[s].symbols = run_sym.data() + st.first_run[s];
-        secs[s].starts = run_start.data() + st.first_run[s];
+        secs[s].symbols = job.host_run_sym.data() + hs.first_run[s];
+        secs[s].starts = job.host_run_start.data() + hs.first_run[s];
+        secs[s].run_freqs = &hs.run_freqs[(size_t)s * 256];
+        secs[s].dist = hs.dist[s].data();
+        secs[s].n_dist = hs.dist[s].size();
       }
-      bwtc::wavelet::encodeSections(secs, threads, &e.wavelet_state, &job.outs, e.wavelet_model);
+      job.host_secs = secs;
+      job.host_threads = threads;
+      job.host_route = true;
     }
   }
-  if (!queued) HostPipeline::finishNow(job);
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;
   return 0;
@@ -129,6 +166,7 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
   if (it == e.jobs.end() || !out_bytes) return -1;
   std::shared_ptr<DeviceWaveletJob> jobp = it->second;
   DeviceWaveletJob& job = *jobp;
+  if (!job.queued) return -1;                        // prepared but never given its place in a stream
   HostPipeline::wait(job);
   if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
     std::fprintf(stderr, "wavelet block %llu: queued -> modelled %.0f ms, -> finished %.0f ms, -> collected %.0f ms\n",
@@ -152,7 +190,7 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
 
 void wavelet_pipeline_release(BwtEngine& e) {
   for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
-    HostPipeline::wait(*it->second);                // uncollected blocks are finished, not abandoned half way
+    if (it->second->queued) HostPipeline::wait(*it->second);   // uncollected blocks are finished, not abandoned half way
   e.jobs.clear();
   if (e.pipeline && std::getenv("BWTC_HIP_DEBUG") && e.pipeline->clock.blocks)
     std::fprintf(stderr, "wavelet pipeline: %llu blocks; host time in models %.3f s, in range coders %.3f s (summed over threads)\n",

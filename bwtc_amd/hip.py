@@ -40,6 +40,7 @@ EXPORTS = [
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
+    "bwtc_hip_wavelet_encode_device_prepare", "bwtc_hip_wavelet_encode_queue",
     "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
@@ -104,6 +105,8 @@ def load():
     L.bwtc_hip_wavelet_encode_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_encode_device_begin.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_wavelet_encode_end.argtypes = [_vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode_device_prepare.argtypes = [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_wavelet_encode_queue.argtypes = [_vp, _u64, _u32, ctypes.POINTER(_u32)]
     L.bwtc_hip_wavelet_depth.restype = ctypes.c_uint32
     L.bwtc_hip_wavelet_depth.argtypes = [_vp]
     L.bwtc_hip_wavelet_reset.restype = None
@@ -358,6 +361,24 @@ class Context:
                                                              ctypes.byref(t)),
                "bwtc_hip_wavelet_encode_device_begin")
         return int(t.value)
+
+    def wavelet_encode_device_prepare(self, d_bwt_ptr, size, lf, freqs, out, threads=0):
+        """The half of _begin that needs nothing from earlier blocks (all the device work)."""
+        lf = np.ascontiguousarray(lf, dtype=np.uint32)
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        t = _u64(0)
+        _check(self.lib.bwtc_hip_wavelet_encode_device_prepare(self.handle, _vp(d_bwt_ptr), size, _ptr(lf), lf.size,
+                                                               _ptr(freqs), threads, _ptr(out), out.size,
+                                                               ctypes.byref(t)),
+               "bwtc_hip_wavelet_encode_device_prepare")
+        return int(t.value)
+
+    def wavelet_encode_queue(self, ticket, state_in):
+        """Gives a prepared block its place in a stream; returns the carried state after it."""
+        st = _u32(0)
+        _check(self.lib.bwtc_hip_wavelet_encode_queue(self.handle, ticket, state_in, ctypes.byref(st)),
+               "bwtc_hip_wavelet_encode_queue")
+        return int(st.value)
 
     def wavelet_encode_end(self, ticket):
         """Second half: waits for the block, returns the record's size."""

@@ -485,6 +485,9 @@ class Compressor {
     m_bwtmanager.setStartingPoints(startingPoints);
   }
   size_t writeGlobalHeader() { m_out->writeByte((byte)m_options.entropyCoder); return 1; }
+  // The blocks of the stream farmed over several contexts, one per listed device (the same device
+  // may be listed more than once): bwtc_hip_farm.hpp.  Same bytes as compress().
+  size_t compressFarmed(const std::vector<int>& devices, uint32 startingPoints);
 
   // Compressor.cpp:65-118 with no precompression: every read of bwtBlockSize bytes is one
   // precompressor block holding one BWT block (pbBlockSize == bwtBlockSize, :81).

@@ -10,6 +10,9 @@
 //     -i, --stdin        read from standard input
 //     -c, --stdout       write to standard output
 //     -d, --device N     GPU to use                                          (default 0)
+//     -D, --devices LIST farm the blocks of the stream over these GPUs, e.g. 0,1,2,3 (one context,
+//                        one thread and one page-locked staging ring per entry; the same bytes as
+//                        with one device)
 //     -v, --verb N       verbosity
 // Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc m/M (models
 // whose reference implementation reads past its table) are rejected, --prepr is not offered.
@@ -19,6 +22,7 @@
 #include <string>
 
 #include "bwtc_hip.hpp"
+#include "bwtc_hip_farm.hpp"
 
 int main(int argc, char** argv) {
   size_t mem = 100;
@@ -26,13 +30,15 @@ int main(int argc, char** argv) {
   char bwt = 'a', enc = 'B';                                     // compress.cpp:115-118 defaults
   bool from_stdin = false, to_stdout = false;
   int verbosity = 0, device = 0;
+  std::vector<int> devices;
   static option longopts[] = {{"mem", required_argument, 0, 'm'},   {"starts", required_argument, 0, 's'},
                               {"bwt", required_argument, 0, 'b'},   {"enc", required_argument, 0, 'e'},
                               {"stdin", no_argument, 0, 'i'},       {"stdout", no_argument, 0, 'c'},
                               {"device", required_argument, 0, 'd'}, {"verb", required_argument, 0, 'v'},
+                              {"devices", required_argument, 0, 'D'},
                               {"help", no_argument, 0, 'h'},        {0, 0, 0, 0}};
   int o;
-  while ((o = getopt_long(argc, argv, "m:s:e:icd:v:h", longopts, 0)) != -1) {
+  while ((o = getopt_long(argc, argv, "m:s:e:icd:D:v:h", longopts, 0)) != -1) {
     switch (o) {
       case 'm': mem = std::strtoul(optarg, 0, 10); break;
       case 's': starts = (unsigned)std::strtoul(optarg, 0, 10); break;
@@ -41,6 +47,9 @@ int main(int argc, char** argv) {
       case 'i': from_stdin = true; break;
       case 'c': to_stdout = true; break;
       case 'd': device = std::atoi(optarg); break;
+      case 'D':
+        for (const char* p = optarg; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        break;
       case 'v': verbosity = std::atoi(optarg); break;
       default:
         std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|b|u|H] [-i] [-c] [input] [output]\n");
@@ -63,8 +72,13 @@ int main(int argc, char** argv) {
   const auto t0 = std::chrono::steady_clock::now();
   bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name),
                               mem * 1000000, enc);                // compress.cpp:192-193
-  compressor.initializeBwtAlgorithm(bwt, starts, device);
-  const size_t compressed = compressor.compress(1);
+  size_t compressed;
+  if (!devices.empty()) {
+    compressed = compressor.compressFarmed(devices, starts < 1 ? 1 : starts > 256 ? 256 : starts);
+  } else {
+    compressor.initializeBwtAlgorithm(bwt, starts, device);
+    compressed = compressor.compress(1);
+  }
   const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (verbosity > 0) std::fprintf(stderr, "Compressed size: %zu bytes, %.3f s\n", compressed, s);
   return 0;

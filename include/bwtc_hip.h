@@ -199,6 +199,20 @@ int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt
                                          uint32_t threads, uint8_t* out, uint64_t out_cap,
                                          uint64_t* ticket);
 int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* out_bytes);
+/* _begin in two halves, for ONE stream whose blocks are farmed over several contexts (one per
+ * GPU): _prepare does everything that does not depend on earlier blocks -- the
+ * whole device half -- and may run on all contexts at once; _queue gives the block its place in
+ * the stream: state_in is the main model's carried state after the previous block (4 for the
+ * first block of a stream; the reference's WaveletEncoder carries it inside its m_probModel,
+ * probmodels/FSM.hpp:196-205), *state_out the state after this block, to be passed to the _queue
+ * of the next block on whichever context holds it.  _queue calls of a stream are made in block
+ * order; each returns at once.  _begin = _prepare + _queue with the context's own state. */
+int bwtc_hip_wavelet_encode_device_prepare(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
+                                           const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
+                                           uint32_t threads, uint8_t* out, uint64_t out_cap,
+                                           uint64_t* ticket);
+int bwtc_hip_wavelet_encode_queue(bwtc_hip_ctx* ctx, uint64_t ticket, uint32_t state_in,
+                                  uint32_t* state_out);
 /* Blocks that may be between _begin and _end at once on this context. */
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
 /* Host time the context's worker threads have spent so far in the two host stages of the wavelet

@@ -137,8 +137,76 @@ static void runStream(std::mt19937& rng, size_t blocks, size_t block_size, unsig
         threads, (unsigned long long)huge, stream.size(), wn);
 }
 
+// One stream farmed over several pipelines (= contexts, one per GPU in the farm): block
+// k goes to pipeline k mod N and joins the stream with the model state the previous block's
+// pipeline reported -- what BlockFarm does through bwtc_hip_wavelet_encode_queue.  The stream must
+// be the sequential encoder's.
+static void runFarmedStream(std::mt19937& rng, size_t blocks, size_t block_size, unsigned n_pipes, unsigned sp) {
+  std::vector<uint8_t> data = text(rng, blocks * block_size - block_size / 4);
+  std::vector<std::unique_ptr<HostPipeline> > pipes;
+  for (unsigned i = 0; i < n_pipes; ++i) pipes.push_back(std::unique_ptr<HostPipeline>(new HostPipeline(2, 40000)));
+  uint32_t state = 4;
+  std::vector<std::shared_ptr<HostJob> > jobs;
+  std::vector<size_t> sizes;
+  for (size_t off = 0, k = 0; off < data.size(); off += block_size, ++k) {
+    const size_t n = std::min(block_size, data.size() - off);
+    std::vector<uint8_t> bwt(data.begin() + off, data.begin() + off + n);
+    bwt.push_back(0);
+    uint32_t lf[256], n_lf = 0, freqs[256];
+    std::memset(freqs, 0, sizeof freqs);
+    CHECK(orc_bwt_block(&bwt[0], (uint32_t)n, sp, lf, &n_lf, freqs) == 0, "oracle transform");
+    bwt.resize(n);
+    BlockRuns runs;
+    scanRuns(bwt, freqs, &runs);
+    const size_t nsec = runs.sections.size();
+    std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
+    for (size_t s = 0; s < nsec; ++s) {
+      secs[s].symbols = runs.run_sym.data() + runs.first_run[s];
+      secs[s].starts = runs.run_start.data() + runs.first_run[s];
+      secs[s].n_runs = runs.first_run[s + 1] - runs.first_run[s];
+      secs[s].run_freqs = &runs.run_freqs[s * 256];
+      secs[s].dist = runs.dist[s].data();
+      secs[s].n_dist = runs.dist[s].size();
+    }
+    std::shared_ptr<HostJob> job(new HostJob());
+    job->rank = k / n_pipes + 1;
+    job->record.assign(6, 0);
+    bwtc::writeBWTBlockHeader(lf, n_lf, job->record);
+    job->record.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
+    for (size_t s = 0; s < nsec; ++s) bwtc::utils::packInteger(runs.sections[s], job->record);
+    CHECK(bwtc::wavelet::planStreams(secs, &job->plan), "planStreams");
+    CHECK(bwtc::wavelet::expandStreamsOnHost(job->plan, secs, &job->coded_pos, &job->codes_owner), "expandStreamsOnHost");
+    job->codes_owner.resize(job->codes_owner.size() + 16);
+    job->codes = job->codes_owner.data();
+    CHECK(job->prob.reserve(job->coded_pos.back() + 8), "probability buffer");
+    job->out.assign(orc_compress_bound(n), 0);
+    job->user_out = job->out.data();
+    job->user_cap = job->out.size();
+    state = pipes[k % n_pipes]->queue(job, state, 'B');               // the state travels from pipeline to pipeline
+    jobs.push_back(job);
+    sizes.push_back(n);
+  }
+  std::vector<uint8_t> stream(1, 'B');
+  for (size_t k = 0; k < jobs.size(); ++k) {
+    HostPipeline::wait(*jobs[k]);
+    std::vector<uint8_t> packed;
+    bwtc::utils::packInteger(sizes[k], packed);
+    stream.insert(stream.end(), packed.begin(), packed.end());
+    stream.push_back(1);
+    stream.push_back(0);
+    stream.insert(stream.end(), jobs[k]->out.begin(), jobs[k]->out.begin() + jobs[k]->record.size());
+  }
+  stream.push_back(0);
+  std::vector<uint8_t> want(orc_compress_bound(data.size()) + blocks * 8192);
+  const size_t wn = orc_compress_B(&data[0], data.size(), block_size, sp, &want[0], want.size());
+  CHECK(wn == stream.size() && std::memcmp(&want[0], &stream[0], wn) == 0,
+        "%zu blocks over %u pipelines: stream differs from the oracle's (%zu vs %zu bytes)", blocks, n_pipes, stream.size(), wn);
+}
+
 int main() {
   std::mt19937 rng(4242);
+  runFarmedStream(rng, 9, 150000, 2, 8);           // one stream over two pipelines, then over three
+  runFarmedStream(rng, 7, 90000, 3, 1);
   runStream(rng, 7, 300000, 4, 32u << 20, 8);      // lanes only (no group reaches the threshold)
   runStream(rng, 6, 400000, 3, 50000, 8);          // several huge groups per block: paired scalar tasks
   runStream(rng, 5, 200000, 1, 20000, 4);          // one worker thread does everything in turn

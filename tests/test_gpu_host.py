@@ -73,6 +73,35 @@ def test_compress_cli_roundtrip(tmp_path, oracle):
     assert r.returncode != 0
 
 
+def test_cli_block_farm_over_two_contexts_gives_the_sequential_stream(tmp_path, oracle):
+    """`compress --devices 0,0` (bwtc_hip_farm.hpp: one thread + context + page-locked staging ring
+    per entry, in-order writer, the 'B' coder's carried model state handed from context to context
+    at bwtc_hip_wavelet_encode_queue): the stream must be byte-equal to the one-device stream and
+    to the oracle's sequential encoder, for both coders, with more blocks than contexts."""
+    exe = os.path.join(ROOT, "bwtc_amd", "host", "compress")
+    unexe = os.path.join(ROOT, "bwtc_amd", "host", "uncompress")
+    data = np.concatenate([synth.gen_text(5_300_000, 41), synth.gen_dna(1_000_000, 7), synth.gen_text(2_100_000, 43)])
+    src = tmp_path / "farm.bin"
+    src.write_bytes(data.tobytes())
+    block = int(1 * 1000000 * 0.185)                  # -m 1 -> 185 000-byte blocks: 46 blocks
+    for enc in ("B", "H"):
+        one = tmp_path / ("one.%s.bwtc" % enc)
+        for devices, dst in (("0,0", tmp_path / ("two.%s.bwtc" % enc)), ("0,0,0", tmp_path / ("three.%s.bwtc" % enc))):
+            r = subprocess.run([exe, "-m", "1", "-e", enc, "--devices", devices, str(src), str(dst)],
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr
+        r = subprocess.run([exe, "-m", "1", "-e", enc, str(src), str(one)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        want = (oracle.oracle_compress_B if enc == "B" else oracle.oracle_compress_H)(data, block, 8).tobytes()
+        assert one.read_bytes() == want, enc
+        assert (tmp_path / ("two.%s.bwtc" % enc)).read_bytes() == want, enc
+        assert (tmp_path / ("three.%s.bwtc" % enc)).read_bytes() == want, enc
+    out = tmp_path / "farm.out"
+    r = subprocess.run([unexe, str(tmp_path / "two.B.bwtc"), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data.tobytes()
+
+
 def test_cli_roundtrip_full_size_block_default_coder(tmp_path):
     """BASELINE's configuration end to end: one 256 MiB text block, the default 'B' coder,
     compress -> uncompress (host wavelet decoder + GPU inverse BWT) gives the input back.
