@@ -158,6 +158,30 @@ def test_full_size_text_roundtrip(hip_ctx, oracle):
           (st.ms_total, st.ms_sort, st.rounds, st.active_sum / st.n))
 
 
+def test_worst_case_blocks_at_64MiB(oracle):
+    """The inputs prefix doubling likes least, at a size where every round takes the window-ordered
+    route: an all-zero block (one group until the last round, log2 N rounds), a period-9 block and
+    a 1 MiB text repeated 64 times (21-23 rounds).  Checked by the GPU inverse (which verifies every
+    LF power against its own ranking) and by the oracle's inverse on the all-zero block."""
+    from bwtc_amd import hip
+    size = 64 << 20
+    blocks = [("zeros", np.zeros(size, np.uint8)),
+              ("period9", np.tile(np.frombuffer(b"abcabcabd", np.uint8), size // 9 + 1)[:size].copy()),
+              ("reptext", np.tile(synth.gen_text(1 << 20, 3), 64))]
+    with hip.Context(0, size) as ctx:
+        for name, d in blocks:
+            bwt, lf, freqs = ctx.bwt_block(d, 8)
+            st = ctx.stats()
+            assert (freqs == np.bincount(d, minlength=256)).all(), name
+            back = ctx.inverse_bwt_block(bwt, lf)
+            assert back.size == size and (back == d).all(), name
+            if name == "zeros":
+                assert (bwt == 0).all() and int(lf[0]) == size      # the end-of-block row is the last one
+                rc, inv = oracle.oracle_inverse_bwt_block(bwt, lf)
+                assert rc == 0 and (inv == d).all()
+            print("%s 64MiB: %.1f ms device, %d rounds" % (name, st.ms_total, st.rounds))
+
+
 def test_baseline_full_size_256MiB_text(oracle):
     """BASELINE.json config 3 at full size (256 MiB text block, 8 starting points): the
     size-independent properties -- inverse transform reproduces the input with every LF power

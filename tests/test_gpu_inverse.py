@@ -48,6 +48,44 @@ def test_inverse_rejects_bad_lf_power(hip_ctx):
         hip_ctx.inverse_bwt_block(bwt, bad)
 
 
+def test_inverse_fails_cleanly_on_corrupt_headers_and_data(hip_ctx):
+    """What a damaged file can hand the inverse transform: LF powers outside the block, a wrong
+    end-of-block row (LF then splits into several cycles, some without a splitter row), damaged
+    bytes.  Every case must come back with an error code (-4 / -1) or a wrong-but-finite result --
+    never a fault or an endless walk; one run each, bounded by the suite's timeout."""
+    d = synth.gen_text(300000, 11)
+    bwt, lf, _ = hip_ctx.bwt_block(d, 8)
+    for k in (1, 7):
+        bad = lf.copy()
+        bad[k] = d.size + 1 + k                       # not a row of this block
+        with pytest.raises(hip.BwtcHipError) as err:
+            hip_ctx.inverse_bwt_block(bwt, bad)
+        assert "-4" in str(err.value)
+    bad = lf.copy()
+    bad[0] = (int(lf[0]) + 12345) % d.size            # wrong end-of-block row, n_lf > 1
+    with pytest.raises(hip.BwtcHipError) as err:
+        hip_ctx.inverse_bwt_block(bwt, bad)
+    assert "-4" in str(err.value)
+    # wrong end-of-block row with a single LF power: nothing to check it against except the cycle
+    # structure (rows that are not on the walk from row 0)
+    bad1 = np.array([(int(lf[0]) + 777) % d.size], np.uint32)
+    try:
+        back = hip_ctx.inverse_bwt_block(bwt, bad1)
+        assert back.size == d.size                    # accepted: LF happened to stay one cycle
+    except hip.BwtcHipError as e:
+        assert "-4" in str(e)
+    # damaged bytes: a few symbols changed
+    hurt = bwt.copy()
+    hurt[1000:1010] ^= 0x55
+    try:
+        back = hip_ctx.inverse_bwt_block(hurt, lf)
+        assert not (back == d).all()
+    except hip.BwtcHipError as e:
+        assert "-4" in str(e)
+    # and the context still works afterwards
+    assert (hip_ctx.inverse_bwt_block(bwt, lf) == d).all()
+
+
 def test_inverse_large_text(hip_ctx):
     size = 64 << 20
     d = synth.gen_text(size, 3)
