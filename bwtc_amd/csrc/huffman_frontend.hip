@@ -1,9 +1,10 @@
 // Device half of the 'H' coder (HuffmanEncoder::encodeData, HuffmanCoders.cpp:119-257):
 // everything that is a pass over the transformed block.
 //
-//   runs      run heads of every section (utils::calculateRunFrequenciesAndStoreRuns,
-//             Utils.cpp:150-170; a run never crosses a section start) -> run_start[], run_sym[]
-//   stats     per section: runs per symbol (the Huffman weights) and total gamma bits
+//   runs +    run heads of every section (utils::calculateRunFrequenciesAndStoreRuns,
+//   stats     Utils.cpp:150-170; a run never crosses a section start) -> run_start[], run_sym[],
+//             and in the same sweep, per section: runs per symbol (the Huffman weights), total
+//             gamma bits ('H'), run-length distribution ('B')
 //   pack      for each of the two bit streams of a section (Huffman codes of the run symbols,
 //             HuffmanCoders.cpp:200-226; gamma codes of the run lengths, :229-251): prefix sum
 //             of the code lengths -> absolute bit position -> MSB-first bits OR-ed into the
@@ -77,37 +78,6 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_count(const u8* __restrict__ b
   if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kRunTPB) void k_runs_emit(const u8* __restrict__ bwt, u32 size,
-                                                       const u32* __restrict__ sec_start,
-                                                       u32 nsec, const u32* __restrict__ tile_off,
-                                                       u32* __restrict__ run_start,
-                                                       u8* __restrict__ run_sym,
-                                                       u32* __restrict__ first_run,
-                                                       u32* __restrict__ n_runs, int aligned) {
-  __shared__ u32 s_sec[256];
-  __shared__ u32 scr[kRunTPB / kWave + 1];
-  if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
-  __syncthreads();
-  const u32 p0 = blockIdx.x * kRunTile + threadIdx.x * kRunE;
-  u8 b[kRunE];
-  u32 sec;
-  const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
-  u32 total;
-  u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[blockIdx.x];
-#pragma unroll
-  for (int e = 0; e < kRunE; ++e) {
-    const u32 p = p0 + e;
-    if (p >= size) break;
-    if ((heads >> e) & 1u) {
-      run_start[r] = p;
-      run_sym[r] = b[e];
-      if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; ++sec; }
-      ++r;
-    }
-    if (p == size - 1) { *n_runs = r; run_start[r] = size; first_run[nsec] = r; }
-  }
-}
-
 // section of run r: last s with first_run[s] <= r
 __device__ __forceinline__ u32 section_of(const u32* s_first, u32 nsec, u32 r) {
   u32 lo = 0, hi = nsec;           // invariant: first_run[lo] <= r < first_run[hi]
@@ -117,48 +87,142 @@ __device__ __forceinline__ u32 section_of(const u32* s_first, u32 nsec, u32 r) {
 
 __device__ __forceinline__ u32 gamma_bits(u32 len) { return 2u * (31u - (u32)__clz(len)) + 1u; }
 
-constexpr int kStatTPB = 256;
-constexpr int kStatE = 8;
-constexpr int kStatTile = kStatTPB * kStatE;
+// ---------------------------------------------------------------------------------------
+// Fused front-end pass: run heads -> run_start[] / run_sym[] AND, in the same sweep over the
+// transformed block, everything the coders' table builders need from the runs -- runs per symbol
+// per section (the Huffman weights of both coders), the gamma bits per section ('H') and the
+// run-length distribution per section ('B': dense table below kLenDense, overflow list above).
+// A run's length is the distance to the next head: inside the thread's 16 bytes, else the first
+// head of a later thread of the tile (LDS), else unknown here -- the tile's LAST run is "open"
+// and is settled by k_open_runs (one run per tile) once run_start[] is complete.
+// Replaces k_runs_emit + k_run_stats + k_run_length_dist (three sweeps) by one.
+// ---------------------------------------------------------------------------------------
+constexpr u32 kLenDense = 4096;
+constexpr u32 kLenLds = 256;
+constexpr u32 kNoRun = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(kStatTPB) void k_run_stats(const u32* __restrict__ run_start,
-                                                        const u8* __restrict__ run_sym,
-                                                        u32 n_runs, const u32* __restrict__ first_run,
-                                                        u32 nsec, u32* __restrict__ run_freqs,
-                                                        unsigned long long* __restrict__ gbits) {
-  __shared__ u32 s_first[257];
-  __shared__ u32 hist[256 * 8];      // 8 interleaved copies per symbol (copy = lane & 7)
-  __shared__ u32 s_g0;
-  for (u32 i = threadIdx.x; i <= nsec; i += kStatTPB) s_first[i] = first_run[i];
-  for (u32 i = threadIdx.x; i < 256 * 8; i += kStatTPB) hist[i] = 0;
-  if (threadIdx.x == 0) s_g0 = 0;
-  __syncthreads();
-  const u32 base = blockIdx.x * kStatTile;
-  const u32 s0 = section_of(s_first, nsec, base);
-  u32 gsum = 0;                     // gamma bits of this thread's runs in section s0
-  for (int e = 0; e < kStatE; ++e) {
-    const u32 r = base + e * kStatTPB + threadIdx.x;
-    if (r >= n_runs) break;
-    const u32 len = run_start[r + 1] - run_start[r];
-    const u32 sym = run_sym[r];
+struct RunStatsOut {
+  u32* run_freqs;                    // [section][256]
+  unsigned long long* gbits;         // [section]   (GAMMA)
+  u32* dense;                        // [section][kLenDense]   (DIST)
+  u32* over_sec; u32* over_len; u32* over_count; u32 over_cap;
+  u32* tile_open;                    // [tile] index of the tile's open run, kNoRun if it has none
+};
+
+template <bool GAMMA, bool DIST>
+__device__ __forceinline__ void count_run(const RunStatsOut& o, u32 s, u32 sym, u32 len, bool in_s0,
+                                          u32* hist, u32* s_len, u32 copy, u32& gsum) {
+  if (in_s0) atomicAdd(&hist[sym * 8u + copy], 1u);
+  else atomicAdd(&o.run_freqs[s * 256u + sym], 1u);
+  if (GAMMA) {
     const u32 g = gamma_bits(len);
-    if (r < s_first[s0 + 1]) {
-      atomicAdd(&hist[sym * 8u + (threadIdx.x & 7u)], 1u);
-      gsum += g;
-    } else {
-      const u32 s = section_of(s_first, nsec, r);
-      atomicAdd(&run_freqs[s * 256u + sym], 1u);
-      atomicAdd(&gbits[s], (unsigned long long)g);
+    if (in_s0) gsum += g;
+    else atomicAdd(&o.gbits[s], (unsigned long long)g);
+  }
+  if (DIST) {
+    if (in_s0 && len < kLenLds) atomicAdd(&s_len[len], 1u);
+    else if (len < kLenDense) atomicAdd(&o.dense[(u64)s * kLenDense + len], 1u);
+    else {
+      const u32 slot = atomicAdd(o.over_count, 1u);
+      if (slot < o.over_cap) { o.over_sec[slot] = s; o.over_len[slot] = len; }
     }
   }
-  gsum = wave_scan_add(gsum, lane_id());
-  if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
+}
+
+template <bool GAMMA, bool DIST>
+__global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
+    const u8* __restrict__ bwt, u32 size, const u32* __restrict__ sec_start, u32 nsec,
+    const u32* __restrict__ tile_off, u32* __restrict__ run_start, u8* __restrict__ run_sym,
+    u32* __restrict__ first_run, u32* __restrict__ n_runs, int aligned, RunStatsOut o) {
+  __shared__ u32 s_sec[256];
+  __shared__ u32 scr[kRunTPB / kWave + 1];
+  __shared__ u32 s_fh[kRunTPB];               // position of the thread's first head, ~0 if it has none
+  __shared__ u32 hist[256 * 8];               // runs per symbol of the tile's first section, 8 copies
+  __shared__ u32 s_len[kLenLds];
+  __shared__ u32 s_g0;
+  if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
+  for (u32 i = threadIdx.x; i < 256 * 8; i += kRunTPB) hist[i] = 0;
+  if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) s_len[i] = 0;
+  if (threadIdx.x == 0) s_g0 = 0;
+  __syncthreads();
+  const u32 t0 = blockIdx.x * kRunTile;
+  const u32 p0 = t0 + threadIdx.x * kRunE;
+  u8 b[kRunE];
+  u32 sec;                                    // first section start >= p0
+  const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
+  s_fh[threadIdx.x] = heads ? p0 + (u32)__builtin_ctz(heads) : 0xFFFFFFFFu;
+  u32 total;
+  u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[blockIdx.x];
+  // (block_scan's barriers also publish s_fh)
+  // section of the tile's first byte: its runs are counted in LDS
+  u32 s0;
+  { u32 lo = 0, hi = nsec; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_sec[mid] <= t0) lo = mid; else hi = mid; } s0 = lo; }
+  const u32 s0_end = s0 + 1 < nsec ? s_sec[s0 + 1] : 0xFFFFFFFFu;
+  u32 cur = sec ? sec - 1u : 0u;              // section of the byte before the next section start
+  u32 gsum = 0;
+  const u32 copy = threadIdx.x & 7u;
+  u32 open_run = kNoRun;
+  if (heads) {
+    // end of the thread's last run: the first head of a later thread, if the tile has one
+    u32 next_after = 0xFFFFFFFFu;
+    for (u32 t = threadIdx.x + 1; t < kRunTPB; ++t) { const u32 f = s_fh[t]; if (f != 0xFFFFFFFFu) { next_after = f; break; } }
+    u32 rest = heads;
+#pragma unroll
+    for (int e = 0; e < kRunE; ++e) {
+      const u32 p = p0 + e;
+      if (p >= size) break;
+      if ((heads >> e) & 1u) {
+        run_start[r] = p;
+        run_sym[r] = b[e];
+        if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; cur = sec; ++sec; }
+        rest &= rest - 1u;                    // heads after this one
+        const u32 nxt = rest ? p0 + (u32)__builtin_ctz(rest) : next_after;
+        if (nxt != 0xFFFFFFFFu) count_run<GAMMA, DIST>(o, cur, b[e], nxt - p, p < s0_end && cur == s0, hist, s_len, copy, gsum);
+        else open_run = r;
+        ++r;
+      }
+      if (p == size - 1) { *n_runs = r; run_start[r] = size; first_run[nsec] = r; }
+    }
+  } else if (p0 < size && p0 + kRunE > size - 1u) {
+    *n_runs = r; run_start[r] = size; first_run[nsec] = r;       // the block's last byte is here, its run started earlier
+  }
+  if (open_run != kNoRun) o.tile_open[blockIdx.x] = open_run;
+  if (GAMMA) {
+    gsum = wave_scan_add(gsum, lane_id());
+    if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
+  }
   __syncthreads();
   u32 c = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c += hist[threadIdx.x * 8u + k];
-  if (c) atomicAdd(&run_freqs[s0 * 256u + threadIdx.x], c);
-  if (threadIdx.x == 0 && s_g0) atomicAdd(&gbits[s0], (unsigned long long)s_g0);
+  if (c) atomicAdd(&o.run_freqs[s0 * 256u + threadIdx.x], c);
+  if (GAMMA && threadIdx.x == 0 && s_g0) atomicAdd(&o.gbits[s0], (unsigned long long)s_g0);
+  if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) { const u32 v = s_len[i]; if (v) atomicAdd(&o.dense[(u64)s0 * kLenDense + i], v); }
+}
+
+// the open run of every tile (its end lies in a later tile), after run_start[] is complete
+template <bool GAMMA, bool DIST>
+__global__ __launch_bounds__(256) void k_open_runs(const u32* __restrict__ run_start,
+                                                   const u8* __restrict__ run_sym,
+                                                   const u32* __restrict__ first_run, u32 nsec,
+                                                   u32 ntiles, RunStatsOut o) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ntiles) return;
+  const u32 r = o.tile_open[t];
+  if (r == kNoRun) return;
+  const u32 len = run_start[r + 1] - run_start[r];
+  u32 lo = 0, hi = nsec;
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (first_run[mid] <= r) lo = mid; else hi = mid; }
+  const u32 s = lo, sym = run_sym[r];
+  atomicAdd(&o.run_freqs[s * 256u + sym], 1u);
+  if (GAMMA) atomicAdd(&o.gbits[s], (unsigned long long)gamma_bits(len));
+  if (DIST) {
+    if (len < kLenDense) atomicAdd(&o.dense[(u64)s * kLenDense + len], 1u);
+    else {
+      const u32 slot = atomicAdd(o.over_count, 1u);
+      if (slot < o.over_cap) { o.over_sec[slot] = s; o.over_len[slot] = len; }
+    }
+  }
 }
 
 // ---- bit packing ---------------------------------------------------------------------
@@ -417,17 +481,18 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   hipLaunchKernelGGL(k_runs_count, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
                      nsec, d_tile, aligned);
   exclusive_scan_u32(d_tile, rtiles, e.d_partial, st);
-  hipLaunchKernelGGL(k_runs_emit, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
-                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
+  // run arrays and statistics in one sweep (k_runs_emit_stats), the tiles' open runs after it
+  RunStatsOut so;
+  so.run_freqs = d_run_freqs; so.gbits = d_gbits; so.dense = nullptr;
+  so.over_sec = so.over_len = so.over_count = nullptr; so.over_cap = 0;
+  so.tile_open = e.d_V1;
+  BWTC_HIP_TRY(hipMemsetAsync(so.tile_open, 0xFF, (size_t)rtiles * 4, st));
+  hipLaunchKernelGGL((k_runs_emit_stats<true, false>), dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so);
+  hipLaunchKernelGGL((k_open_runs<true, false>), dim3(ceil_div(rtiles, 256)), dim3(256), 0, st, d_run_start,
+                     d_run_sym, d_first_run, nsec, rtiles, so);
   u32 n_runs = 0;
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(e.wait());
-  n_runs = e.h_small[0];
-  if (n_runs == 0 || n_runs > size) return -3;
-
-  // ---- stats
-  hipLaunchKernelGGL(k_run_stats, dim3(ceil_div(n_runs, kStatTile)), dim3(kStatTPB), 0, st,
-                     d_run_start, d_run_sym, n_runs, d_first_run, nsec, d_run_freqs, d_gbits);
   std::vector<u32> h_run_freqs((size_t)nsec * 256);
   std::vector<unsigned long long> h_gbits(nsec);
   std::vector<u32> h_first(nsec + 1);
@@ -435,6 +500,8 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   BWTC_HIP_TRY(hipMemcpyAsync(h_gbits.data(), d_gbits, (size_t)nsec * 8, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(h_first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(e.wait());
+  n_runs = e.h_small[0];
+  if (n_runs == 0 || n_runs > size) return -3;
 
   // ---- host: per-section tables and layout (encodeData, :133-198)
   std::vector<uint8_t> clen_tab((size_t)nsec * 256);
@@ -510,40 +577,6 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
 // dense per-section table (LDS-aggregated for the tile's first section), longer ones are
 // appended to an overflow list; the host folds both into sorted (length, count) pairs.
 // ---------------------------------------------------------------------------------------
-constexpr u32 kLenDense = 4096;
-constexpr u32 kLenLds = 256;
-
-__global__ __launch_bounds__(kStatTPB) void k_run_length_dist(
-    const u32* __restrict__ run_start, u32 n_runs, const u32* __restrict__ first_run, u32 nsec,
-    u32* __restrict__ dense, u32* __restrict__ over_sec, u32* __restrict__ over_len,
-    u32* __restrict__ over_count, u32 over_cap) {
-  __shared__ u32 s_first[257];
-  __shared__ u32 s_hist[kLenLds];
-  for (u32 i = threadIdx.x; i <= nsec; i += kStatTPB) s_first[i] = first_run[i];
-  for (u32 i = threadIdx.x; i < kLenLds; i += kStatTPB) s_hist[i] = 0;
-  __syncthreads();
-  const u32 base = blockIdx.x * kStatTile;
-  const u32 s0 = section_of(s_first, nsec, base);
-  for (int e = 0; e < kStatE; ++e) {
-    const u32 r = base + e * kStatTPB + threadIdx.x;
-    if (r >= n_runs) break;
-    const u32 len = run_start[r + 1] - run_start[r];
-    const bool in_s0 = r < s_first[s0 + 1];
-    if (in_s0 && len < kLenLds) { atomicAdd(&s_hist[len], 1u); continue; }
-    const u32 s = in_s0 ? s0 : section_of(s_first, nsec, r);
-    if (len < kLenDense) atomicAdd(&dense[(u64)s * kLenDense + len], 1u);
-    else {
-      const u32 slot = atomicAdd(over_count, 1u);
-      if (slot < over_cap) { over_sec[slot] = s; over_len[slot] = len; }
-    }
-  }
-  __syncthreads();
-  for (u32 i = threadIdx.x; i < kLenLds; i += kStatTPB) {
-    const u32 c = s_hist[i];
-    if (c) atomicAdd(&dense[(u64)s0 * kLenDense + i], c);
-  }
-}
-
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
                                  WaveletSectionStats* out) {
   hipStream_t st = e.stream;
@@ -584,17 +617,16 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   hipLaunchKernelGGL(k_runs_count, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
                      nsec, d_tile, aligned);
   exclusive_scan_u32(d_tile, rtiles, e.d_partial, st);
-  hipLaunchKernelGGL(k_runs_emit, dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
-                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned);
+  RunStatsOut so;
+  so.run_freqs = d_run_freqs; so.gbits = d_gbits; so.dense = d_dense;
+  so.over_sec = d_over_sec; so.over_len = d_over_len; so.over_count = d_over_count; so.over_cap = over_cap;
+  so.tile_open = e.d_V1;
+  BWTC_HIP_TRY(hipMemsetAsync(so.tile_open, 0xFF, (size_t)rtiles * 4, st));
+  hipLaunchKernelGGL((k_runs_emit_stats<false, true>), dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so);
+  hipLaunchKernelGGL((k_open_runs<false, true>), dim3(ceil_div(rtiles, 256)), dim3(256), 0, st, d_run_start,
+                     d_run_sym, d_first_run, nsec, rtiles, so);
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(e.wait());
-  const u32 n_runs = e.h_small[0];
-  if (n_runs == 0 || n_runs > size) return -3;
-  const u32 stiles = ceil_div(n_runs, kStatTile);
-  hipLaunchKernelGGL(k_run_stats, dim3(stiles), dim3(kStatTPB), 0, st, d_run_start, d_run_sym,
-                     n_runs, d_first_run, nsec, d_run_freqs, d_gbits);
-  hipLaunchKernelGGL(k_run_length_dist, dim3(stiles), dim3(kStatTPB), 0, st, d_run_start, n_runs,
-                     d_first_run, nsec, d_dense, d_over_sec, d_over_len, d_over_count, over_cap);
   std::vector<u32> first(nsec + 1), dense((size_t)nsec * kLenDense);
   u32 n_over = 0;
   BWTC_HIP_TRY(hipMemcpyAsync(out->run_freqs.data(), d_run_freqs, (size_t)nsec * 1024, hipMemcpyDeviceToHost, st));
@@ -602,6 +634,8 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   BWTC_HIP_TRY(hipMemcpyAsync(dense.data(), d_dense, dense.size() * 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(e.wait());
+  const u32 n_runs = e.h_small[0];
+  if (n_runs == 0 || n_runs > size) return -3;
   if (n_over > over_cap) return -2;
   std::vector<u32> osec(n_over), olen(n_over);
   if (n_over) {
