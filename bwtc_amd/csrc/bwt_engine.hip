@@ -354,43 +354,102 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 
 constexpr int kSimpleE = 4;   // independent items per thread in the latency-bound kernels
 
-__global__ __launch_bounds__(256) void k_scatter_pairs(u32* __restrict__ dst,
-                                                       const u32* __restrict__ where,
-                                                       const u32* __restrict__ what, u32 m) {
-  // XCD-contiguous chunking (speed only): the pairs are partitioned by destination window,
-  // so giving each XCD one contiguous eighth of the list keeps every window in ONE L2.
-  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
+// ---------------------------------------------------------------------------------------
+// Window kernels.  The lists they sweep are partitioned by suffix window (the top bits of s),
+// so a chunk of consecutive items touches one or two windows of rank[] / T -- but inside a
+// window the order is arbitrary, and a wave's 64 accesses still hit 64 different cache lines:
+// rocprofv3 showed these kernels stalled on instruction issue (SQ_WAIT_INST_ANY 0.4-0.5 of the
+// wave cycles, the address pipe working through one line per lane), not on HBM.  Each workgroup
+// therefore reorders its chunk in LDS by eight more bits of s first -- an unstable counting sort,
+// one returning ds_add per item gives both the bin count and the item's place in its bin -- and
+// performs the accesses in that order: neighbouring lanes then share cache lines.  The order in
+// which a chunk's items are processed (and, for the gather, written back) does not matter.
+// ---------------------------------------------------------------------------------------
+constexpr int kWinTPB = 256;
+constexpr int kWinE = 8;
+constexpr int kWinTile = kWinTPB * kWinE;     // items per workgroup
+
+// XCD-contiguous chunking (speed only): the lists are partitioned by destination window, so
+// giving each XCD one contiguous eighth of the list keeps every window in ONE L2.
+__device__ __forceinline__ bool win_chunk(u32 m, u32* blk_out) {
+  const u32 nblk = (m + (u32)kWinTile - 1u) / (u32)kWinTile;
   const u32 per_xcd = (nblk + 7u) / 8u;
   const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (blk >= nblk) return;
-  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
-  u32 w[kSimpleE], v[kSimpleE];
-#pragma unroll
-  for (int e = 0; e < kSimpleE; ++e) {
-    const u32 p = p0 + e * 256u;
-    w[e] = p < m ? where[p] : 0u;
-    v[e] = p < m ? what[p] : 0u;
-  }
-#pragma unroll
-  for (int e = 0; e < kSimpleE; ++e)
-    if (p0 + e * 256u < m) dst[w[e]] = v[e];
+  *blk_out = blk;
+  return blk < nblk;
 }
 
-// Dense route, step 2: rank[s] = nr for records (s << 32 | nr) partitioned by the high bits of
-// s, so that consecutive records write into one window of rank[] (same chunking as above).
-__global__ __launch_bounds__(256) void k_scatter_dense(u32* __restrict__ rank,
-                                                       const u64* __restrict__ rec, u32 m) {
-  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
-  const u32 per_xcd = (nblk + 7u) / 8u;
-  const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (blk >= nblk) return;
-  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
-  u64 r[kSimpleE];
+// Places of the chunk's items in bin order.  bin[e] (< 256) of this thread's item e (ok bit e of
+// okm) -> slot[e] in [0, count); s_cnt is 256 words of LDS, scr the block scan's scratch.
+// Contains barriers; every thread of the workgroup must call it.
+__device__ __forceinline__ void win_places(const u32 (&bin)[kWinE], u32 okm, u32 (&slot)[kWinE],
+                                           u32* s_cnt, u32* scr) {
+  s_cnt[threadIdx.x] = 0;                                 // kWinTPB == 256 bins
+  __syncthreads();
 #pragma unroll
-  for (int e = 0; e < kSimpleE; ++e) { const u32 p = p0 + e * 256u; r[e] = p < m ? rec[p] : 0ull; }
+  for (int e = 0; e < kWinE; ++e) slot[e] = ((okm >> e) & 1u) ? atomicAdd(&s_cnt[bin[e]], 1u) : 0u;
+  __syncthreads();
+  u32 total;
+  const u32 base = block_scan_excl_add<kWinTPB>(s_cnt[threadIdx.x], scr, &total);
+  s_cnt[threadIdx.x] = base;
+  __syncthreads();
 #pragma unroll
-  for (int e = 0; e < kSimpleE; ++e)
-    if (p0 + e * 256u < m) rank[(u32)(r[e] >> 32)] = (u32)r[e];
+  for (int e = 0; e < kWinE; ++e) slot[e] += s_cnt[bin[e]];
+}
+
+// rank[where[i]] = what[i] for pairs partitioned by the high bits of `where`.
+__global__ __launch_bounds__(kWinTPB) void k_scatter_pairs(u32* __restrict__ dst,
+                                                           const u32* __restrict__ where,
+                                                           const u32* __restrict__ what, u32 m,
+                                                           int bin_shift) {
+  __shared__ u32 s_cnt[256], scr[kWinTPB / kWave + 1];
+  __shared__ u32 s_w[kWinTile], s_v[kWinTile];
+  u32 blk;
+  if (!win_chunk(m, &blk)) return;
+  const u32 p0 = blk * (u32)kWinTile + threadIdx.x;
+  u32 w[kWinE], v[kWinE], bin[kWinE], slot[kWinE], okm = 0;
+#pragma unroll
+  for (int e = 0; e < kWinE; ++e) {
+    const u32 p = p0 + e * kWinTPB;
+    const bool ok = p < m;
+    w[e] = ok ? where[p] : 0u;
+    v[e] = ok ? what[p] : 0u;
+    bin[e] = (w[e] >> bin_shift) & 255u;
+    okm |= (ok ? 1u : 0u) << e;
+  }
+  win_places(bin, okm, slot, s_cnt, scr);
+#pragma unroll
+  for (int e = 0; e < kWinE; ++e) if ((okm >> e) & 1u) { s_w[slot[e]] = w[e]; s_v[slot[e]] = v[e]; }
+  __syncthreads();
+  const u32 count = min((u32)kWinTile, m - blk * (u32)kWinTile);
+  for (u32 i = threadIdx.x; i < count; i += kWinTPB) dst[s_w[i]] = s_v[i];
+}
+
+// Dense route, step 2: rank[s] = nr for records (s << 32 | nr) partitioned by the high bits of s.
+__global__ __launch_bounds__(kWinTPB) void k_scatter_dense(u32* __restrict__ rank,
+                                                           const u64* __restrict__ rec, u32 m,
+                                                           int bin_shift) {
+  __shared__ u32 s_cnt[256], scr[kWinTPB / kWave + 1];
+  __shared__ u64 s_r[kWinTile];
+  u32 blk;
+  if (!win_chunk(m, &blk)) return;
+  const u32 p0 = blk * (u32)kWinTile + threadIdx.x;
+  u64 r[kWinE];
+  u32 bin[kWinE], slot[kWinE], okm = 0;
+#pragma unroll
+  for (int e = 0; e < kWinE; ++e) {
+    const u32 p = p0 + e * kWinTPB;
+    const bool ok = p < m;
+    r[e] = ok ? rec[p] : 0ull;
+    bin[e] = ((u32)(r[e] >> 32) >> bin_shift) & 255u;
+    okm |= (ok ? 1u : 0u) << e;
+  }
+  win_places(bin, okm, slot, s_cnt, scr);
+#pragma unroll
+  for (int e = 0; e < kWinE; ++e) if ((okm >> e) & 1u) s_r[slot[e]] = r[e];
+  __syncthreads();
+  const u32 count = min((u32)kWinTile, m - blk * (u32)kWinTile);
+  for (u32 i = threadIdx.x; i < count; i += kWinTPB) { const u64 x = s_r[i]; rank[(u32)(x >> 32)] = (u32)x; }
 }
 
 // Dense route, step 3 (after ALL of rank[] is updated): the next round's sort input, written
@@ -398,37 +457,44 @@ __global__ __launch_bounds__(256) void k_scatter_dense(u32* __restrict__ rank,
 // becomes key = grp << b2 | rank[s+h]+1 (0 when s+h is past the end) | T[s-1] << 56 (emit),
 // value = s; finished suffixes become the all-ones key, which the sort's first pass drops.
 // The records are in window order of s and h is small against a window at the dense stage, so
-// rank[s+h] and T[s-1] are read from the window being swept, not at random.
-__global__ __launch_bounds__(256) void k_gather_dense(u64* __restrict__ rec, u32* __restrict__ val,
-                                                      const u32* __restrict__ rank,
-                                                      const u8* __restrict__ T, u32 m, u32 n, u32 h,
-                                                      int b2, int emit) {
-  const u32 nblk = (m + 256u * kSimpleE - 1u) / (256u * kSimpleE);
-  const u32 per_xcd = (nblk + 7u) / 8u;
-  const u32 blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (blk >= nblk) return;
-  const u32 p0 = blk * (256u * kSimpleE) + threadIdx.x;
-  u32 s[kSimpleE], g[kSimpleE], r[kSimpleE], c[kSimpleE];
+// rank[s+h] and T[s-1] are read from the window being swept, not at random.  The chunk's items
+// are written back in their LDS order (any order will do: the sort that follows does not care).
+__global__ __launch_bounds__(kWinTPB) void k_gather_dense(u64* __restrict__ rec, u32* __restrict__ val,
+                                                          const u32* __restrict__ rank,
+                                                          const u8* __restrict__ T, u32 m, u32 n, u32 h,
+                                                          int b2, int emit, int bin_shift) {
+  __shared__ u32 s_cnt[256], scr[kWinTPB / kWave + 1];
+  __shared__ u32 s_s[kWinTile], s_g[kWinTile];
+  u32 blk;
+  if (!win_chunk(m, &blk)) return;
+  const u32 base = blk * (u32)kWinTile;
+  const u32 p0 = base + threadIdx.x;
+  u32 s[kWinE], g[kWinE], bin[kWinE], slot[kWinE], okm = 0;
 #pragma unroll
-  for (int e = 0; e < kSimpleE; ++e) {
-    const u32 p = p0 + e * 256u;
-    s[e] = p < m ? (u32)(rec[p] >> 32) : 0u;
-    g[e] = p < m ? val[p] : 0xFFFFFFFFu;
+  for (int e = 0; e < kWinE; ++e) {
+    const u32 p = p0 + e * kWinTPB;
+    const bool ok = p < m;
+    s[e] = ok ? (u32)(rec[p] >> 32) : 0u;
+    g[e] = ok ? val[p] : 0xFFFFFFFFu;
+    bin[e] = (s[e] >> bin_shift) & 255u;
+    okm |= (ok ? 1u : 0u) << e;
   }
+  win_places(bin, okm, slot, s_cnt, scr);
 #pragma unroll
-  for (int e = 0; e < kSimpleE; ++e) {
-    const u64 t = (u64)s[e] + (u64)h;
-    const bool live = g[e] != 0xFFFFFFFFu;
-    r[e] = (live && t < (u64)n) ? rank[t] + 1u : 0u;
-    c[e] = (live && emit && s[e]) ? T[s[e] - 1u] : 0u;
-  }
-#pragma unroll
-  for (int e = 0; e < kSimpleE; ++e) {
-    const u32 p = p0 + e * 256u;
-    if (p < m) {
-      rec[p] = g[e] != 0xFFFFFFFFu ? (((u64)g[e] << b2) | (u64)r[e] | ((u64)c[e] << 56)) : ~0ull;
-      val[p] = s[e];
+  for (int e = 0; e < kWinE; ++e) if ((okm >> e) & 1u) { s_s[slot[e]] = s[e]; s_g[slot[e]] = g[e]; }
+  __syncthreads();
+  const u32 count = min((u32)kWinTile, m - base);
+  for (u32 i = threadIdx.x; i < count; i += kWinTPB) {
+    const u32 ss = s_s[i], gg = s_g[i];
+    u64 key = ~0ull;
+    if (gg != 0xFFFFFFFFu) {
+      const u64 t = (u64)ss + (u64)h;
+      const u32 r = t < (u64)n ? rank[t] + 1u : 0u;
+      const u32 c = (emit && ss) ? T[ss - 1u] : 0u;
+      key = ((u64)gg << b2) | (u64)r | ((u64)c << 56);
     }
+    rec[base + i] = key;
+    val[base + i] = ss;
   }
 }
 
@@ -742,8 +808,8 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
   u32 *ws = pairs, *wr = pairs + cap;
   if (m >= kPairsMin && bits > 12)
     sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, &ws, &wr, false, lo);
-  hipLaunchKernelGGL(k_scatter_pairs, dim3((ceil_div(m, 256 * kSimpleE) + 7u) / 8u * 8u), dim3(256), 0, st,
-                     d_rank, ws, wr, m);
+  hipLaunchKernelGGL(k_scatter_pairs, dim3((ceil_div(m, kWinTile) + 7u) / 8u * 8u), dim3(kWinTPB), 0, st,
+                     d_rank, ws, wr, m, lo > 8 ? lo - 8 : 0);
 }
 
 // One ranking step over a sorted list (INIT: all suffixes by their initial key; rounds: the
@@ -792,11 +858,12 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo);
     u64* ws_other = ws == recA ? recB : recA;
     u32* wv_other = wv == rb.v_free ? rb.v_keys : rb.v_free;
-    const u32 grid = (ceil_div(m, 256 * kSimpleE) + 7u) / 8u * 8u;
-    hipLaunchKernelGGL(k_scatter_dense, dim3(grid), dim3(256), 0, st, d_rank, (const u64*)ws, m);
-    hipLaunchKernelGGL(k_gather_dense, dim3(grid), dim3(256), 0, st, ws, wv, (const u32*)d_rank,
+    const u32 grid = (ceil_div(m, kWinTile) + 7u) / 8u * 8u;
+    const int bin_shift = lo > 8 ? lo - 8 : 0;           // the eight bits of s below the window bits
+    hipLaunchKernelGGL(k_scatter_dense, dim3(grid), dim3(kWinTPB), 0, st, d_rank, (const u64*)ws, m, bin_shift);
+    hipLaunchKernelGGL(k_gather_dense, dim3(grid), dim3(kWinTPB), 0, st, ws, wv, (const u32*)d_rank,
                        (const u8*)d_T, m, n, (u32)(h_next > 0xFFFFFFFFull ? 0xFFFFFFFFu : h_next), b2,
-                       emit ? 1 : 0);
+                       emit ? 1 : 0, bin_shift);
     const bool timed = n_sort_events + 2 <= kMaxSortEvents;
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     sort_pairs<u64>(ws, ws_other, wv, wv_other, m_next, nbits, &res->ks, &res->vs, true, 0, (u64)(m - m_next));
