@@ -64,6 +64,17 @@ def mem_available_gb():
     return 0.0
 
 
+def has_avx512():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                f = line.split()
+                return all(x in f for x in ("avx512f", "avx512bw", "avx512vl", "avx512dq"))
+    except OSError:
+        pass
+    return False
+
+
 def cpu_baseline(size_mib, seed, coder, runs):
     """The CPU path on the same block, one thread (the reference cannot use more,
     Compressor.cpp:67-70): BWT = the reference's own divbwtf when oracle/_ref was built
@@ -111,9 +122,9 @@ def main():
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
     ap.add_argument("--bwt-only", action="store_true", help="the transform alone (config 5 with --size-mib 1024)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="'B': blocks under way at once (0 = 64 when the host has 128 GB of free memory per rank, "
-                         "else 16: a block under way holds 1.2 GB of host memory, and the 16-lane range-coder "
-                         "engines only pay in a deep pipeline)")
+                    help="'B': blocks under way at once.  0 = 96 when the host CPU has AVX-512 (the fused model + "
+                         "range-coder lane engines: a block under way then holds 0.2 GB of host memory) and 24 GB "
+                         "of free memory per rank, else 16 (scalar coders, 1.2 GB per block)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
     ap.add_argument("--cpu-runs", type=int, default=1, help="runs of the one-thread CPU baseline (median and best reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
@@ -135,7 +146,7 @@ def main():
 
     size = args.size_mib << 20
     world_hint = max(1, int(os.environ.get("WORLD_SIZE", "1")))
-    auto_depth = 64 if mem_available_gb() / world_hint >= 128 else 16
+    auto_depth = 96 if (has_avx512() and mem_available_gb() / world_hint >= 24) else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
@@ -216,6 +227,7 @@ def main():
     # ---- timed: K steps, each begins one block and (B) collects one ------------------------------
     elapsed = farm.timed(timed_step, args.steps, 0, None)
     m1, c1, b1 = ctx.wavelet_host_clock()
+    gpu_s, collect_s = clock["gpu_s"], clock["collect_s"]            # of the timed region only
     t0 = time.perf_counter()
     drain()
     drain_ms = 1e3 * (time.perf_counter() - t0)
@@ -254,8 +266,8 @@ def main():
                                         "frac": round(whole_bytes / (bwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                         "rule": "SURVEY.md 8(d): N (97 + 100 R_eff) bytes / device time of the transform"}}
         step_ms = 1e3 * elapsed / args.steps
-        gpu_ms = 1e3 * clock["gpu_s"] / args.steps
-        wait_ms = 1e3 * clock["collect_s"] / args.steps
+        gpu_ms = 1e3 * gpu_s / args.steps
+        wait_ms = 1e3 * collect_s / args.steps
         blocks_done = max(1, b1 - b0)
         what = ("BWT only" if coder is None else "BWT+encode")
         out = {

@@ -107,9 +107,12 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
       if (rc) return rc;
       job.codes = job.codes_owner.data();
       const auto t2 = std::chrono::steady_clock::now();
-      if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
-      if (!job.prob.reserve(e.wt_coded + 8)) return -2;
       if (!e.pipeline) e.pipeline = new HostPipeline(threads, e.huge_group_elements, e.max_inflight);
+      job.fused = e.pipeline->fusedNow(e.wavelet_model);
+      if (!job.fused) {
+        if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
+        if (!job.prob.reserve(e.wt_coded + 8)) return -2;
+      }
       if (debug) {
         uint64_t cnt[8] = {0}, el[8] = {0};
         const uint32_t* pos = job.coded_pos.data();

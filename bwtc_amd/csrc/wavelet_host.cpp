@@ -1063,6 +1063,38 @@ void StreamCoder::describeChain(size_t k, const uint16_t* prob, std::vector<Sect
   d->cookie = 0;
 }
 
+void StreamCoder::describeSectionFused(size_t k, std::vector<SectionOutput>* out, std::vector<FusedGroup>* groups,
+                                       FusedSectionDesc* d) const {
+  const size_t s = sections_[k];
+  const StreamPlan::Section& sec = plan_.sections[s];
+  std::vector<uint8_t>& bytes = (*out)[s].bytes;
+  bytes = sec.prefix;
+  const uint32_t* pos = pos_ + sec.group_base;
+  groups->clear();
+  // the same groups, in the same order, as the model tasks of the constructor: the symbol tree's
+  // nodes, then the integer levels (one model reset per level, WaveletTree.hpp:792-797)
+  for (uint32_t g = 0; g < sec.n_nodes; ++g) {
+    if (pos[g + 1] <= pos[g]) continue;
+    FusedGroup fg;
+    fg.begin = pos[g]; fg.end = pos[g + 1];
+    fg.type = plan_.group_type[sec.group_base + g];
+    fg.mainState = (fg.type == kInteger || fg.type == kBothLeaves) ? 0 : static_cast<uint8_t>(stateBefore(s, g));
+    groups->push_back(fg);
+  }
+  for (size_t l = 0; l + 1 < sec.level_first.size(); ++l) {
+    if (pos[sec.level_first[l + 1]] <= pos[sec.level_first[l]]) continue;
+    FusedGroup fg;
+    fg.begin = pos[sec.level_first[l]]; fg.end = pos[sec.level_first[l + 1]];
+    fg.type = kInteger; fg.mainState = 0;
+    groups->push_back(fg);
+  }
+  d->codes = codes_;
+  d->groups = groups->data();
+  d->n_groups = groups->size();
+  d->out = &bytes;
+  d->cookie = 0;
+}
+
 void StreamCoder::startSection(size_t k, std::vector<SectionOutput>* out, void* chain) const {
   const size_t s = sections_[k];
   const StreamPlan::Section& sec = plan_.sections[s];

@@ -122,6 +122,11 @@ class StreamCoder {
   // section task k as a chain for the 16-lane coder engine (wavelet_rc.hpp): puts the section's
   // prefix into out[section] and describes the elements to code
   void describeChain(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out, ChainDesc* d) const;
+  // section task k for the fused model + coder engine (wavelet_simd.hpp): its non-empty model groups
+  // in coding order with the main model's state at each group's start (-> *groups, which must
+  // outlive the coding), the section's prefix into out[section]
+  void describeSectionFused(size_t k, std::vector<SectionOutput>* out, std::vector<FusedGroup>* groups,
+                            FusedSectionDesc* d) const;
 
  private:
   struct Task { uint32_t section, group; uint64_t begin, end; uint8_t type; };

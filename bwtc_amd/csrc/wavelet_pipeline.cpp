@@ -43,8 +43,16 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests: small blocks
   if (long_chain_ == 0) long_chain_ = ~static_cast<uint64_t>(0);
   max_pair_engines_ = lanes && long_chain_ != ~static_cast<uint64_t>(0) ? envNumber("BWTC_HIP_PAIR_ENGINES", std::max(1u, (P * 3 + 7) / 8)) : 0u;
+  // Fused engines (models + coder in one lane loop, no probability arrays): every thread runs
+  // one; for pipelines deep enough to keep sixteen chains per engine going through the 4.5 s a
+  // text block's longest chain takes at a lane's pace.  BWTC_HIP_FUSED=1 / 0 overrides.
+  const char* fforce = std::getenv("BWTC_HIP_FUSED");
+  const bool fused = bwtc::wavelet::simdCoderAvailable() && bwtc::wavelet::simdModelsAvailable() &&
+                     (fforce ? fforce[0] == '1' : depth >= kFusedDepth);
+  max_fused_engines_ = fused ? envNumber("BWTC_HIP_FUSED_ENGINES", P) : 0u;
   groups_.on_block_modelled = [this](const std::shared_ptr<WaveletJob>& j) { submitSections(j); };
   chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
+  fused_sections_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   long_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
 }
 
@@ -78,7 +86,9 @@ void HostPipeline::finish(WaveletJob& job) {
 // Every group of the block is modelled: its sections' range coders.
 void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
   jobp->t_modelled = std::chrono::steady_clock::now();
-  if (max_coder_engines_) {
+  // (a lone block, or the first blocks of a stream, keep the scalar chains even in a deep
+  // pipeline: a third of the latency, and there is nothing to share vectors with yet)
+  if (max_coder_engines_ && clock.unfinished.load() >= (int)kFusedBacklog) {
     // section tasks are sorted largest first: [0, n_long) are the very long ones
     size_t n_long = 0;
     while (max_pair_engines_ && n_long < jobp->coder->sectionTasks() && jobp->coder->sectionElements(n_long) >= long_chain_) ++n_long;
@@ -121,6 +131,14 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
   ++clock.blocks;
   if (job.models_left == 0 || job.sections_left == 0) { finishNow(job); return next_state; }
   ++clock.unfinished;
+  if (model == 'B' && max_fused_engines_ && job.fused) {
+    job.models_left = 0;
+    job.fused_groups.assign(job.coder->sectionTasks(), std::vector<bwtc::wavelet::FusedGroup>());
+    job.t_modelled = job.t_queued;
+    if (fused_sections_.add(jobp, max_fused_engines_))
+      pool_.submit(0, [this] { bwtc::wavelet::runFusedLanes(fused_sections_, &clock.coder_ns); });
+    return next_state;
+  }
   if (model == 'B' && bwtc::wavelet::simdModelsAvailable()) {
     // Sixteen groups per thread at a time, lanes refilled across blocks (wavelet_simd.hpp,
     // BlockGroupSource).  The block's few huge groups keep scalar tasks of their own, two groups

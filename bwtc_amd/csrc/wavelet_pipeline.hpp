@@ -170,6 +170,27 @@ class BlockChainSource : public bwtc::wavelet::ChainSource {
   unsigned engines_;
 };
 
+// The sections of all queued blocks for the fused model + coder engines (wavelet_simd.hpp).
+class BlockSectionSource : public bwtc::wavelet::SectionSource {
+ public:
+  BlockSectionSource() : engines_(0) {}
+  bool add(const std::shared_ptr<WaveletJob>& job, unsigned max_engines);   // true: start another engine
+  bool next(bwtc::wavelet::FusedSectionDesc* d);
+  void done(void* cookie);
+  bool retire() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!queue_.empty()) return false;
+    --engines_;
+    return true;
+  }
+  std::function<void(WaveletJob&)> on_block_coded;
+ private:
+  struct Entry { std::shared_ptr<WaveletJob> job; size_t at; };
+  std::mutex mu_;
+  std::deque<Entry> queue_;
+  unsigned engines_;
+};
+
 // One block between bwtc_hip_wavelet_encode_device_begin and ..._end.
 struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   virtual ~WaveletJob() {}
@@ -181,6 +202,8 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   RawBuffer<uint16_t> prob;                          // probability of every coded element
   std::unique_ptr<bwtc::wavelet::StreamCoder> coder;
   std::vector<bwtc::wavelet::SectionOutput> outs;
+  std::vector<std::vector<bwtc::wavelet::FusedGroup> > fused_groups;   // fused engines: the sections' group lists
+  bool fused = false;                                // coded by the fused engines (no `prob`); set before queue()
   std::mutex mu;
   std::condition_variable cv;
   size_t models_left = 0, sections_left = 0;
@@ -220,6 +243,14 @@ class HostPipeline {
   // a block without coded elements (or coded elsewhere): closes the record right away
   static void finishNow(WaveletJob& job);
   unsigned threads() const { return pool_.size(); }
+  // Route of the next block of a 'B' stream: true = the fused engines (the job then needs no
+  // probability array).  Even a pipeline built for them sends a block the two-stage way (parallel
+  // models, scalar chains -- a third of the latency) while fewer than kFusedBacklog blocks are
+  // under way: a lone block, or the first blocks of a stream, would crawl through nearly empty
+  // vectors.  The caller sets WaveletJob::fused from this before queue().
+  bool fusedNow(char model) const { return max_fused_engines_ && model == 'B' && clock.unfinished.load() >= (int)kFusedBacklog; }
+  static constexpr unsigned kFusedDepth = 72;
+  static constexpr unsigned kFusedBacklog = 6;
   StageClock clock;
  private:
   void submitSections(const std::shared_ptr<WaveletJob>& job);
@@ -227,12 +258,14 @@ class HostPipeline {
   BlockGroupSource groups_;                          // before the pool: the workers are joined first
   BlockChainSource chains_;                          // sections for the 16-lane coder engines
   BlockChainSource long_chains_;                     // very long sections: scalar engines, two chains at a time
+  BlockSectionSource fused_sections_;                // fused model + coder engines
   WorkerPool pool_;
   uint64_t huge_;
   unsigned max_engines_;
   unsigned max_coder_engines_;                       // 16-lane range-coder engines (0: scalar pairs per block)
   unsigned max_pair_engines_;                        // scalar engines for the very long chains
   uint64_t long_chain_;                              // elements from which a chain counts as very long
+  unsigned max_fused_engines_;                       // > 0: 'B' blocks go to the fused engines, no probability arrays
   size_t coder_tasks_;
 };
 
@@ -310,6 +343,40 @@ inline bool BlockChainSource::next(bwtc::wavelet::ChainDesc* d) {
 inline void BlockChainSource::done(void* cookie) {
   WaveletJob* job = static_cast<WaveletJob*>(cookie);
   const std::shared_ptr<WaveletJob> keep = job->shared_from_this();   // whoever waits for the block may drop it the moment it is done
+  bool last;
+  { std::lock_guard<std::mutex> g(job->mu); last = --job->sections_left == 0; }
+  if (last) on_block_coded(*job);
+}
+
+inline bool BlockSectionSource::add(const std::shared_ptr<WaveletJob>& job, unsigned max_engines) {
+  Entry e;
+  e.job = job;
+  e.at = 0;
+  std::lock_guard<std::mutex> g(mu_);
+  queue_.push_back(std::move(e));
+  if (engines_ >= max_engines) return false;
+  ++engines_;
+  return true;
+}
+
+inline bool BlockSectionSource::next(bwtc::wavelet::FusedSectionDesc* d) {
+  std::shared_ptr<WaveletJob> job;
+  size_t k = 0;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    while (!queue_.empty() && queue_.front().at >= queue_.front().job->coder->sectionTasks()) queue_.pop_front();
+    if (queue_.empty()) return false;
+    job = queue_.front().job;
+    k = queue_.front().at++;
+  }
+  job->coder->describeSectionFused(k, &job->outs, &job->fused_groups[k], d);
+  d->cookie = job.get();
+  return true;
+}
+
+inline void BlockSectionSource::done(void* cookie) {
+  WaveletJob* job = static_cast<WaveletJob*>(cookie);
+  const std::shared_ptr<WaveletJob> keep = job->shared_from_this();
   bool last;
   { std::lock_guard<std::mutex> g(job->mu); last = --job->sections_left == 0; }
   if (last) on_block_coded(*job);

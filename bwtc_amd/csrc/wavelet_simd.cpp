@@ -13,6 +13,9 @@
 #include <cstring>
 
 #include "wavelet_host.hpp"
+#include "wavelet_rc.hpp"
+
+#include <chrono>
 
 namespace bwtc {
 namespace wavelet {
@@ -66,6 +69,23 @@ struct GroupState {
     ++i;
   }
   void run(uint64_t until) { while (i < until) step(); }
+  // the same step without the store: returns the probability of a one, *bit_out = the coded bit
+  inline uint32_t stepP(uint32_t* bit_out) {
+    const uint32_t v = codeAt(codes, i), bit = v & 1u;
+    const uint32_t gap = gapAlways | (gapFromCode & (v >> 1));
+    const uint32_t slot = isInt ? 12u + ic : (gap ? 8u + gc : mc);
+    const uint32_t delay = 5u - static_cast<uint32_t>(slot == 0 || slot == 7);
+    const uint32_t floor = isInt ? 100u : 2u;
+    const uint32_t pr = q[slot];
+    const uint32_t up = pr + (((4096u - floor) - pr) >> delay), down = pr - ((pr - floor) >> delay);
+    q[slot] = bit ? up : down;
+    ic = isInt ? kNext3[ic][bit] : ic;
+    gc = gap ? kNext4[gc][bit] : gc;
+    mc = mainMoves ? kNext8[mc][bit] : mc;
+    ++i;
+    *bit_out = bit;
+    return pr;
+  }
 };
 
 // Lane state between vector runs, structure of arrays
@@ -258,6 +278,227 @@ void runModelLanes(GroupSource& src, int prefer) {
       L.idle(l);
     }
     sourceDry = false;                                                 // ask again: other blocks may have arrived
+  }
+}
+
+
+// ---- fused engine ------------------------------------------------------------------------------
+namespace {
+
+const uint64_t kFusedMaxWords = 256;     // words per vector run (bounds the output room reserved per lane)
+
+struct FusedLanes : Lanes {
+  alignas(64) uint32_t lo[kLanes], size[kLanes];
+  uint8_t* outp[kLanes];
+};
+
+// one lane's section between vector runs
+struct FusedChain {
+  FusedSectionDesc d;
+  size_t g;                 // current group
+  GroupState m;             // its model (m.i = the chain's position)
+  CoderChain c;
+  void startGroup() {
+    ModelGroupDesc gd;
+    gd.codes = d.codes; gd.prob = nullptr; gd.begin = d.groups[g].begin; gd.end = d.groups[g].end;
+    gd.type = d.groups[g].type; gd.mainState = d.groups[g].mainState; gd.cookie = nullptr;
+    m.start(gd);
+  }
+  // scalar: model + coder, elements [m.i, until)
+  void runScalar(uint64_t until) {
+    while (m.i < until) {
+      const uint64_t ce = std::min<uint64_t>(until, m.i + 4096);
+      uint8_t* o = c.room(ce - m.i);
+      uint32_t lo = c.lo, size = c.size;
+      while (m.i < ce) {
+        uint32_t bit;
+        const uint32_t p = m.stepP(&bit);
+        const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(size) * p + 2048u) >> 12);
+        lo = bit ? lo : lo + t + 1;
+        size = bit ? t - 1 : size - t - 1;
+        while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
+      }
+      c.lo = lo; c.size = size;
+      c.used = static_cast<size_t>(o - c.out->data());
+    }
+  }
+  // Brings the lane to the next place where a vector run can start: at least one whole word of
+  // the current group ahead and the position on a word boundary.  Groups too short for that are
+  // coded here.  false: the section is finished (flushed).
+  bool settle() {
+    for (;;) {
+      if (m.i >= m.e) {
+        if (++g >= d.n_groups) { c.finish(); return false; }
+        startGroup();
+      }
+      const uint64_t aligned = (m.i + 15) & ~static_cast<uint64_t>(15);
+      if (m.e - m.i < kScalarOnly || aligned + 16 > m.e) { runScalar(m.e); continue; }
+      if (m.i < aligned) runScalar(aligned);
+      return true;
+    }
+  }
+};
+
+// `words` 16-element words of every busy lane; each stands on a word boundary with that many
+// words of its current group ahead.  The model half is runWords<true, true, true>, the coder half
+// wavelet_rc.cpp's runWords; the probability goes from one to the other in a register.
+BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask) {
+  constexpr int kLo = 0, kHi = 15;
+  __m512i Q[kSlots];
+  for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_load_si512(L.q[s]);
+  __m512i mc = _mm512_load_si512(L.mc), gc = _mm512_load_si512(L.gc), ic = _mm512_load_si512(L.ic);
+  __m512i lo = _mm512_load_si512(L.lo), size = _mm512_load_si512(L.size);
+  const __m512i zero = _mm512_setzero_si512(), one = _mm512_set1_epi32(1), two = _mm512_set1_epi32(2);
+  const __mmask16 kInt = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.isInt), zero);
+  const __mmask16 kGapAlways = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapAlways), zero);
+  const __mmask16 kGapCode = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.gapFromCode), zero);
+  const __mmask16 kMainMoves = _mm512_cmpneq_epi32_mask(_mm512_load_si512(L.mainMoves), zero);
+  const __mmask16 kBusy = static_cast<__mmask16>(busy_mask);
+  const __m512i floorV = _mm512_mask_blend_epi32(kInt, two, _mm512_set1_epi32(100));
+  const __m512i topV = _mm512_sub_epi32(_mm512_set1_epi32(4096), floorV);
+  const __m512i five = _mm512_set1_epi32(5), c8 = _mm512_set1_epi32(8), c12 = _mm512_set1_epi32(12);
+  const __m512i T8 = _mm512_setr_epi32(0, 4, 0, 4, 1, 4, 2, 4, 3, 5, 3, 6, 3, 7, 3, 7);
+  const __m512i T4 = _mm512_setr_epi32(0, 2, 0, 2, 1, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m512i T3 = _mm512_setr_epi32(0, 1, 0, 2, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m512i c4095 = _mm512_set1_epi32(4095), c2048 = _mm512_set1_epi32(2048), c510 = _mm512_set1_epi32(510);
+  const __m512i top = _mm512_set1_epi32(static_cast<int>(0xFF000000u));
+  const __m512i lane_id = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
+  alignas(64) uint32_t in[kLanes];
+  alignas(64) uint32_t ev[16 * kLanes * 4 + 64];
+  for (uint64_t w = 0; w < words; ++w) {
+    for (int l = 0; l < kLanes; ++l) {
+      uint32_t x = 0;
+      if (L.busy[l]) { std::memcpy(&x, L.codes[l] + (L.i[l] >> 2), 4); L.i[l] += 16; }
+      in[l] = x;
+    }
+    __m512i W = _mm512_load_si512(in);
+    uint32_t n = 0;
+    for (int step = 0; step < 16; ++step) {
+      // ---- model: the lane's predictor and its move (runWords<true, true, true>)
+      const __m512i v = _mm512_and_si512(W, _mm512_set1_epi32(3));
+      W = _mm512_srli_epi32(W, 2);
+      const __mmask16 kBit = _mm512_test_epi32_mask(v, one);
+      const __mmask16 kGap = static_cast<__mmask16>(kGapAlways | (kGapCode & _mm512_test_epi32_mask(v, two)));
+      __m512i slot = mc;
+      slot = _mm512_mask_add_epi32(slot, kGap, gc, c8);
+      slot = _mm512_mask_add_epi32(slot, kInt, ic, c12);
+      __mmask16 m[kSlots];
+      __m512i part[16];
+      part[15] = zero;
+      for (int s = kLo; s < kHi; ++s) {
+        m[s] = _mm512_cmpeq_epi32_mask(slot, _mm512_set1_epi32(s));
+        part[s] = _mm512_maskz_mov_epi32(m[s], Q[s]);
+      }
+      for (int width = 8; width >= 1; width >>= 1)
+        for (int k = 0; k < width; ++k) part[k] = _mm512_or_si512(part[k], part[k + width]);
+      const __m512i pr = part[0];
+      const __m512i delay = _mm512_mask_sub_epi32(five, m[0] | m[7], five, one);
+      const __m512i up = _mm512_add_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(topV, pr), delay));
+      const __m512i down = _mm512_sub_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(pr, floorV), delay));
+      const __m512i moved = _mm512_mask_blend_epi32(kBit, down, up);
+      for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_mask_mov_epi32(Q[s], m[s], moved);
+      const __m512i bit = _mm512_and_si512(v, one);
+      mc = _mm512_mask_mov_epi32(mc, kMainMoves, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(mc, 1), bit), T8));
+      gc = _mm512_mask_mov_epi32(gc, kGap, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(gc, 1), bit), T4));
+      ic = _mm512_mask_mov_epi32(ic, kInt, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(ic, 1), bit), T3));
+      // ---- coder: BitEncoder's step with that probability (wavelet_rc.cpp runWords)
+      const __m512i hi = _mm512_srli_epi32(size, 12), lw = _mm512_and_si512(size, c4095);
+      const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, pr),
+                                          _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, pr), c2048), 12));
+      const __m512i t1 = _mm512_add_epi32(tt, one);
+      lo = _mm512_mask_add_epi32(lo, static_cast<__mmask16>(~kBit), lo, t1);
+      size = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(size, t1), _mm512_sub_epi32(tt, one));
+      __m512i hiend = _mm512_add_epi32(_mm512_add_epi32(lo, size), one);
+      __mmask16 em = _mm512_mask_testn_epi32_mask(kBusy, _mm512_xor_si512(lo, hiend), top);
+      for (;;) {
+        _mm512_storeu_si512(ev + n, _mm512_maskz_compress_epi32(em, _mm512_or_si512(_mm512_srli_epi32(lo, 24), lane_id)));
+        n += static_cast<uint32_t>(__builtin_popcount(em));
+        lo = _mm512_mask_slli_epi32(lo, em, lo, 8);
+        size = _mm512_mask_add_epi32(size, em, _mm512_slli_epi32(size, 8), c510);
+        hiend = _mm512_add_epi32(_mm512_add_epi32(lo, size), one);
+        em = _mm512_mask_testn_epi32_mask(em, _mm512_xor_si512(lo, hiend), top);
+        if (__builtin_expect(em == 0, 1)) break;
+      }
+    }
+    for (uint32_t k = 0; k < n; ++k) { const uint32_t e = ev[k]; *L.outp[e >> 8]++ = static_cast<uint8_t>(e); }
+  }
+  for (int s = kLo; s < kHi; ++s) _mm512_store_si512(L.q[s], Q[s]);
+  _mm512_store_si512(L.mc, mc);
+  _mm512_store_si512(L.gc, gc);
+  _mm512_store_si512(L.ic, ic);
+  _mm512_store_si512(L.lo, lo);
+  _mm512_store_si512(L.size, size);
+}
+
+}  // namespace
+
+void runFusedLanes(SectionSource& src, std::atomic<uint64_t>* busy_ns) {
+  auto tick = std::chrono::steady_clock::now();
+  auto account = [&] {
+    if (!busy_ns) return;
+    const auto now = std::chrono::steady_clock::now();
+    *busy_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(now - tick).count());
+    tick = now;
+  };
+  static FusedLanes* dummy = nullptr; (void)dummy;
+  std::vector<FusedChain> chain(kLanes);
+  FusedLanes L;
+  std::memset(static_cast<Lanes*>(&L), 0, sizeof(Lanes));
+  for (int l = 0; l < kLanes; ++l) { L.idle(l); L.lo[l] = 0; L.size[l] = 0xFFFFFFFEu; L.outp[l] = nullptr; }
+  bool sourceDry = false;
+  for (;;) {
+    int busy = 0;
+    for (int l = 0; l < kLanes; ++l) {
+      while (!L.busy[l] && !sourceDry) {
+        FusedChain& ch = chain[l];
+        if (!src.next(&ch.d)) { sourceDry = true; break; }
+        ch.c.start(ch.d.n_groups ? ch.d.groups[0].begin : 0, ch.d.n_groups ? ch.d.groups[ch.d.n_groups - 1].end : 0, ch.d.out);
+        if (ch.d.n_groups == 0) { ch.c.finish(); src.done(ch.d.cookie); continue; }
+        ch.g = 0;
+        ch.startGroup();
+        if (!ch.settle()) { src.done(ch.d.cookie); continue; }
+        L.busy[l] = true;
+      }
+      busy += L.busy[l];
+    }
+    account();
+    if (busy == 0) {
+      if (sourceDry && src.retire()) return;
+      sourceDry = false;
+      continue;
+    }
+    if (busy < kMinLanes && sourceDry) {
+      // too few chains for a vector: a slice of each, scalar; then ask the source again
+      for (int l = 0; l < kLanes; ++l) {
+        if (!L.busy[l]) continue;
+        FusedChain& ch = chain[l];
+        ch.runScalar(std::min<uint64_t>(ch.m.e, ch.m.i + (static_cast<uint64_t>(1) << 20)));
+        if (!ch.settle()) { src.done(ch.d.cookie); L.idle(l); }
+      }
+      sourceDry = false;
+      continue;
+    }
+    uint64_t words = kFusedMaxWords;
+    uint32_t mask = 0;
+    for (int l = 0; l < kLanes; ++l) if (L.busy[l]) { words = std::min(words, (chain[l].m.e - chain[l].m.i) >> 4); mask |= 1u << l; }
+    for (int l = 0; l < kLanes; ++l) {
+      if (!L.busy[l]) continue;
+      FusedChain& ch = chain[l];
+      L.put(l, ch.m);                              // predictors, state machines, type switches, position
+      L.lo[l] = ch.c.lo; L.size[l] = ch.c.size;
+      L.outp[l] = ch.c.room(words * 16);
+    }
+    runFusedWords(L, words, mask);
+    for (int l = 0; l < kLanes; ++l) {
+      if (!L.busy[l]) continue;
+      FusedChain& ch = chain[l];
+      L.take(l, &ch.m);
+      ch.c.lo = L.lo[l]; ch.c.size = L.size[l];
+      ch.c.i = ch.m.i;
+      ch.c.used = static_cast<size_t>(L.outp[l] - ch.c.out->data());
+      if (ch.m.e - ch.m.i < 16 && !ch.settle()) { src.done(ch.d.cookie); L.idle(l); }
+    }
+    sourceDry = false;
   }
 }
 

@@ -115,6 +115,7 @@ static void runStream(std::mt19937& rng, size_t blocks, size_t block_size, unsig
     job->out.assign(orc_compress_bound(n), 0);
     job->user_out = job->out.data();
     job->user_cap = job->out.size();
+    job->fused = std::getenv("BWTC_HIP_FUSED") != nullptr && (jobs.size() % 3) != 1;   // fused engines, with two-stage blocks in between
     state = pipe.queue(job, state, 'B');                               // all blocks under way at once
     jobs.push_back(job);
     sizes.push_back(n);
@@ -182,6 +183,7 @@ static void runFarmedStream(std::mt19937& rng, size_t blocks, size_t block_size,
     job->out.assign(orc_compress_bound(n), 0);
     job->user_out = job->out.data();
     job->user_cap = job->out.size();
+    job->fused = std::getenv("BWTC_HIP_FUSED") != nullptr;
     state = pipes[k % n_pipes]->queue(job, state, 'B');               // the state travels from pipeline to pipeline
     jobs.push_back(job);
     sizes.push_back(n);
@@ -221,6 +223,12 @@ int main() {
   unsetenv("BWTC_HIP_LONG_CHAIN_ELEMENTS");
   runStream(rng, 7, 300000, 5, 32u << 20, 8);
   unsetenv("BWTC_HIP_CODER_LANES");
+  // fused engines: models and range coder in one lane loop, no probability arrays
+  setenv("BWTC_HIP_FUSED", "1", 1);
+  runStream(rng, 9, 250000, 6, 32u << 20, 8);
+  runStream(rng, 14, 70000, 3, 32u << 20, 1);
+  runFarmedStream(rng, 8, 120000, 2, 8);
+  unsetenv("BWTC_HIP_FUSED");
   std::printf(failures ? "%d FAILURES\n" : "host pipeline: all tests passed\n", failures);
   return failures ? 1 : 0;
 }

@@ -380,3 +380,43 @@ def test_wavelet_streams_cross_decode_with_the_oracle_decoder(hip_ctx, oracle):
         back = oracle.oracle_decompress_wavelet(np.frombuffer(out, np.uint8), d.size + 8)
         assert back is not None and back.tobytes() == d.tobytes(), (length, reps, block, sp)
         assert out == oracle.oracle_compress_B(d, block, sp).tobytes(), (length, reps, block, sp)
+
+
+@pytest.mark.parametrize("switch", ["BWTC_HIP_CODER_LANES", "BWTC_HIP_FUSED"])
+def test_wavelet_B_lane_engines_give_the_sequential_stream(switch, oracle):
+    """The two host routes that deep pipelines use -- the 16-lane range-coder engines over stored
+    probabilities, and the fused model + coder engines -- forced on for a short pipeline: eight
+    blocks under way at once must still give the oracle's sequential stream (with the fused
+    engines the first blocks of the stream take the two-stage route, the later ones the lanes)."""
+    from bwtc_amd import hip
+    os.environ[switch] = "1"
+    try:
+        os.environ["BWTC_HIP_WAVELET_DEPTH"] = "32"
+        ctx = hip.Context(device=0, max_block_size=(2 << 20) + 1024)
+    finally:
+        del os.environ[switch]
+        del os.environ["BWTC_HIP_WAVELET_DEPTH"]
+    try:
+        d = np.concatenate([synth.gen_text(9 << 20, 21), synth.gen_dna(2 << 20, 5), synth.gen_random_bytes(1 << 20, 9),
+                            synth.gen_text(7 << 20, 22)])
+        bs = 1 << 20
+        ctx.wavelet_reset()
+        d_in = ctx.dmalloc(bs + 64)
+        outs, tickets, sizes = [], [], []
+        for off in range(0, d.size, bs):
+            blk = d[off:off + bs]
+            ctx.to_device(d_in, blk)
+            lf, freqs = ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+            out = np.zeros(ctx.compress_bound(blk.size), np.uint8)
+            tickets.append(ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=6))
+            outs.append(out)
+            sizes.append(blk.size)
+        ctx.dfree(d_in)
+        stream = b"B"
+        for t, out, n in zip(tickets, outs, sizes):
+            m = ctx.wavelet_encode_end(t)
+            stream += _packed(n) + _packed(1) + b"\x00" + out[:m].tobytes()
+        stream += b"\x00"
+        assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes(), switch
+    finally:
+        ctx.close()
