@@ -19,12 +19,21 @@ namespace bwtc_hip {
 
 constexpr int kRadixBits = 8;
 constexpr int kRadixBins = 1 << kRadixBits;
-constexpr int kRadixTPB = 512;                    // 8 waves
+#ifndef BWTC_RADIX_TPB
+#define BWTC_RADIX_TPB 512
+#endif
+#ifndef BWTC_RADIX_E64
+#define BWTC_RADIX_E64 8
+#endif
+#ifndef BWTC_RADIX_E32
+#define BWTC_RADIX_E32 16
+#endif
+constexpr int kRadixTPB = BWTC_RADIX_TPB;         // 8 waves
 constexpr int kRadixWaves = kRadixTPB / kWave;
 
 template <typename K> struct RadixCfg;
-template <> struct RadixCfg<u32> { static constexpr int E = 16; };   // 8192 pairs, 64 KiB LDS
-template <> struct RadixCfg<u64> { static constexpr int E = 8; };    // 4096 pairs, 48 KiB LDS
+template <> struct RadixCfg<u32> { static constexpr int E = BWTC_RADIX_E32; };   // 8192 pairs, 64 KiB LDS
+template <> struct RadixCfg<u64> { static constexpr int E = BWTC_RADIX_E64; };    // 4096 pairs, 48 KiB LDS
 
 template <typename K> constexpr int radix_tile() { return kRadixTPB * RadixCfg<K>::E; }
 
