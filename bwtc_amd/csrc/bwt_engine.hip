@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
                                                         u8* __restrict__ T, u32 ncopy,
                                                         u32 padded, int reverse, int aligned,
                                                         u32* __restrict__ freqs) {
-  __shared__ __attribute__((aligned(16))) u8 s_src[kLoadTile + 32];
+  __shared__ __attribute__((aligned(16))) u8 s_src[kLoadTile + 48];   // + slack: the fast path reads one word past its 16 bytes
   __shared__ u32 s_hist[256 * 16];
   const u32 tid = threadIdx.x;
   for (u32 i = tid; i < 256 * 16; i += kLoadTPB) s_hist[i] = 0;
@@ -56,14 +56,32 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
   if (j0 < dend) {
     u32 wds[4] = {0, 0, 0, 0};
     const u32 copy = tid & 15u;
+    if (j0 + 16u <= ncopy) {
+      // all sixteen bytes have a source: five aligned LDS words, shifted into place (byte reads of
+      // LDS made this kernel latency bound); reversed = the same bytes, words and bytes swapped
+      const u32 off = (reverse ? (ncopy - 16u - j0) : j0) - w_lo;
+      const u32* s32 = reinterpret_cast<const u32*>(s_src) + (off >> 2);
+      const u32 sh = (off & 3u) * 8u;
+      u32 d[5];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const u32 j = j0 + e;
-      if (j < ncopy) {
-        const u32 a = reverse ? (ncopy - 1u - j) : j;
-        const u32 c = s_src[a - w_lo];
-        wds[e >> 2] |= c << (8 * (e & 3));
-        atomicAdd(&s_hist[c * 16u + copy], 1u);
+      for (int q = 0; q < 5; ++q) d[q] = s32[q];
+      u32 w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = sh ? ((d[q] >> sh) | (d[q + 1] << (32u - sh))) : d[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wds[q] = reverse ? __builtin_bswap32(w[3 - q]) : w[q];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) atomicAdd(&s_hist[((wds[e >> 2] >> (8 * (e & 3))) & 255u) * 16u + copy], 1u);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const u32 j = j0 + e;
+        if (j < ncopy) {
+          const u32 a = reverse ? (ncopy - 1u - j) : j;
+          const u32 c = s_src[a - w_lo];
+          wds[e >> 2] |= c << (8 * (e & 3));
+          atomicAdd(&s_hist[c * 16u + copy], 1u);
+        }
       }
     }
     *reinterpret_cast<uint4*>(T + j0) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
@@ -90,24 +108,37 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
                                                    K* __restrict__ keys, u32* __restrict__ idx,
                                                    u32 n, int k, u32 sigma, K top) {
-  // four consecutive slots (= four consecutive suffixes) per thread: the first key is built
-  // from k characters, the next three by rolling one character out and one in
-  // (top = sigma^(k-1)), so a thread reads k+3 bytes instead of 4k.
+  // A workgroup makes 1024 consecutive slots.  The dense codes of its stretch of T are staged in
+  // LDS once; a thread builds four consecutive suffixes' keys -- the first from k characters, the
+  // next three by rolling one character out and one in (top = sigma^(k-1)), k+3 LDS bytes instead
+  // of 4k -- and parks them in LDS, from where consecutive lanes write consecutive slots (a thread
+  // storing its own four keys would touch a cache line per lane).
+  constexpr u32 kTile = 1024;
   __shared__ u8 s_lut[256];
+  __shared__ u8 s_code[kTile + 64];
+  __shared__ K s_key[kTile];
   s_lut[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
-  const u32 j0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-  if (j0 >= n) return;
-  const u32 cnt = min(4u, n - j0);
-  const u32 i_low = n - j0 - cnt;                   // suffix of slot j0 + cnt - 1
-  K key = 0;
-  for (int t = 0; t < k; ++t) key = (K)(key * (K)sigma) + (K)s_lut[T[i_low + t]];
-  for (u32 s = 0; s < cnt; ++s) {
-    const u32 i = i_low + s;
-    const u32 slot = n - 1u - i;
-    keys[slot] = key;
-    idx[slot] = i;
-    key = (K)((key - (K)s_lut[T[i]] * top) * (K)sigma) + (K)s_lut[T[i + k]];
+  const u32 J0 = blockIdx.x * kTile;                // first slot of the tile
+  if (J0 >= n) return;
+  const u32 cntw = min(kTile, n - J0);              // its slots
+  const u32 i_base = n - J0 - cntw;                 // smallest suffix of the tile (its last slot)
+  for (u32 t = threadIdx.x; t < cntw + (u32)k; t += 256u) s_code[t] = s_lut[T[i_base + t]];   // T is zero padded
+  __syncthreads();
+  const u32 o = 4u * threadIdx.x;                   // this thread's suffixes: i_base + o .. + 3
+  if (o < cntw) {
+    const u32 cnt = min(4u, cntw - o);
+    K key = 0;
+    for (int t = 0; t < k; ++t) key = (K)(key * (K)sigma) + (K)s_code[o + t];
+    for (u32 s = 0; s < cnt; ++s) {
+      s_key[cntw - 1u - (o + s)] = key;             // slot order is descending suffix order
+      key = (K)((key - (K)s_code[o + s] * top) * (K)sigma) + (K)s_code[o + s + k];
+    }
+  }
+  __syncthreads();
+  for (u32 j = threadIdx.x; j < cntw; j += 256u) {
+    keys[J0 + j] = s_key[j];
+    idx[J0 + j] = n - 1u - (J0 + j);
   }
 }
 
