@@ -30,7 +30,13 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
   __shared__ u32 s_hist[256 * 16];
   const u32 tid = threadIdx.x;
   for (u32 i = tid; i < 256 * 16; i += kLoadTPB) s_hist[i] = 0;
-  const u32 d0 = blockIdx.x * kLoadTile;                 // first destination byte
+  // A workgroup walks many tiles and flushes its histogram once: one flush per 4 KiB tile was
+  // 65 000 global atomics on each of the 256 counters for a 256 MiB block, and that serialisation
+  // -- not the bytes -- was this kernel's time.
+  const u32 ntiles = (padded + (u32)kLoadTile - 1u) / (u32)kLoadTile;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();                                       // the previous tile's readers of s_src are done
+  const u32 d0 = tile * kLoadTile;                       // first destination byte
   const u32 dend = min(d0 + (u32)kLoadTile, padded);     // one past the last one
   // source bytes this tile needs: [a_lo, a_hi)
   u32 a_lo = 0, a_hi = 0;
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
     }
     *reinterpret_cast<uint4*>(T + j0) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
   }
+  }                                                      // tiles
   __syncthreads();
   u32 c = 0;
 #pragma unroll
@@ -1030,7 +1037,7 @@ int BwtEngine::load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* h
   BWTC_HIP_TRY(hipMemsetAsync(d_small, 0, 1024 * 4, st));
   const u32 padded = (u32)((((u64)n + kTextPad + 15) / 16) * 16);
   const int aligned = (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0;
-  hipLaunchKernelGGL(k_load_hist, dim3(ceil_div(padded, kLoadTile)), dim3(kLoadTPB), 0, st, d_src,
+  hipLaunchKernelGGL(k_load_hist, dim3(std::min<u32>(ceil_div(padded, kLoadTile), 2048u)), dim3(kLoadTPB), 0, st, d_src,
                      d_T, ncopy, padded, reverse ? 1 : 0, aligned, d_small + kSmallFreqs);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFreqs, d_small + kSmallFreqs, 256 * 4,
                               hipMemcpyDeviceToHost, st));
