@@ -133,11 +133,12 @@ template <bool GAMMA, bool DIST>
 __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
     const u8* __restrict__ bwt, u32 size, const u32* __restrict__ sec_start, u32 nsec,
     const u32* __restrict__ tile_off, u32* __restrict__ run_start, u8* __restrict__ run_sym,
-    u32* __restrict__ first_run, u32* __restrict__ n_runs, int aligned, RunStatsOut o) {
+    u32* __restrict__ first_run, u32* __restrict__ n_runs, int aligned, RunStatsOut o, u32 ntiles,
+    u32 tiles_per_wg) {
   __shared__ u32 s_sec[256];
   __shared__ u32 scr[kRunTPB / kWave + 1];
   __shared__ u32 s_fh[kRunTPB];               // position of the thread's first head, ~0 if it has none
-  __shared__ u32 hist[256 * 8];               // runs per symbol of the tile's first section, 8 copies
+  __shared__ u32 hist[256 * 8];               // runs per symbol of the section being accumulated, 8 copies
   __shared__ u32 s_len[kLenLds];
   __shared__ u32 s_g0;
   if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
@@ -145,59 +146,74 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
   if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) s_len[i] = 0;
   if (threadIdx.x == 0) s_g0 = 0;
   __syncthreads();
-  const u32 t0 = blockIdx.x * kRunTile;
-  const u32 p0 = t0 + threadIdx.x * kRunE;
-  u8 b[kRunE];
-  u32 sec;                                    // first section start >= p0
-  const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
-  s_fh[threadIdx.x] = heads ? p0 + (u32)__builtin_ctz(heads) : 0xFFFFFFFFu;
-  u32 total;
-  u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[blockIdx.x];
-  // (block_scan's barriers also publish s_fh)
-  // section of the tile's first byte: its runs are counted in LDS
-  u32 s0;
-  { u32 lo = 0, hi = nsec; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_sec[mid] <= t0) lo = mid; else hi = mid; } s0 = lo; }
-  const u32 s0_end = s0 + 1 < nsec ? s_sec[s0 + 1] : 0xFFFFFFFFu;
-  u32 cur = sec ? sec - 1u : 0u;              // section of the byte before the next section start
-  u32 gsum = 0;
-  const u32 copy = threadIdx.x & 7u;
-  u32 open_run = kNoRun;
-  if (heads) {
-    // end of the thread's last run: the first head of a later thread, if the tile has one
-    u32 next_after = 0xFFFFFFFFu;
-    for (u32 t = threadIdx.x + 1; t < kRunTPB; ++t) { const u32 f = s_fh[t]; if (f != 0xFFFFFFFFu) { next_after = f; break; } }
-    u32 rest = heads;
+  // A workgroup walks a contiguous range of tiles and keeps the LDS statistics of the section its
+  // tiles start in; they are flushed when that section changes and at the end (a flush per tile
+  // is tens of thousands of global atomics on the same few hundred counters).
+  auto flush = [&](u32 s) {                   // all threads; barriers around it are the caller's
+    u32 c = 0;
 #pragma unroll
-    for (int e = 0; e < kRunE; ++e) {
-      const u32 p = p0 + e;
-      if (p >= size) break;
-      if ((heads >> e) & 1u) {
-        run_start[r] = p;
-        run_sym[r] = b[e];
-        if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; cur = sec; ++sec; }
-        rest &= rest - 1u;                    // heads after this one
-        const u32 nxt = rest ? p0 + (u32)__builtin_ctz(rest) : next_after;
-        if (nxt != 0xFFFFFFFFu) count_run<GAMMA, DIST>(o, cur, b[e], nxt - p, p < s0_end && cur == s0, hist, s_len, copy, gsum);
-        else open_run = r;
-        ++r;
-      }
-      if (p == size - 1) { *n_runs = r; run_start[r] = size; first_run[nsec] = r; }
+    for (int k = 0; k < 8; ++k) { c += hist[threadIdx.x * 8u + k]; hist[threadIdx.x * 8u + k] = 0; }
+    if (c) atomicAdd(&o.run_freqs[s * 256u + threadIdx.x], c);
+    if (GAMMA && threadIdx.x == 0 && s_g0) { atomicAdd(&o.gbits[s], (unsigned long long)s_g0); s_g0 = 0; }
+    if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) { const u32 v = s_len[i]; if (v) { atomicAdd(&o.dense[(u64)s * kLenDense + i], v); s_len[i] = 0; } }
+  };
+  const u32 tile_begin = blockIdx.x * tiles_per_wg;
+  const u32 tile_end = min(tile_begin + tiles_per_wg, ntiles);
+  u32 acc_s = 0xFFFFFFFFu;                    // section the LDS statistics belong to
+  const u32 copy = threadIdx.x & 7u;
+  for (u32 tile = tile_begin; tile < tile_end; ++tile) {
+    const u32 t0 = tile * kRunTile;
+    const u32 p0 = t0 + threadIdx.x * kRunE;
+    // section of the tile's first byte: its runs are counted in LDS
+    u32 s0;
+    { u32 lo = 0, hi = nsec; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_sec[mid] <= t0) lo = mid; else hi = mid; } s0 = lo; }
+    __syncthreads();                          // the previous tile's LDS traffic is done
+    if (s0 != acc_s) {
+      if (acc_s != 0xFFFFFFFFu) { flush(acc_s); __syncthreads(); }
+      acc_s = s0;
     }
-  } else if (p0 < size && p0 + kRunE > size - 1u) {
-    *n_runs = r; run_start[r] = size; first_run[nsec] = r;       // the block's last byte is here, its run started earlier
-  }
-  if (open_run != kNoRun) o.tile_open[blockIdx.x] = open_run;
-  if (GAMMA) {
-    gsum = wave_scan_add(gsum, lane_id());
-    if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
+    u8 b[kRunE];
+    u32 sec;                                  // first section start >= p0
+    const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
+    s_fh[threadIdx.x] = heads ? p0 + (u32)__builtin_ctz(heads) : 0xFFFFFFFFu;
+    u32 total;
+    u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[tile];
+    // (block_scan's barriers also publish s_fh)
+    const u32 s0_end = s0 + 1 < nsec ? s_sec[s0 + 1] : 0xFFFFFFFFu;
+    u32 cur = sec ? sec - 1u : 0u;            // section of the byte before the next section start
+    u32 gsum = 0;
+    u32 open_run = kNoRun;
+    if (heads) {
+      // end of the thread's last run: the first head of a later thread, if the tile has one
+      u32 next_after = 0xFFFFFFFFu;
+      for (u32 t = threadIdx.x + 1; t < kRunTPB; ++t) { const u32 f = s_fh[t]; if (f != 0xFFFFFFFFu) { next_after = f; break; } }
+      u32 rest = heads;
+#pragma unroll
+      for (int e = 0; e < kRunE; ++e) {
+        const u32 p = p0 + e;                 // (heads has no bits at or beyond size)
+        if ((heads >> e) & 1u) {
+          run_start[r] = p;
+          run_sym[r] = b[e];
+          if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; cur = sec; ++sec; }
+          rest &= rest - 1u;                  // heads after this one
+          const u32 nxt = rest ? p0 + (u32)__builtin_ctz(rest) : next_after;
+          if (nxt != 0xFFFFFFFFu) count_run<GAMMA, DIST>(o, cur, b[e], nxt - p, p < s0_end && cur == s0, hist, s_len, copy, gsum);
+          else open_run = r;
+          ++r;
+        }
+        if (p == size - 1) { *n_runs = r; run_start[r] = size; first_run[nsec] = r; }
+      }
+    } else if (p0 < size && p0 + kRunE > size - 1u) {
+      *n_runs = r; run_start[r] = size; first_run[nsec] = r;     // the block's last byte is here, its run started earlier
+    }
+    if (open_run != kNoRun) o.tile_open[tile] = open_run;
+    if (GAMMA) {
+      gsum = wave_scan_add(gsum, lane_id());
+      if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
+    }
   }
   __syncthreads();
-  u32 c = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) c += hist[threadIdx.x * 8u + k];
-  if (c) atomicAdd(&o.run_freqs[s0 * 256u + threadIdx.x], c);
-  if (GAMMA && threadIdx.x == 0 && s_g0) atomicAdd(&o.gbits[s0], (unsigned long long)s_g0);
-  if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) { const u32 v = s_len[i]; if (v) atomicAdd(&o.dense[(u64)s0 * kLenDense + i], v); }
+  if (acc_s != 0xFFFFFFFFu) flush(acc_s);
 }
 
 // the open run of every tile (its end lies in a later tile), after run_start[] is complete
@@ -487,8 +503,9 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
   so.over_sec = so.over_len = so.over_count = nullptr; so.over_cap = 0;
   so.tile_open = e.d_V1;
   BWTC_HIP_TRY(hipMemsetAsync(so.tile_open, 0xFF, (size_t)rtiles * 4, st));
-  hipLaunchKernelGGL((k_runs_emit_stats<true, false>), dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
-                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so);
+  const u32 tiles_per_wg = ceil_div(rtiles, 2048);
+  hipLaunchKernelGGL((k_runs_emit_stats<true, false>), dim3(ceil_div(rtiles, tiles_per_wg)), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so, rtiles, tiles_per_wg);
   hipLaunchKernelGGL((k_open_runs<true, false>), dim3(ceil_div(rtiles, 256)), dim3(256), 0, st, d_run_start,
                      d_run_sym, d_first_run, nsec, rtiles, so);
   u32 n_runs = 0;
@@ -622,8 +639,9 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   so.over_sec = d_over_sec; so.over_len = d_over_len; so.over_count = d_over_count; so.over_cap = over_cap;
   so.tile_open = e.d_V1;
   BWTC_HIP_TRY(hipMemsetAsync(so.tile_open, 0xFF, (size_t)rtiles * 4, st));
-  hipLaunchKernelGGL((k_runs_emit_stats<false, true>), dim3(rtiles), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
-                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so);
+  const u32 tiles_per_wg = ceil_div(rtiles, 2048);
+  hipLaunchKernelGGL((k_runs_emit_stats<false, true>), dim3(ceil_div(rtiles, tiles_per_wg)), dim3(kRunTPB), 0, st, d_bwt, size, d_sec_start,
+                     nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so, rtiles, tiles_per_wg);
   hipLaunchKernelGGL((k_open_runs<false, true>), dim3(ceil_div(rtiles, 256)), dim3(256), 0, st, d_run_start,
                      d_run_sym, d_first_run, nsec, rtiles, so);
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
