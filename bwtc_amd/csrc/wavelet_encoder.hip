@@ -188,7 +188,12 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
     e.prob_free.back()->swap(job.prob);
   }
   *out_bytes = job.record.size();
-  return job.record.size() <= job.user_cap ? 0 : -1;
+  const int rc = job.record.size() <= job.user_cap ? 0 : -1;
+  if (e.pipeline) {                                   // freed by a worker, not by the thread that feeds the GPU
+    std::shared_ptr<WaveletJob> last(std::move(jobp));
+    e.pipeline->dispose(std::move(last));
+  }
+  return rc;
 }
 
 void wavelet_pipeline_release(BwtEngine& e) {

@@ -243,6 +243,13 @@ class HostPipeline {
   // a block without coded elements (or coded elsewhere): closes the record right away
   static void finishNow(WaveletJob& job);
   unsigned threads() const { return pool_.size(); }
+  // Lets a worker thread drop the last reference to a collected block: its record, section
+  // outputs and tables are a few hundred MB of heap, and returning them to the system costs the
+  // caller's thread -- the one that feeds the GPU -- several milliseconds per block.
+  void dispose(std::shared_ptr<WaveletJob>&& job) {
+    std::shared_ptr<WaveletJob> j(std::move(job));
+    pool_.submit(~static_cast<uint64_t>(0), [j]() mutable { j.reset(); });
+  }
   // Route of the next block of a 'B' stream: true = the fused engines (the job then needs no
   // probability array).  Even a pipeline built for them sends a block the two-stage way (parallel
   // models, scalar chains -- a third of the latency) while fewer than kFusedBacklog blocks are
