@@ -723,6 +723,15 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   return 0;
 }
 
+int BwtEngine::reserve_run_arrays() {
+  if (d_run_start[0]) return 0;
+  for (int b = 0; b < 2; ++b) {
+    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_run_start[b]), (cap + 2) * 4));
+    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_run_sym[b]), cap + 64));
+  }
+  return 0;
+}
+
 hipError_t BwtEngine::wait() {
   const bool block = wait_mode == 2 || (wait_mode == 0 && pipeline != nullptr);
   if (!block || !ev_wait) return hipStreamSynchronize(stream);
@@ -739,6 +748,11 @@ void BwtEngine::release() {
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);
   if (h_stage) (void)hipHostFree(h_stage);
+  for (int b = 0; b < 2; ++b) {
+    if (d_run_start[b]) (void)hipFree(d_run_start[b]);
+    if (d_run_sym[b]) (void)hipFree(d_run_sym[b]);
+    d_run_start[b] = nullptr; d_run_sym[b] = nullptr;
+  }
   if (d_wt) (void)hipFree(d_wt);
   if (h_wt) (void)hipHostFree(h_wt);
   d_wt = nullptr; h_wt = nullptr; wt_bytes = 0; h_wt_bytes = 0;

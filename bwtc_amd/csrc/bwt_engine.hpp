@@ -20,6 +20,7 @@
 #include "radix_sort.hpp"
 #include "wavelet_host.hpp"
 #include "wavelet_pipeline.hpp"
+#include <future>
 #include <map>
 #include <memory>
 #include <utility>
@@ -59,11 +60,16 @@ class PinnedBytes {
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
 struct WaveletSectionStats;
 struct DeviceWaveletJob : WaveletJob {
+  ~DeviceWaveletJob() { if (plan_future.valid()) plan_future.wait(); }   // the planner reads this object
   PinnedBytes codes_owner;
   // between wavelet_encode_prepare and wavelet_encode_queue
   bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
   bool host_route = false;             // coded by encodeSections at queue time instead
   bool queued = false;
+  bool half = false;                   // scanned and (being) planned; streams not made yet
+  int run_buf = 0;                     // which of the engine's run-array buffers holds its runs
+  u32 block_size = 0;
+  std::future<bool> plan_future;       // planStreams on a helper thread
   std::vector<bwtc::wavelet::SectionRuns> host_secs;
   std::vector<u8> host_run_sym;
   std::vector<u32> host_run_start;
@@ -116,6 +122,14 @@ struct BwtEngine {
   u8* h_wt = nullptr;      // pinned: tables up, packed streams down
   u64 h_wt_bytes = 0;
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
+  // run arrays of the 'B' coder's scanner, two buffers: block i is scanned while block i-1's runs still
+  // wait for their stream kernels (wavelet_encoder.hip)
+  u32* d_run_start[2] = {nullptr, nullptr};
+  u8* d_run_sym[2] = {nullptr, nullptr};
+  int next_run_buf = 0;
+  int reserve_run_arrays();
+  std::shared_ptr<DeviceWaveletJob> half_job;   // scanned + planned, its streams still to be made
+  bool deferred_queue = false;        // _begin is in use: a begun block joins the stream one call later
   HostPipeline* pipeline = nullptr;   // worker threads, lane engines, coder tasks ('B'; made by the first block)
   std::map<u64, std::shared_ptr<DeviceWaveletJob> > jobs;
   u64 next_ticket = 1;
@@ -193,12 +207,13 @@ struct WaveletSectionStats {
   std::vector<std::vector<std::pair<u32, u32> > > dist;       // per section: (run length, count), ascending
   std::vector<u32> first_run;                                 // first run of every section, + total
 };
+// d_run_start / d_run_sym: where the runs go (null: the transform's workspace, e.d_R1 / e.d_R2)
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
-                                 WaveletSectionStats* out);
+                                 WaveletSectionStats* out, u32* d_run_start = nullptr, u8* d_run_sym = nullptr);
 
 // Steps of all runs of the block sorted into coding order, skipped bits dropped, the packed
 // streams copied into `codes` (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
-int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
+int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
                            PinnedBytes* codes);
 

@@ -595,7 +595,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
 // appended to an overflow list; the host folds both into sorted (length, count) pairs.
 // ---------------------------------------------------------------------------------------
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
-                                 WaveletSectionStats* out) {
+                                 WaveletSectionStats* out, u32* d_run_start_arg, u8* d_run_sym_arg) {
   hipStream_t st = e.stream;
   if (!freqs || !out) return -1;
   if ((u64)size > e.cap) return -1;
@@ -607,8 +607,8 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   out->dist.assign(nsec, std::vector<std::pair<u32, u32> >());
   if (size == 0 || nsec == 0) return 0;
 
-  u32* d_run_start = static_cast<u32*>(e.d_R1);
-  u8* d_run_sym = static_cast<u8*>(e.d_R2);
+  u32* d_run_start = d_run_start_arg ? d_run_start_arg : static_cast<u32*>(e.d_R1);
+  u8* d_run_sym = d_run_sym_arg ? d_run_sym_arg : static_cast<u8*>(e.d_R2);
   u32* d_tile = e.d_V0;
   u32* d_sec = reinterpret_cast<u32*>(e.d_ent);
   u32* d_sec_start = d_sec;

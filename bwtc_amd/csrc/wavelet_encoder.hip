@@ -11,6 +11,7 @@
 #include "wavelet_pipeline.hpp"
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,11 +22,103 @@
 
 namespace bwtc_hip {
 
+// The device half of a block comes in two parts with a piece of host work between them:
+//   scan     run scanner + section statistics (one sweep over the transformed block); the runs go
+//            to one of the engine's two run-array buffers, not into the transform's workspace
+//   plan     (host, ~3 ms) code sets, tree shapes, coding order of every section -- started on a
+//            helper thread as soon as the statistics are on the host
+//   streams  expand / sort / select / pack kernels, copy of the packed streams to the host
+// With _begin called block after block, the GPU would idle through every plan.  So _begin(i) does
+// scan(i), starts plan(i), and only then runs streams(i-1) -- whose plan was made while the GPU
+// transformed block i -- and queues block i-1 on the host pipeline.  Block i's second part happens
+// in the next _begin, or when somebody needs it (_queue / _end of that block).  The records are
+// the same; a block just joins the host pipeline one call later.
+
+// second part of a block whose first part is done: streams (or the host route), buffers
+static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job) {
+  if (!job.half) return 0;
+  job.half = false;
+  if (!job.plan_future.valid()) return 0;                 // empty block: nothing to plan or code
+  const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool planned = job.plan_future.get();
+  const auto t1 = std::chrono::steady_clock::now();
+  const WaveletSectionStats& st = *job.host_stats;
+  const u32 nsec = (u32)st.sections.size();
+  const u32 n_runs = st.first_run[nsec];
+  const bool on_device = !e.wavelet_on_host && planned && job.plan.max_elements + (1u << 16) < (1ull << 32);
+  if (!on_device && !e.wavelet_on_host)
+    std::fprintf(stderr, "bwtc_hip: block of %u bytes is outside the stream kernels' range (%llu steps, %zu groups); "
+                 "its wavelet trees are built by the host route instead (same bytes, much slower)\n", job.block_size,
+                 (unsigned long long)job.plan.max_elements, job.plan.group_type.size());
+  const u32* d_run_start = e.d_run_start[job.run_buf];
+  const u8* d_run_sym = e.d_run_sym[job.run_buf];
+  if (on_device) {
+    if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
+    int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner);
+    if (rc) return rc;
+    job.codes = job.codes_owner.data();
+    const auto t2 = std::chrono::steady_clock::now();
+    if (!e.pipeline) e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
+    job.fused = e.pipeline->fusedNow(e.wavelet_model);
+    if (!job.fused) {
+      if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
+      if (!job.prob.reserve(e.wt_coded + 8)) return -2;
+    }
+    if (debug) {
+      uint64_t cnt[8] = {0}, el[8] = {0};
+      const uint32_t* pos = job.coded_pos.data();
+      for (size_t g = 0; g + 1 < job.coded_pos.size(); ++g) {
+        const uint64_t n = pos[g + 1] - pos[g];
+        const int b = n >= (32u << 20) ? 7 : n >= (16u << 20) ? 6 : n >= (8u << 20) ? 5 : n >= (4u << 20) ? 4 : n >= (1u << 20) ? 3 : n >= (1u << 16) ? 2 : n >= 256 ? 1 : 0;
+        ++cnt[b]; el[b] += n;
+      }
+      std::fprintf(stderr, "wavelet groups by coded size (<256, <64Ki, <1Mi, <4Mi, <8Mi, <16Mi, <32Mi, more): ");
+      for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
+      std::fprintf(stderr, "\n");
+      std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; waited %.1f ms for the plan, "
+                   "device streams %.1f ms, %u threads\n", n_runs,
+                   (unsigned long long)e.wt_elements, (unsigned long long)e.wt_coded, job.plan.group_type.size(),
+                   std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                   std::chrono::duration<double, std::milli>(t2 - t1).count(), e.pipeline->threads());
+    }
+    job.streams_ready = true;
+  } else {
+    // the runs themselves: symbols and start offsets, as the scanner left them
+    job.host_run_sym.resize(n_runs);
+    job.host_run_start.resize((size_t)n_runs + 1);
+    BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_sym.data(), d_run_sym, n_runs, hipMemcpyDeviceToHost, e.stream));
+    BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_start.data(), d_run_start, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
+    BWTC_HIP_TRY(e.wait());
+    for (u32 s = 0; s < nsec; ++s) {
+      job.host_secs[s].symbols = job.host_run_sym.data() + st.first_run[s];
+      job.host_secs[s].starts = job.host_run_start.data() + st.first_run[s];
+    }
+    job.host_route = true;
+  }
+  return 0;
+}
+
+// the block that still waits for its second part, if any
+static int wavelet_finish_pending_half(BwtEngine& e) {
+  if (!e.half_job) return 0;
+  std::shared_ptr<DeviceWaveletJob> jobp;
+  jobp.swap(e.half_job);
+  return wavelet_finish_device_half(e, *jobp);
+}
+
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
-  int rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);
+  // the previous block: its plan was made while the GPU transformed this one
+  std::shared_ptr<DeviceWaveletJob> prev = e.half_job;
+  int rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);   // scan(i), then streams(i-1)
   if (rc) return rc;
-  return wavelet_encode_queue(e, *ticket, e.wavelet_state, &e.wavelet_state);
+  if (prev && !prev->queued) {
+    rc = wavelet_encode_queue(e, prev->rank, e.wavelet_state, &e.wavelet_state);
+    if (rc) return rc;
+  }
+  e.deferred_queue = true;                            // *ticket joins the stream at the next _begin, or when it is needed
+  return 0;
 }
 
 // Second half of _begin: the block joins its stream.  state_in = the main model's carried state
@@ -37,6 +130,11 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   std::shared_ptr<DeviceWaveletJob> jobp = it->second;
   DeviceWaveletJob& job = *jobp;
   if (job.queued) return -1;
+  if (job.half) {                                    // its streams are not made yet: now
+    if (e.half_job == jobp) e.half_job.reset();
+    const int rc = wavelet_finish_device_half(e, job);
+    if (rc) return rc;
+  }
   job.queued = true;
   if (job.host_route) {
     // shapes the stream kernels do not take: the library's own tree builder, here and now
@@ -53,8 +151,9 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   return 0;
 }
 
-// First half of _begin: everything that does not depend on the blocks before this one (run
-// scanner, plan, stream kernels, copy of the streams to the host).
+// First half of _begin: everything that does not depend on the blocks before this one.  (The
+// streams of THIS block are made later, see above; what is made here are the streams of the block
+// prepared before it.)
 int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                            const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
@@ -65,22 +164,28 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
   job.rank = e.next_ticket;
   job.user_out = out;
   job.user_cap = out_cap;
+  job.block_size = size;
+  job.host_threads = threads;
   // header: WaveletEncoder::writeBlockHeader, WaveletCoders.cpp:173-219
   std::vector<uint8_t>& rec = job.record;
   rec.assign(6, 0);
   bwtc::writeBWTBlockHeader(lf, n_lf, rec);
-  WaveletSectionStats st;
-  const auto t_begin = std::chrono::steady_clock::now();
-  int rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st);
+  job.host_stats.reset(new WaveletSectionStats());
+  WaveletSectionStats& st = *job.host_stats;
+  int rc = e.reserve_run_arrays();
+  if (rc) return rc;
+  job.run_buf = e.next_run_buf;
+  e.next_run_buf ^= 1;
+  rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st, e.d_run_start[job.run_buf], e.d_run_sym[job.run_buf]);
   if (rc) return rc;
   const u32 nsec = (u32)st.sections.size();
   rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
   for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
+  job.half = true;
   if (size && nsec) {
-    const u32 n_runs = st.first_run[nsec];
-    std::vector<bwtc::wavelet::SectionRuns> secs(nsec);
+    job.host_secs.assign(nsec, bwtc::wavelet::SectionRuns());
     for (u32 s = 0; s < nsec; ++s) {
-      bwtc::wavelet::SectionRuns& r = secs[s];
+      bwtc::wavelet::SectionRuns& r = job.host_secs[s];
       r.symbols = nullptr;
       r.starts = nullptr;
       r.n_runs = st.first_run[s + 1] - st.first_run[s];
@@ -91,74 +196,15 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
     // Tree bit vectors and traversal on the GPU (wavelet_tree.hip), models + range coder on the
     // host.  Shapes the device path does not take (planStreams) and BWTC_HIP_WAVELET=host go
     // through the host's own tree builder instead; both are this library's code and give the
-    // same bytes.
-    const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const bool on_device = !e.wavelet_on_host && bwtc::wavelet::planStreams(secs, &job.plan) &&
-                           job.plan.max_elements + (1u << 16) < (1ull << 32);
-    if (!on_device && !e.wavelet_on_host)
-      std::fprintf(stderr, "bwtc_hip: block of %u bytes is outside the stream kernels' range (%llu steps, %zu groups); "
-                   "its wavelet trees are built by the host route instead (same bytes, much slower)\n", size,
-                   (unsigned long long)job.plan.max_elements, job.plan.group_type.size());
-    if (on_device) {
-      const auto t1 = std::chrono::steady_clock::now();
-      if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-      rc = wavelet_streams_device(e, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner);
-      if (rc) return rc;
-      job.codes = job.codes_owner.data();
-      const auto t2 = std::chrono::steady_clock::now();
-      if (!e.pipeline) e.pipeline = new HostPipeline(threads, e.huge_group_elements, e.max_inflight);
-      job.fused = e.pipeline->fusedNow(e.wavelet_model);
-      if (!job.fused) {
-        if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
-        if (!job.prob.reserve(e.wt_coded + 8)) return -2;
-      }
-      if (debug) {
-        uint64_t cnt[8] = {0}, el[8] = {0};
-        const uint32_t* pos = job.coded_pos.data();
-        for (size_t g = 0; g + 1 < job.coded_pos.size(); ++g) {
-          const uint64_t n = pos[g + 1] - pos[g];
-          const int b = n >= (32u << 20) ? 7 : n >= (16u << 20) ? 6 : n >= (8u << 20) ? 5 : n >= (4u << 20) ? 4 : n >= (1u << 20) ? 3 : n >= (1u << 16) ? 2 : n >= 256 ? 1 : 0;
-          ++cnt[b]; el[b] += n;
-        }
-        std::fprintf(stderr, "wavelet groups by coded size (<256, <64Ki, <1Mi, <4Mi, <8Mi, <16Mi, <32Mi, more): ");
-        for (int b = 0; b < 8; ++b) std::fprintf(stderr, "%llu/%.1fM ", (unsigned long long)cnt[b], el[b] * 1e-6);
-        std::fprintf(stderr, "\n");
-      }
-      const auto t3 = std::chrono::steady_clock::now();
-      if (debug) {
-        std::fprintf(stderr, "wavelet: %u runs, %llu steps, %llu coded, %zu groups; run scanner %.1f ms, plan %.1f ms, "
-                     "device streams %.1f ms, hand-over %.1f ms, %u threads\n", n_runs,
-                     (unsigned long long)e.wt_elements, (unsigned long long)e.wt_coded, job.plan.group_type.size(),
-                     std::chrono::duration<double, std::milli>(t0 - t_begin).count(),
-                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                     std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                     std::chrono::duration<double, std::milli>(t3 - t2).count(), e.pipeline->threads());
-      }
-      job.streams_ready = true;
-    } else {
-      // the runs themselves: symbols and start offsets, left in the workspace by the scanner; the
-      // statistics the sections point into move into the job with them
-      job.host_run_sym.resize(n_runs);
-      job.host_run_start.resize((size_t)n_runs + 1);
-      BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_sym.data(), e.d_R2, n_runs, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(hipMemcpyAsync(job.host_run_start.data(), e.d_R1, ((size_t)n_runs + 1) * 4, hipMemcpyDeviceToHost, e.stream));
-      BWTC_HIP_TRY(e.wait());
-      job.host_stats.reset(new WaveletSectionStats());
-      *job.host_stats = std::move(st);
-      const WaveletSectionStats& hs = *job.host_stats;
-      for (u32 s = 0; s < nsec; ++s) {
-        secs[s].symbols = job.host_run_sym.data() + hs.first_run[s];
-        secs[s].starts = job.host_run_start.data() + hs.first_run[s];
-        secs[s].run_freqs = &hs.run_freqs[(size_t)s * 256];
-        secs[s].dist = hs.dist[s].data();
-        secs[s].n_dist = hs.dist[s].size();
-      }
-      job.host_secs = secs;
-      job.host_threads = threads;
-      job.host_route = true;
-    }
+    // same bytes.  The plan is made on a helper thread while the GPU does something else.
+    DeviceWaveletJob* jp = jobp.get();
+    const bool want_plan = !e.wavelet_on_host;
+    job.plan_future = std::async(std::launch::async, [jp, want_plan] { return want_plan && bwtc::wavelet::planStreams(jp->host_secs, &jp->plan); });
   }
+  // the block prepared before this one: its streams, now that its plan has had the time of a transform
+  rc = wavelet_finish_pending_half(e);
+  if (rc) return rc;
+  e.half_job = jobp;
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;
   return 0;
@@ -169,7 +215,14 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
   if (it == e.jobs.end() || !out_bytes) return -1;
   std::shared_ptr<DeviceWaveletJob> jobp = it->second;
   DeviceWaveletJob& job = *jobp;
-  if (!job.queued) return -1;                        // prepared but never given its place in a stream
+  if (!job.queued) {
+    // _begin defers a block's entry into the stream to the next _begin; nobody else may have
+    // blocks of this context waiting (the farm's _prepare / _queue callers queue explicitly)
+    if (!e.deferred_queue) return -1;                 // prepared but never given its place in a stream
+    // every block begun before this one is queued already (they are queued in order)
+    const int rc = wavelet_encode_queue(e, ticket, e.wavelet_state, &e.wavelet_state);
+    if (rc) return rc;
+  }
   HostPipeline::wait(job);
   if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
     std::fprintf(stderr, "wavelet block %llu: queued -> modelled %.0f ms, -> finished %.0f ms, -> collected %.0f ms\n",
@@ -197,6 +250,11 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
 }
 
 void wavelet_pipeline_release(BwtEngine& e) {
+  // a block begun with _begin joins the stream one call later: the last one still has to
+  if (e.deferred_queue)
+    for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
+      if (!it->second->queued) (void)wavelet_encode_queue(e, it->first, e.wavelet_state, &e.wavelet_state);
+  e.half_job.reset();
   for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
     if (it->second->queued) HostPipeline::wait(*it->second);   // uncollected blocks are finished, not abandoned half way
   e.jobs.clear();

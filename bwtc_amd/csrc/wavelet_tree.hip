@@ -230,10 +230,9 @@ int BwtEngine::reserve_wavelet(u64 device_bytes, u64 host_bytes) {
   return 0;
 }
 
-// Runs of the block are in e.d_R1 (starts) / e.d_R2 (symbols) as wavelet_section_stats_device
-// left them.  On success coded_pos has plan.group_type.size() + 1 entries and `codes` holds the
+// Runs of the block are in d_run_start / d_run_sym as wavelet_section_stats_device left them.  On success coded_pos has plan.group_type.size() + 1 entries and `codes` holds the
 // packed elements.
-int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& first_run,
+int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
                            PinnedBytes* codes) {
   hipStream_t st = e.stream;
@@ -299,8 +298,6 @@ int wavelet_streams_device(BwtEngine& e, u32 n_runs, const std::vector<u32>& fir
   t.over = reinterpret_cast<const uint4*>(base + o_over);
   t.pool = ptr32(o_pool);
   const u8* d_gtype = base + o_gtype;
-  const u32* d_run_start = static_cast<const u32*>(e.d_R1);
-  const u8* d_run_sym = static_cast<const u8*>(e.d_R2);
 
   // expand
   u32* d_cnt = ptr32(o_cnt);
