@@ -723,6 +723,21 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   return 0;
 }
 
+hipError_t BwtEngine::ensure_d2h_stream() {
+  if (d2h_stream) return hipSuccess;
+  hipError_t rc = hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking);
+  if (rc != hipSuccess) return rc;
+  rc = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming);
+  if (rc != hipSuccess) return rc;
+  return hipEventCreateWithFlags(&ev_codes, hipEventBlockingSync | hipEventDisableTiming);
+}
+
+hipError_t BwtEngine::codes_wait() {
+  if (!codes_in_flight) return hipSuccess;
+  codes_in_flight = false;
+  return hipEventSynchronize(ev_codes);
+}
+
 int BwtEngine::reserve_run_arrays() {
   if (d_run_start[0]) return 0;
   for (int b = 0; b < 2; ++b) {
@@ -745,6 +760,9 @@ void BwtEngine::release() {
   if (stream) (void)hipStreamSynchronize(stream);
   if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
   if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
+  if (d2h_stream) { (void)hipStreamSynchronize(d2h_stream); (void)hipStreamDestroy(d2h_stream); d2h_stream = nullptr; }
+  if (ev_packed) { (void)hipEventDestroy(ev_packed); ev_packed = nullptr; }
+  if (ev_codes) { (void)hipEventDestroy(ev_codes); ev_codes = nullptr; }
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);
   if (h_stage) (void)hipHostFree(h_stage);

@@ -67,6 +67,7 @@ struct DeviceWaveletJob : WaveletJob {
   bool host_route = false;             // coded by encodeSections at queue time instead
   bool queued = false;
   bool half = false;                   // scanned and (being) planned; streams not made yet
+  bool copying = false;                // streams made, their copy to the host may still be in flight
   int run_buf = 0;                     // which of the engine's run-array buffers holds its runs
   u32 block_size = 0;
   std::future<bool> plan_future;       // planStreams on a helper thread
@@ -82,6 +83,11 @@ struct BwtEngine {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;   // uploads that overlap the kernels (bwtc_hip_memcpy_to_device_async)
   hipEvent_t ev_copy = nullptr;
+  hipStream_t d2h_stream = nullptr;    // packed wavelet streams to the host, under the next block's transform
+  hipEvent_t ev_packed = nullptr, ev_codes = nullptr;
+  bool codes_in_flight = false;
+  hipError_t ensure_d2h_stream();
+  hipError_t codes_wait();             // the copy issued by wavelet_streams_device(async_copy) has landed
   u32 max_block = 0;     // largest block size in bytes
   u64 cap = 0;           // suffix capacity = max_block + 1
 
@@ -129,7 +135,9 @@ struct BwtEngine {
   int next_run_buf = 0;
   int reserve_run_arrays();
   std::shared_ptr<DeviceWaveletJob> half_job;   // scanned + planned, its streams still to be made
-  bool deferred_queue = false;        // _begin is in use: a begun block joins the stream one call later
+  std::shared_ptr<DeviceWaveletJob> copy_job;   // streams made, copy to the host in flight, not queued yet (_begin flow)
+  bool deferred_queue = false;        // _begin is in use: a begun block joins the stream one or two calls later
+  bool async_streams_copy = false;    // set by _begin around its _prepare
   HostPipeline* pipeline = nullptr;   // worker threads, lane engines, coder tasks ('B'; made by the first block)
   std::map<u64, std::shared_ptr<DeviceWaveletJob> > jobs;
   u64 next_ticket = 1;
@@ -215,7 +223,7 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
 // streams copied into `codes` (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           PinnedBytes* codes);
+                           PinnedBytes* codes, bool async_copy = false);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
 // 112-157, 159-163) for a device-resident transformed block, in two halves so that blocks

@@ -35,7 +35,7 @@ namespace bwtc_hip {
 // the same; a block just joins the host pipeline one call later.
 
 // second part of a block whose first part is done: streams (or the host route), buffers
-static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job) {
+static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool async_copy = false) {
   if (!job.half) return 0;
   job.half = false;
   if (!job.plan_future.valid()) return 0;                 // empty block: nothing to plan or code
@@ -55,8 +55,9 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job) {
   const u8* d_run_sym = e.d_run_sym[job.run_buf];
   if (on_device) {
     if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-    int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner);
+    int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner, async_copy);
     if (rc) return rc;
+    job.copying = async_copy;
     job.codes = job.codes_owner.data();
     const auto t2 = std::chrono::steady_clock::now();
     if (!e.pipeline) e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
@@ -99,25 +100,41 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job) {
   return 0;
 }
 
-// the block that still waits for its second part, if any
-static int wavelet_finish_pending_half(BwtEngine& e) {
+// the block that still waits for its second part, if any; async_copy: its streams' copy to the
+// host is left in flight and the block becomes e.copy_job
+static int wavelet_finish_pending_half(BwtEngine& e, bool async_copy) {
   if (!e.half_job) return 0;
   std::shared_ptr<DeviceWaveletJob> jobp;
   jobp.swap(e.half_job);
-  return wavelet_finish_device_half(e, *jobp);
+  const int rc = wavelet_finish_device_half(e, *jobp, async_copy);
+  if (rc == 0 && async_copy && jobp->copying) e.copy_job = jobp;
+  return rc;
 }
 
 int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                          const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
-  // the previous block: its plan was made while the GPU transformed this one
+  // Block i-2: its packed streams were copied to the host under the transform of block i; it joins
+  // the host pipeline now.  Block i-1: its plan was made while the GPU transformed block i; its
+  // streams are made below, their copy is left in flight.  (Blocks join the stream in order.)
+  e.deferred_queue = true;                            // begun blocks join the stream later, or when they are needed
+  int rc;
+  if (e.copy_job) {
+    std::shared_ptr<DeviceWaveletJob> ready;
+    ready.swap(e.copy_job);
+    if (!ready->queued) {
+      rc = wavelet_encode_queue(e, ready->rank, e.wavelet_state, &e.wavelet_state);
+      if (rc) return rc;
+    }
+  }
   std::shared_ptr<DeviceWaveletJob> prev = e.half_job;
-  int rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);   // scan(i), then streams(i-1)
+  e.async_streams_copy = true;
+  rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);   // scan(i), then streams(i-1)
+  e.async_streams_copy = false;
   if (rc) return rc;
-  if (prev && !prev->queued) {
+  if (prev && !prev->queued && !prev->copying) {      // no copy in flight (host route, empty block): it can join at once
     rc = wavelet_encode_queue(e, prev->rank, e.wavelet_state, &e.wavelet_state);
     if (rc) return rc;
   }
-  e.deferred_queue = true;                            // *ticket joins the stream at the next _begin, or when it is needed
   return 0;
 }
 
@@ -134,6 +151,11 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
     if (e.half_job == jobp) e.half_job.reset();
     const int rc = wavelet_finish_device_half(e, job);
     if (rc) return rc;
+  }
+  if (job.copying) {                                 // its streams are on their way to the host
+    if (e.copy_job == jobp) e.copy_job.reset();
+    job.copying = false;
+    if (e.codes_wait() != hipSuccess) return -3;
   }
   job.queued = true;
   if (job.host_route) {
@@ -202,7 +224,7 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
     job.plan_future = std::async(std::launch::async, [jp, want_plan] { return want_plan && bwtc::wavelet::planStreams(jp->host_secs, &jp->plan); });
   }
   // the block prepared before this one: its streams, now that its plan has had the time of a transform
-  rc = wavelet_finish_pending_half(e);
+  rc = wavelet_finish_pending_half(e, e.async_streams_copy);
   if (rc) return rc;
   e.half_job = jobp;
   *ticket = e.next_ticket++;
@@ -219,9 +241,12 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
     // _begin defers a block's entry into the stream to the next _begin; nobody else may have
     // blocks of this context waiting (the farm's _prepare / _queue callers queue explicitly)
     if (!e.deferred_queue) return -1;                 // prepared but never given its place in a stream
-    // every block begun before this one is queued already (they are queued in order)
-    const int rc = wavelet_encode_queue(e, ticket, e.wavelet_state, &e.wavelet_state);
-    if (rc) return rc;
+    // blocks join the stream in order: the ones begun before this one first
+    for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator o = e.jobs.begin(); o != e.jobs.end() && o->first <= ticket; ++o) {
+      if (o->second->queued) continue;
+      const int rc = wavelet_encode_queue(e, o->first, e.wavelet_state, &e.wavelet_state);
+      if (rc) return rc;
+    }
   }
   HostPipeline::wait(job);
   if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
@@ -255,6 +280,7 @@ void wavelet_pipeline_release(BwtEngine& e) {
     for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
       if (!it->second->queued) (void)wavelet_encode_queue(e, it->first, e.wavelet_state, &e.wavelet_state);
   e.half_job.reset();
+  e.copy_job.reset();
   for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
     if (it->second->queued) HostPipeline::wait(*it->second);   // uncollected blocks are finished, not abandoned half way
   e.jobs.clear();

@@ -234,11 +234,12 @@ int BwtEngine::reserve_wavelet(u64 device_bytes, u64 host_bytes) {
 // packed elements.
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           PinnedBytes* codes) {
+                           PinnedBytes* codes, bool async_copy) {
   hipStream_t st = e.stream;
   const u32 nsec = (u32)plan.sections.size();
   const u32 n_groups = (u32)plan.group_type.size();
   if (nsec == 0 || nsec > 256 || first_run.size() != nsec + 1 || n_runs == 0) return -1;
+  BWTC_HIP_TRY(e.codes_wait());                       // the previous block's packed streams have left the device
   if (plan.max_elements + kWtTile >= (1ull << 32)) return -5;       // step indices are 32 bit
   BWTC_HIP_TRY(hipSetDevice(e.device));
   const u64 cap = plan.max_elements;
@@ -338,9 +339,21 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   if (words) {
     hipLaunchKernelGGL(k_wt_pack, dim3(ceil_div(words, kWtTPB)), dim3(kWtTPB), 0, st, d_compact, n_coded,
                        ptr32(o_packed));
-    BWTC_HIP_TRY(hipMemcpyAsync(codes->data(), base + o_packed, words * 4ull, hipMemcpyDeviceToHost, st));
+    if (async_copy) {
+      // the packed streams go to the host on a stream of their own, under whatever the compute
+      // stream does next (the next block's transform); e.codes_wait() before anybody reads them,
+      // and before the next block's stream kernels reuse the packed buffer
+      BWTC_HIP_TRY(e.ensure_d2h_stream());
+      BWTC_HIP_TRY(hipEventRecord(e.ev_packed, st));
+      BWTC_HIP_TRY(hipStreamWaitEvent(e.d2h_stream, e.ev_packed, 0));
+      BWTC_HIP_TRY(hipMemcpyAsync(codes->data(), base + o_packed, words * 4ull, hipMemcpyDeviceToHost, e.d2h_stream));
+      BWTC_HIP_TRY(hipEventRecord(e.ev_codes, e.d2h_stream));
+      e.codes_in_flight = true;
+    } else {
+      BWTC_HIP_TRY(hipMemcpyAsync(codes->data(), base + o_packed, words * 4ull, hipMemcpyDeviceToHost, st));
+    }
   }
-  BWTC_HIP_TRY(e.wait());
+  if (!async_copy) BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   (*coded_pos)[n_groups] = n_coded;
   for (u32 g = n_groups; g-- > 0;)
