@@ -85,29 +85,46 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_count(const u32* __restrict__ run
   cnt[r] = c;
 }
 
+// One thread per run; the step words of a workgroup's 256 runs are consecutive in the output
+// (off[] is the prefix of the step counts), so they are assembled in LDS and written by
+// consecutive lanes -- a thread storing its own four or five words would touch a cache line
+// per lane and instruction.  Workgroups whose runs expand to more than the LDS window (very long
+// codes) write directly.
+constexpr u32 kWtExpandWin = 6144;    // words of LDS staging: 24 steps per run on average
+
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
                                                       u32* __restrict__ key) {
   __shared__ u32 s_first[257];
+  __shared__ u32 s_out[kWtExpandWin];
   for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
   __syncthreads();
-  const u32 r = blockIdx.x * kWtTPB + threadIdx.x;
-  if (r >= n_runs) return;
-  const u32 s = wt_section_of(s_first, t.nsec, r);
-  const u32 c = run_sym[r];
-  const uint2 sy = t.symtab[s * 256u + c];
-  // steps at depth > (common prefix with the previous run's code) carry the gap flag
-  u32 common = 0;
-  if (r > s_first[s]) common = (u32)__clzll(t.symcode[s * 256u + c] ^ t.symcode[s * 256u + run_sym[r - 1]]);
-  u32 o = off[r];
-  const u32 ns = sy.y & 255u;
-  for (u32 i = 0; i < ns; ++i, ++o) key[o] = t.pool[sy.x + i] | ((i > common ? 1u : 0u) << kStepGapShift);
-  if (sy.y >> 16) {
-    const uint2 le = wt_length_entry(t, s, run_start[r + 1] - run_start[r]);
-    const u32 leaf = ((sy.y >> 8) & 255u) << kStepLeafShift;
-    for (u32 i = 0; i < le.y; ++i, ++o) key[o] = t.pool[le.x + i] | leaf;
+  const u32 r0 = blockIdx.x * kWtTPB;
+  const u32 r = r0 + threadIdx.x;
+  const u32 r_end = min(r0 + (u32)kWtTPB, n_runs);
+  const u32 o0 = off[r0], o1 = off[r_end];               // off[n_runs] = total
+  const bool staged = o1 - o0 <= kWtExpandWin;
+  auto put = [&](u32 o, u32 v) { if (staged) s_out[o - o0] = v; else key[o] = v; };
+  if (r < n_runs) {
+    const u32 s = wt_section_of(s_first, t.nsec, r);
+    const u32 c = run_sym[r];
+    const uint2 sy = t.symtab[s * 256u + c];
+    // steps at depth > (common prefix with the previous run's code) carry the gap flag
+    u32 common = 0;
+    if (r > s_first[s]) common = (u32)__clzll(t.symcode[s * 256u + c] ^ t.symcode[s * 256u + run_sym[r - 1]]);
+    u32 o = off[r];
+    const u32 ns = sy.y & 255u;
+    for (u32 i = 0; i < ns; ++i, ++o) put(o, t.pool[sy.x + i] | ((i > common ? 1u : 0u) << kStepGapShift));
+    if (sy.y >> 16) {
+      const uint2 le = wt_length_entry(t, s, run_start[r + 1] - run_start[r]);
+      const u32 leaf = ((sy.y >> 8) & 255u) << kStepLeafShift;
+      for (u32 i = 0; i < le.y; ++i, ++o) put(o, t.pool[le.x + i] | leaf);
+    }
   }
+  if (!staged) return;
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < o1 - o0; i += kWtTPB) key[o0 + i] = s_out[i];
 }
 
 constexpr u8 kWtSkip = 0xFF;
