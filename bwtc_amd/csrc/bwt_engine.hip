@@ -114,7 +114,7 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
                                                    K* __restrict__ keys, u32* __restrict__ idx,
-                                                   u32 n, int k, u32 sigma, K top) {
+                                                   u32 n, int k, u32 sigma, K top, u8* __restrict__ plane) {
   // A workgroup makes 1024 consecutive slots.  The dense codes of its stretch of T are staged in
   // LDS once; a thread builds four consecutive suffixes' keys -- the first from k characters, the
   // next three by rolling one character out and one in (top = sigma^(k-1)), k+3 LDS bytes instead
@@ -146,6 +146,156 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
     keys[J0 + j] = s_key[j];
     idx[J0 + j] = n - 1u - (J0 + j);
+    if (plane) plane[J0 + j] = (u8)s_key[j];         // the first radix pass's digits (radix_sort.hpp, planes)
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2g initial keys from dense g-gram codes.  A text uses few of the sigma^g possible g-grams
+//     (the 256 MiB synthetic text: 40 symbols, 2.56 M possible 4-grams, some ten thousand
+//     present), so numbering the PRESENT grams in order packs g characters into
+//     b = log2(present) bits instead of g log2(sigma): 12 characters of that text take 48 key bits
+//     = 6 radix passes instead of 64 bits = 8 passes, and the order of the keys is the same
+//     (the numbering is monotone in the gram's value, which is its characters as a base-sigma
+//     number).  Four small passes: mark the grams that occur (byte map, plain stores: every
+//     writer stores the same 1), count and number them, then make the keys with one table lookup
+//     per text position.  Grams that start in the padding are the all-zero gram, which position
+//     n-1 (the terminator and padding) marks.
+// ---------------------------------------------------------------------------------------
+constexpr u32 kGramMaxU = 1u << 22;         // largest gram universe (byte map 4 MiB, code table 16 MiB)
+constexpr u32 kGramTile = 4096;
+constexpr u32 kGramMinN = 1u << 22;         // smaller blocks keep the plain base-sigma key
+
+__global__ __launch_bounds__(256) void k_gram_mark(const u8* __restrict__ T, const u8* __restrict__ lut,
+                                                   u32 n, int g, u32 sigma, u32 top,
+                                                   u8* __restrict__ present) {
+  __shared__ u8 s_lut[256];
+  __shared__ __attribute__((aligned(16))) u8 s_code[kGramTile + 64];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  const u32 ntiles = (n + kGramTile - 1u) / kGramTile;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    const u32 base = tile * kGramTile;
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(T + base + 16u * threadIdx.x);   // T's region is padded by a tile
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+      u32 c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        c[q] = (u32)s_lut[w[q] & 255u] | (u32)s_lut[(w[q] >> 8) & 255u] << 8 |
+               (u32)s_lut[(w[q] >> 16) & 255u] << 16 | (u32)s_lut[w[q] >> 24] << 24;
+      *reinterpret_cast<uint4*>(&s_code[16u * threadIdx.x]) = make_uint4(c[0], c[1], c[2], c[3]);
+      if (threadIdx.x < 64u) s_code[kGramTile + threadIdx.x] = s_lut[T[base + kGramTile + threadIdx.x]];
+    }
+    __syncthreads();
+    const u32 o = 16u * threadIdx.x;
+    if (base + o < n) {
+      u32 v = 0;
+      for (int t = 0; t < g; ++t) v = v * sigma + s_code[o + t];
+      const u32 cnt = min(16u, n - (base + o));
+      for (u32 e = 0; e < cnt; ++e) {
+        if (!present[v]) present[v] = 1;
+        v = (v - (u32)s_code[o + e] * top) * sigma + s_code[o + e + g];
+      }
+    }
+  }
+}
+
+// present grams per 4096 values -> cnt[tile]
+__global__ __launch_bounds__(256) void k_gram_count(const u8* __restrict__ present, u32 U, u32* __restrict__ cnt) {
+  __shared__ u32 scratch[256 / kWave + 1];
+  const u32 o = blockIdx.x * kGramTile + 16u * threadIdx.x;
+  u32 c = 0;
+  if (o < U) {                                         // the map is allocated in whole tiles, zero beyond U
+    const uint4 v = *reinterpret_cast<const uint4*>(present + o);
+    c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);     // bytes are 0 or 1
+  }
+  u32 total;
+  block_scan_excl_add<256>(c, scratch, &total);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+}
+
+// exclusive scan of at most 1024 tile counts, in place; the total goes to *distinct
+__global__ __launch_bounds__(1024) void k_gram_scan(u32* __restrict__ cnt, u32 ntiles, u32* __restrict__ distinct) {
+  __shared__ u32 scratch[1024 / kWave + 1];
+  const u32 v = threadIdx.x < ntiles ? cnt[threadIdx.x] : 0u;
+  u32 total;
+  const u32 ex = block_scan_excl_add<1024>(v, scratch, &total);
+  if (threadIdx.x < ntiles) cnt[threadIdx.x] = ex;
+  if (threadIdx.x == 0) *distinct = total;
+}
+
+// code[v] = number of present grams below v (for a gram that is absent: the code of the next present one)
+__global__ __launch_bounds__(256) void k_gram_codes(const u8* __restrict__ present, u32 U,
+                                                    const u32* __restrict__ tile_off, u32* __restrict__ code) {
+  __shared__ u32 scratch[256 / kWave + 1];
+  const u32 o = blockIdx.x * kGramTile + 16u * threadIdx.x;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (o < U) v = *reinterpret_cast<const uint4*>(present + o);
+  const u32 w[4] = {v.x, v.y, v.z, v.w};
+  const u32 mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  u32 total;
+  u32 run = tile_off[blockIdx.x] + block_scan_excl_add<256>(mine, scratch, &total);
+  if (o >= U) return;
+  u32 out[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { out[e] = run; run += (w[e >> 2] >> (8 * (e & 3))) & 1u; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<uint4*>(code + o + 4 * q) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
+// keys of G grams of g characters, b bits per gram code; slots in descending suffix order as in k_make_keys
+__global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T, const u8* __restrict__ lut,
+                                                        const u32* __restrict__ gcode,
+                                                        u64* __restrict__ keys, u32* __restrict__ idx, u32 n,
+                                                        int g, int G, int b, u32 sigma, u32 top,
+                                                        u8* __restrict__ plane) {
+  constexpr u32 kTile = 1024;
+  __shared__ u8 s_lut[256];
+  __shared__ u8 s_code[kTile + 128];
+  __shared__ u32 s_g[kTile + 64];
+  __shared__ u64 s_key[kTile];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const u32 J0 = blockIdx.x * kTile;
+  if (J0 >= n) return;
+  const u32 cntw = min(kTile, n - J0);
+  const u32 i_base = n - J0 - cntw;
+  const u32 span = cntw + (u32)((G - 1) * g);        // gram starts this tile looks at (G g <= 64)
+  for (u32 t = threadIdx.x; t < span + (u32)g; t += 256u) s_code[t] = s_lut[T[i_base + t]];   // T is zero padded
+  __syncthreads();
+  {
+    // span <= 1024 + 60: at most five gram starts per thread, strided, so that the five table
+    // lookups (the kernel's only latency) are in flight together
+    u32 v[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      const u32 t = threadIdx.x + 256u * e;
+      v[e] = 0;
+      if (t < span) for (int c = 0; c < g; ++c) v[e] = v[e] * sigma + s_code[t + c];
+    }
+    u32 cd[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) cd[e] = threadIdx.x + 256u * e < span ? gcode[v[e]] : 0u;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) if (threadIdx.x + 256u * e < span) s_g[threadIdx.x + 256u * e] = cd[e];
+  }
+  __syncthreads();
+  const u32 o = 4u * threadIdx.x;
+  if (o < cntw) {
+    const u32 cnt = min(4u, cntw - o);
+    for (u32 s = 0; s < cnt; ++s) {
+      u64 key = 0;
+      for (int j = 0; j < G; ++j) key = (key << b) | (u64)s_g[o + s + (u32)(j * g)];
+      s_key[cntw - 1u - (o + s)] = key;
+    }
+  }
+  __syncthreads();
+  for (u32 j = threadIdx.x; j < cntw; j += 256u) {
+    keys[J0 + j] = s_key[j];
+    idx[J0 + j] = n - 1u - (J0 + j);
+    if (plane) plane[J0 + j] = (u8)s_key[j];
   }
 }
 
@@ -314,6 +464,7 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
 // written when somebody wants it (SA != nullptr).
 struct RrEmit {
   u8* out; u32 out_n; u32* last_char; u32* pidx; const u8* T; u8* achr_out;
+  u8* rec_plane; int rec_shift;      // MODE 2: digit (s >> rec_shift) & 255 of every record, for the window partition's first pass
 };
 
 template <typename K, bool INIT, int MODE, int EMIT>
@@ -362,6 +513,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       if (MODE == 2) {
         reinterpret_cast<u64*>(pair_s)[p] = ((u64)s << 32) | (u64)nr;
         pair_r[p] = a ? grp : 0xFFFFFFFFu;
+        if (em.rec_plane) em.rec_plane[p] = (u8)(s >> em.rec_shift);
       } else if (MODE == 1) { pair_s[p] = s; pair_r[p] = nr; }
       else rank[s] = nr;
       u32 c = 0;
@@ -707,6 +859,10 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_WINDOW_BITS") && std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")) > 0)
       window_bits = std::min(24, std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")));
     digit_planes = !(std::getenv("BWTC_HIP_PLANES") && std::getenv("BWTC_HIP_PLANES")[0] == '0');
+    if (const char* gr = std::getenv("BWTC_HIP_GRAMS")) {       // 0: base-sigma keys only; N > 0: N grams per key
+      gram_keys = gr[0] != '0';
+      gram_count_override = std::atoi(gr);
+    }
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -848,7 +1004,7 @@ static bool can_carry(u32 n) { return rank_bits(n) + bit_width_u64(n / 2 ? n / 2
 
 template <typename K>
 void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                           bool probe_it, int bit_lo, u64 n_holes) {
+                           bool probe_it, int bit_lo, u64 n_holes, bool plane_ready) {
   if (use_sweep && n_holes == 0) {
     SweepWs ws;
     ws.hist_all = d_sweep;
@@ -861,7 +1017,7 @@ void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K**
   } else {
     radix_sort_pairs<K>(k0, k1, v0, v1, n, nbits, d_table, d_partial, stream, ks, vs,
                         probe_it ? &probe : nullptr, bit_lo, false, false, n_holes,
-                        digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr);
+                        digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr, plane_ready && digit_planes);
   }
 }
 
@@ -919,13 +1075,15 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
                      AIDX, rb.aglob_next, d_GRP, PS, PR, re)
   if (dense) {
     u32* tri_key = reinterpret_cast<u32*>(recA);
-    if (emit) BWTC_APPLY(2, kEmitKind, tri_key, rb.v_free, (u32*)nullptr);
-    else BWTC_APPLY(2, 0, tri_key, rb.v_free, (u32*)nullptr);
     // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
     const int bits = bit_width_u64(n ? n - 1 : 0);
     const int lo = bits > window_bits ? bits - window_bits : 0;
+    re.rec_plane = digit_planes ? d_P0 : nullptr;
+    re.rec_shift = lo;
+    if (emit) BWTC_APPLY(2, kEmitKind, tri_key, rb.v_free, (u32*)nullptr);
+    else BWTC_APPLY(2, 0, tri_key, rb.v_free, (u32*)nullptr);
     u64* ws = nullptr; u32* wv = nullptr;
-    sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo);
+    sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo, 0, true);
     u64* ws_other = ws == recA ? recB : recA;
     u32* wv_other = wv == rb.v_free ? rb.v_keys : rb.v_free;
     const u32 grid = (ceil_div(m, kWinTile) + 7u) / 8u * 8u;
@@ -968,6 +1126,53 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   return 0;
 }
 
+// Decides whether the initial key is made of dense gram codes (K2g) and, if so, leaves the code
+// table in d_rank (free until the first ranking step; the byte map lives in d_SA).  G = 0: keep
+// the base-sigma key.  The gram length is the longest whose universe fits kGramMaxU; the key takes
+// as few grams as cover the base-sigma key's characters, and is used when that saves a radix pass.
+static constexpr int kSmallGram = 526;
+int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp) {
+  hipStream_t st = stream;
+  gp->G = 0;
+  if (!gram_keys || n < kGramMinN) return 0;
+  int g = 1;
+  u64 U = plan.sigma;
+  while (U * plan.sigma <= kGramMaxU && U * plan.sigma <= (u64)cap / 2 && g < 32) { U *= plan.sigma; ++g; }
+  if (g < 2) return 0;
+  const u32 ntiles = ceil_div((u32)U, kGramTile);          // <= 1024
+  u8* present = reinterpret_cast<u8*>(d_SA);
+  u32* code = d_rank;
+  u32 top = 1;
+  for (int t = 1; t < g; ++t) top *= plan.sigma;
+  BWTC_HIP_TRY(hipMemsetAsync(present, 0, (u64)ntiles * kGramTile, st));
+  hipLaunchKernelGGL(k_gram_mark, dim3(std::min<u32>(ceil_div(n, kGramTile), 4096u)), dim3(256), 0, st,
+                     (const u8*)d_T, d_lut, n, g, plan.sigma, top, present);
+  hipLaunchKernelGGL(k_gram_count, dim3(ntiles), dim3(256), 0, st, (const u8*)present, (u32)U, d_aggA);
+  hipLaunchKernelGGL(k_gram_scan, dim3(1), dim3(1024), 0, st, d_aggA, ntiles, d_small + kSmallGram);
+  hipLaunchKernelGGL(k_gram_codes, dim3(ntiles), dim3(256), 0, st, (const u8*)present, (u32)U,
+                     (const u32*)d_aggA, code);
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallGram, d_small + kSmallGram, 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(wait());
+  const u32 distinct = h_small[kSmallGram];
+  if (distinct == 0) return -3;
+  const int b = std::max(1, bit_width_u64(distinct - 1));
+  const int g_max = std::min(64 / b, 64 / g);                 // key bits, and the text's zero padding
+  if (g_max < 1) return 0;
+  int G = std::min(g_max, (plan.k + g - 1) / g);
+  if (gram_count_override > 0) G = std::min(g_max, gram_count_override);
+  const int passes = (b * G + kRadixBits - 1) / kRadixBits;
+  const int base_passes = (plan.bits + kRadixBits - 1) / kRadixBits;
+  // fewer passes for at least as many characters, or the same passes for more
+  const bool better = (g * G >= plan.k && passes < base_passes) || (g * G > plan.k && passes <= base_passes);
+  if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "grams: sigma=%u g=%d universe=%llu present=%u bits=%d G=%d (%d chars, %d passes) vs base %d chars, %d passes -> %s\n",
+                 plan.sigma, g, (unsigned long long)U, distinct, b, G, g * G, passes, plan.k, base_passes,
+                 better || gram_count_override > 0 ? "grams" : "base");
+  if (!better && gram_count_override <= 0) return 0;
+  gp->g = g; gp->G = G; gp->b = b; gp->top = top;
+  return 0;
+}
+
 // em != nullptr: the rankers emit the transform's bytes (see RrEmit) and the suffix array itself
 // is not stored; em == nullptr: d_SA is filled and nothing is emitted.
 int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const EmitTarget* em) {
@@ -983,10 +1188,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   std::memcpy(h_small + kSmallLut, plan.lut, 256);
   BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallLut, h_small + kSmallLut, 256, hipMemcpyHostToDevice, st));
   const u8* d_lut = reinterpret_cast<const u8*>(d_small + kSmallLut);
-  const int key_bits = plan.bits;
+  int key_bits = plan.bits;
   // suffixes of length <= k are finished by the initial ranking (a suffix of length exactly
   // k is a proper prefix of every other suffix with the same key)
-  const u32 short_len = (u32)plan.k;
+  u32 short_len = (u32)plan.k;
 
   RrEmit re;
   re.out = emit ? em->out : nullptr;
@@ -995,6 +1200,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   re.pidx = d_small + kSmallPidx;
   re.T = d_T;
   re.achr_out = d_C0;
+  re.rec_plane = nullptr;
+  re.rec_shift = 0;
   u8* achr_other = d_C1;
 
   RankBuffers rb;
@@ -1006,16 +1213,28 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 
   // initial sort + ranking
   BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-  int rc;
+  int rc = 0;
+  u8* key_plane = digit_planes && !use_sweep ? d_P0 : nullptr;     // the key makers leave the first pass's digits
   if (plan.wide) {
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
-    u64 top = 1;
-    for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
-    hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.sigma, top);
+    GramPlan gp;
+    rc = plan_grams(plan, n, d_lut, &gp);
+    if (rc) return rc;
+    if (gp.G > 0) {
+      key_bits = gp.b * gp.G;
+      short_len = (u32)(gp.g * gp.G);
+      h = (u64)short_len;
+      hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
+                         (const u32*)d_rank, ka, d_V0, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
+    } else {
+      u64 top = 1;
+      for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
+      hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
+                         d_V0, n, plan.k, plan.sigma, top, key_plane);
+    }
     u64* ks = nullptr; u32* vs = nullptr;
-    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
+    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
     rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
@@ -1026,9 +1245,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     u32 top = 1;
     for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
     hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.sigma, top);
+                       d_V0, n, plan.k, plan.sigma, top, key_plane);
     u32* ks = nullptr; u32* vs = nullptr;
-    sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true);
+    sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     rb.rec_keys = d_R1; rb.rec_free = d_R2;             // both 32-bit key arrays live in R1
     rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;

@@ -78,6 +78,7 @@ struct DeviceWaveletJob : WaveletJob {
   unsigned host_threads = 0;
 };
 
+struct KeyPlan;
 struct BwtEngine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -181,7 +182,7 @@ struct BwtEngine {
   // radix sort front door: picks the chained single-read passes or the classic ones
   template <typename K>
   void sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                  bool probe_it, int bit_lo = 0, u64 n_holes = 0);
+                  bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false);
   // one ranking step of the suffix sorter (bwt_engine.hip)
   struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
   struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; };
@@ -191,6 +192,10 @@ struct BwtEngine {
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
+  bool gram_keys = true;     // BWTC_HIP_GRAMS=0: initial keys are always base-sigma numbers (no dense gram codes)
+  int gram_count_override = 0;
+  struct GramPlan { int g = 0, G = 0, b = 0; u32 top = 0; };
+  int plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp);
   bool no_emit = false;      // BWTC_HIP_NO_EMIT: suffix array + gather even for blocks that could carry
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);

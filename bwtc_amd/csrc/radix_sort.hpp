@@ -277,12 +277,14 @@ struct ScatterProbe {
 // not exist; the first pass drops them (at least one pass is then made, even for nbits == 0).
 // plane0 / plane1 (optional, n bytes each, 16-byte aligned): digit planes; every pass but the
 // last leaves the next pass's digits there and the next histogram is taken from them.
+// plane0_ready: the producer of the keys already left the first pass's digits in plane0.
 template <typename K>
 static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
                                     K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
                                     int bit_lo = 0, bool values_are_positions = false, bool keys_only = false,
-                                    u64 n_holes = 0, u8* plane0 = nullptr, u8* plane1 = nullptr) {
+                                    u64 n_holes = 0, u8* plane0 = nullptr, u8* plane1 = nullptr,
+                                    bool plane0_ready = false) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1 || n_holes) {
@@ -293,7 +295,7 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       const u32 ntiles = ceil_div(n_in, radix_tile<K>());
       const int vmode = keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0;
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
-      const bool have_plane = plane0 && !first;                             // the previous pass left this pass's digits
+      const bool have_plane = plane0 && (!first || (plane0_ready && !skip));   // the previous pass (or the producer) left this pass's digits
       const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's
       if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles);
       else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);

@@ -95,7 +95,7 @@ constexpr u32 kWtExpandWin = 6144;    // words of LDS staging: 24 steps per run 
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
-                                                      u32* __restrict__ key) {
+                                                      u32* __restrict__ key, u8* __restrict__ plane) {
   __shared__ u32 s_first[257];
   __shared__ u32 s_out[kWtExpandWin];
   for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   const u32 r_end = min(r0 + (u32)kWtTPB, n_runs);
   const u32 o0 = off[r0], o1 = off[r_end];               // off[n_runs] = total
   const bool staged = o1 - o0 <= kWtExpandWin;
-  auto put = [&](u32 o, u32 v) { if (staged) s_out[o - o0] = v; else key[o] = v; };
+  // plane: the sort's first digit of every step word (radix_sort.hpp, digit planes)
+  auto put = [&](u32 o, u32 v) { if (staged) s_out[o - o0] = v; else { key[o] = v; plane[o] = (u8)(v >> kStepLeafShift); } };
   if (r < n_runs) {
     const u32 s = wt_section_of(s_first, t.nsec, r);
     const u32 c = run_sym[r];
@@ -124,7 +125,11 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   }
   if (!staged) return;
   __syncthreads();
-  for (u32 i = threadIdx.x; i < o1 - o0; i += kWtTPB) key[o0 + i] = s_out[i];
+  for (u32 i = threadIdx.x; i < o1 - o0; i += kWtTPB) {
+    const u32 v = s_out[i];
+    key[o0 + i] = v;
+    plane[o0 + i] = (u8)(v >> kStepLeafShift);
+  }
 }
 
 constexpr u8 kWtSkip = 0xFF;
@@ -327,11 +332,12 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 n = e.h_small[0];
   if (n == 0 || (u64)n > cap) return -3;
   hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_start,
-                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0));
+                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), base + o_code);
   // sort by (group, leaf rank), keys only; the bit and the gap flag ride along in the word
   u32* ks = nullptr; u32* vs = nullptr;
   radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), nullptr, nullptr, n, key_bits,
-                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, false, true);
+                        ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, false, true,
+                        0, base + o_code, base + o_compact, true);     // planes: both byte arrays are free until the select kernel
   // select + compact + pack
   u32* d_gstart = ptr32(o_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_gstart, 0xFF, (n_groups + 1) * 4ull, st));
