@@ -193,10 +193,17 @@ __global__ __launch_bounds__(256) void k_gram_mark(const u8* __restrict__ T, con
       u32 v = 0;
       for (int t = 0; t < g; ++t) v = v * sigma + s_code[o + t];
       const u32 cnt = min(16u, n - (base + o));
-      for (u32 e = 0; e < cnt; ++e) {
-        if (!present[v]) present[v] = 1;
+      u32 vs[16];
+      u8 seen[16];
+#pragma unroll
+      for (u32 e = 0; e < 16u; ++e) {
+        vs[e] = e < cnt ? v : 0u;
         v = (v - (u32)s_code[o + e] * top) * sigma + s_code[o + e + g];
       }
+#pragma unroll
+      for (u32 e = 0; e < 16u; ++e) seen[e] = present[vs[e]];     // sixteen independent lookups, then the few stores
+#pragma unroll
+      for (u32 e = 0; e < 16u; ++e) if (e < cnt && !seen[e]) present[vs[e]] = 1;
     }
   }
 }

@@ -62,6 +62,35 @@ __device__ __forceinline__ u64 match_any(u32 d, bool valid) {
   return m;
 }
 
+// For every valid lane: how many LOWER lanes of the wave hold the same (valid) digit, and how many
+// lanes hold it in all -- match_any() + two popcounts, written for the instruction count: the
+// ranking loops of the radix passes are bound by VALU issue (rocprofv3: SQ_ACTIVE_INST_VALU 0.99
+// of the busy cycles for 32-bit keys), not by memory.  Per digit bit: the bit as 0 / -1 (one
+// v_bfe_i32), its ballot, and per 32-lane half one xor that leaves the lanes whose bit differs;
+// those are OR-ed up as "not a peer".  The rank is then v_mbcnt of the peer mask (no lane mask, no
+// 64-bit shift) and the highest peer is the lane with rank + 1 == count.
+template <int BITS>
+__device__ __forceinline__ void wave_digit_rank(u32 d, bool valid, u32* rank, u32* count) {
+  const u64 vb = __ballot(valid);
+  u32 nlo = ~(u32)vb, nhi = ~(u32)(vb >> 32);
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const u32 x = (u32)__builtin_amdgcn_sbfe((int)d, (u32)b, 1u);
+    const u64 bal = __ballot(x != 0u);
+    nlo |= (u32)bal ^ x;
+    nhi |= (u32)(bal >> 32) ^ x;
+  }
+  const u32 mlo = ~nlo, mhi = ~nhi;
+  *rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+  *count = (u32)__popc(mlo) + (u32)__popc(mhi);
+}
+
+// LDS words that a wave reads and rewrites in lockstep (the per-wave digit counters): volatile, and
+// typed as LDS so that the accesses are ds_read / ds_write (a volatile generic pointer compiles to
+// system-scope FLAT loads and stores, which go through the vector memory path).
+typedef __attribute__((address_space(3))) u32 lds_u32;
+__device__ __forceinline__ volatile lds_u32* lds_volatile(u32* p) { return (volatile lds_u32*)p; }
+
 // Block-wide exclusive sum for TPB threads (TPB multiple of 64, <= 1024).
 // `scratch` needs TPB/64 + 1 words of LDS.  Returns the exclusive prefix of v; *total gets
 // the block total.  Contains two barriers; every thread of the block must call it.

@@ -68,19 +68,19 @@ __global__ __launch_bounds__(kInvTPB) void k_inv_lf(const u8* __restrict__ bwt, 
   const u32 wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const u32 wrow = blockIdx.x * kInvTile + wave * (kWave * kInvE) + lane;
   u32 c[kInvE], r[kInvE];
-  volatile u32* my_cnt = &s_cnt[wave][0];
-  const u64 lt_mask = (1ull << lane) - 1ull;
+  volatile lds_u32* my_cnt = lds_volatile(&s_cnt[wave][0]);
 #pragma unroll
   for (int e = 0; e < kInvE; ++e) {
     const u32 row = wrow + e * kWave;
     const bool ok = row < n && row != eob;
     c[e] = row < n ? inv_L(bwt, size, eob, row) : 0u;
-    const u64 m = match_any<8>(c[e], ok);
+    u32 below, peers;
+    wave_digit_rank<8>(c[e], ok, &below, &peers);
     u32 prev = 0;
     if (ok) prev = my_cnt[c[e]];
     __builtin_amdgcn_wave_barrier();
-    r[e] = prev + (u32)__popcll(m & lt_mask);
-    if (ok && (m >> lane) == 1ull) my_cnt[c[e]] = prev + (u32)__popcll(m);
+    r[e] = prev + below;
+    if (ok && below + 1u == peers) my_cnt[c[e]] = prev + peers;
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();

@@ -136,19 +136,19 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   }
   __syncthreads();
 
-  volatile u32* my_cnt = &s_cnt[wave][0];
-  const u64 lt_mask = (1ull << lane) - 1ull;
+  volatile lds_u32* my_cnt = lds_volatile(&s_cnt[wave][0]);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const bool ok = BWTC_EXISTS(e);
     const u32 d = radix_digit(k[e], shift);
-    const u64 m = match_any<kRadixBits>(d, ok);
+    u32 below, peers;
+    wave_digit_rank<kRadixBits>(d, ok, &below, &peers);
     u32 prev = 0;
     if (ok) prev = my_cnt[d];
     __builtin_amdgcn_wave_barrier();
-    r[e] = prev + (u32)__popcll(m & lt_mask);
+    r[e] = prev + below;
     // the highest lane of each group publishes the new count
-    if (ok && (m >> lane) == 1ull) my_cnt[d] = prev + (u32)__popcll(m);
+    if (ok && below + 1u == peers) my_cnt[d] = prev + peers;
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
@@ -460,18 +460,18 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_sweep(
     v[e] = ok ? vin[tile_base + slot] : 0u;
   }
 
-  volatile u32* my_cnt = &s_cnt[wave][0];
-  const u64 lt_mask = (1ull << lane) - 1ull;
+  volatile lds_u32* my_cnt = lds_volatile(&s_cnt[wave][0]);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const bool ok = (wslot + e * kWave) < tile_n;
     const u32 d = radix_digit(k[e], shift);
-    const u64 m = match_any<kRadixBits>(d, ok);
+    u32 below, peers;
+    wave_digit_rank<kRadixBits>(d, ok, &below, &peers);
     u32 prev = 0;
     if (ok) prev = my_cnt[d];
     __builtin_amdgcn_wave_barrier();
-    r[e] = prev + (u32)__popcll(m & lt_mask);
-    if (ok && (m >> lane) == 1ull) my_cnt[d] = prev + (u32)__popcll(m);
+    r[e] = prev + below;
+    if (ok && below + 1u == peers) my_cnt[d] = prev + peers;
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();

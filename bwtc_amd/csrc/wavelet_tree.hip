@@ -60,6 +60,18 @@ __device__ __forceinline__ u32 wt_section_of(const u32* s_first, u32 nsec, u32 r
   return lo;
 }
 
+// The section of a workgroup's first run, searched with uniform (scalar) loads from the table in
+// global memory; *uniform = all `cnt` runs from r0 on lie in that section (nearly always: a block
+// has some eighty sections and a hundred million runs), so that the lanes need no search of their own.
+__device__ __forceinline__ u32 wt_section_uniform(const u32* __restrict__ first_run, u32 nsec, u32 r0,
+                                                  u32 cnt, bool* uniform, u32* sec_first) {
+  u32 lo = 0, hi = nsec;
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (first_run[mid] <= r0) lo = mid; else hi = mid; }
+  *uniform = r0 + cnt <= first_run[lo + 1];
+  *sec_first = first_run[lo];
+  return lo;
+}
+
 __device__ __forceinline__ uint2 wt_length_entry(const WtTables& t, u32 s, u32 len) {
   if (len < kWtLenDense) return t.lendense[(u64)s * kWtLenDense + len];
   u32 lo = t.over_first[s], hi = t.over_first[s + 1];
@@ -68,67 +80,132 @@ __device__ __forceinline__ uint2 wt_length_entry(const WtTables& t, u32 s, u32 l
   return make_uint2(e.y, e.z);
 }
 
-// steps per run -> cnt[r]; cnt[n_runs] = 0 so that the exclusive scan leaves the total there
+// steps per run -> cnt[r]; cnt[n_runs] = 0 so that the exclusive scan leaves the total there.
+// Four runs per thread, and the table lookups unconditional, so that a thread has its eight
+// dependent lookups in flight together (one run per thread was a chain of three latencies).
+constexpr int kWtCountE = 4;
+
 __global__ __launch_bounds__(kWtTPB) void k_wt_count(const u32* __restrict__ run_start,
                                                      const u8* __restrict__ run_sym, u32 n_runs,
                                                      WtTables t, u32* __restrict__ cnt) {
   __shared__ u32 s_first[257];
-  for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
-  __syncthreads();
-  const u32 r = blockIdx.x * kWtTPB + threadIdx.x;
-  if (r > n_runs) return;
-  if (r == n_runs) { cnt[r] = 0; return; }
-  const u32 s = wt_section_of(s_first, t.nsec, r);
-  const uint2 sy = t.symtab[s * 256u + run_sym[r]];
-  u32 c = sy.y & 255u;
-  if (sy.y >> 16) c += wt_length_entry(t, s, run_start[r + 1] - run_start[r]).y;
-  cnt[r] = c;
+  const u32 r0 = blockIdx.x * (kWtTPB * kWtCountE);
+  const u32 rs = min(r0, n_runs - 1u);                     // the last workgroup may hold only slot n_runs
+  bool uniform; u32 sec_first;
+  const u32 sA = wt_section_uniform(t.first_run, t.nsec, rs, min((u32)(kWtTPB * kWtCountE), n_runs - rs), &uniform, &sec_first);
+  if (!uniform) {                                          // a section border inside the workgroup (same for all its threads)
+    for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
+    __syncthreads();
+  }
+  u32 sec[kWtCountE], len[kWtCountE];
+  uint2 sy[kWtCountE], led[kWtCountE];
+#pragma unroll
+  for (int u = 0; u < kWtCountE; ++u) {
+    const u32 r = min(r0 + (u32)u * kWtTPB + threadIdx.x, n_runs - 1u);
+    sec[u] = uniform ? sA : wt_section_of(s_first, t.nsec, r);
+    len[u] = run_start[r + 1] - run_start[r];
+    sy[u] = t.symtab[sec[u] * 256u + run_sym[r]];
+    led[u] = t.lendense[(u64)sec[u] * kWtLenDense + min(len[u], kWtLenDense - 1u)];
+  }
+#pragma unroll
+  for (int u = 0; u < kWtCountE; ++u) {
+    const u32 r = r0 + (u32)u * kWtTPB + threadIdx.x;
+    if (r > n_runs) continue;
+    u32 c = 0;
+    if (r < n_runs) {
+      c = sy[u].y & 255u;
+      if (sy[u].y >> 16) c += len[u] < kWtLenDense ? led[u].y : wt_length_entry(t, sec[u], len[u]).y;
+    }
+    cnt[r] = c;
+  }
 }
 
-// One thread per run; the step words of a workgroup's 256 runs are consecutive in the output
-// (off[] is the prefix of the step counts), so they are assembled in LDS and written by
-// consecutive lanes -- a thread storing its own four or five words would touch a cache line
-// per lane and instruction.  Workgroups whose runs expand to more than the LDS window (very long
-// codes) write directly.
-constexpr u32 kWtExpandWin = 6144;    // words of LDS staging: 24 steps per run on average
+// Two phases per workgroup of 256 runs.  One thread per RUN looks the run up (symbol entry, gap
+// prefix, length entry), parks what its steps need in LDS and writes its number into the owner
+// byte of each of its steps; then one thread per STEP of the workgroup's consecutive stretch of
+// output (off[] is the prefix of the step counts) fetches its word from the pool, so the lookups
+// of all steps are independent and consecutive lanes store consecutive words.  (A thread walking
+// its own run's steps ran the pool lookups one after the other, as many as the longest code in its
+// wave, and stored a word per lane and cache line.)  Stretches longer than the owner window (very
+// long codes) find the run by a search over the 257 offsets instead.  `plane` receives the sort's
+// first digit of every step word (radix_sort.hpp, digit planes).
+constexpr u32 kWtOwnerWin = 8192;     // 32 steps per run on average
 
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
                                                       u32* __restrict__ key, u8* __restrict__ plane) {
   __shared__ u32 s_first[257];
-  __shared__ u32 s_out[kWtExpandWin];
-  for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
-  __syncthreads();
+  __shared__ u32 s_off[kWtTPB + 1];
+  __shared__ u32 s_sym[kWtTPB];        // pool offset of the run's symbol steps
+  __shared__ u32 s_len[kWtTPB];        // pool offset of its length steps
+  __shared__ u32 s_meta[kWtTPB];       // symbol steps | common prefix << 8 | leaf rank << 16
+  __shared__ u8 s_owner[kWtOwnerWin];
   const u32 r0 = blockIdx.x * kWtTPB;
   const u32 r = r0 + threadIdx.x;
-  const u32 r_end = min(r0 + (u32)kWtTPB, n_runs);
-  const u32 o0 = off[r0], o1 = off[r_end];               // off[n_runs] = total
-  const bool staged = o1 - o0 <= kWtExpandWin;
-  // plane: the sort's first digit of every step word (radix_sort.hpp, digit planes)
-  auto put = [&](u32 o, u32 v) { if (staged) s_out[o - o0] = v; else { key[o] = v; plane[o] = (u8)(v >> kStepLeafShift); } };
+  const u32 cnt = min((u32)kWtTPB, n_runs - r0);
+  bool uniform; u32 sec_first;
+  u32 s = wt_section_uniform(t.first_run, t.nsec, r0, cnt, &uniform, &sec_first);
+  if (!uniform)
+    for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
+  s_off[threadIdx.x] = off[min(r, n_runs)];                 // off[n_runs] = total
+  if (threadIdx.x == 0) s_off[kWtTPB] = off[min(r0 + (u32)kWtTPB, n_runs)];
+  __syncthreads();
+  const u32 o0 = s_off[0], o1 = s_off[cnt];
+  const bool owned = o1 - o0 <= kWtOwnerWin;
   if (r < n_runs) {
-    const u32 s = wt_section_of(s_first, t.nsec, r);
+    if (!uniform) { s = wt_section_of(s_first, t.nsec, r); sec_first = s_first[s]; }
+    // every lookup unconditional, so that they are in flight together
     const u32 c = run_sym[r];
+    const u32 cp = run_sym[r ? r - 1u : 0u];
+    const u32 len = run_start[r + 1] - run_start[r];
     const uint2 sy = t.symtab[s * 256u + c];
+    const u64 code_c = t.symcode[s * 256u + c], code_p = t.symcode[s * 256u + cp];
+    const uint2 led = t.lendense[(u64)s * kWtLenDense + min(len, kWtLenDense - 1u)];
     // steps at depth > (common prefix with the previous run's code) carry the gap flag
-    u32 common = 0;
-    if (r > s_first[s]) common = (u32)__clzll(t.symcode[s * 256u + c] ^ t.symcode[s * 256u + run_sym[r - 1]]);
-    u32 o = off[r];
-    const u32 ns = sy.y & 255u;
-    for (u32 i = 0; i < ns; ++i, ++o) put(o, t.pool[sy.x + i] | ((i > common ? 1u : 0u) << kStepGapShift));
-    if (sy.y >> 16) {
-      const uint2 le = wt_length_entry(t, s, run_start[r + 1] - run_start[r]);
-      const u32 leaf = ((sy.y >> 8) & 255u) << kStepLeafShift;
-      for (u32 i = 0; i < le.y; ++i, ++o) put(o, t.pool[le.x + i] | leaf);
+    const u32 common = r > sec_first ? (u32)__clzll(code_c ^ code_p) : 0u;
+    u32 len_off = 0;
+    if (sy.y >> 16) len_off = len < kWtLenDense ? led.x : wt_length_entry(t, s, len).x;
+    s_sym[threadIdx.x] = sy.x;
+    s_len[threadIdx.x] = len_off;
+    s_meta[threadIdx.x] = (sy.y & 255u) | (min(common, 64u) << 8) | (((sy.y >> 8) & 255u) << 16);
+    if (owned) {
+      const u32 b = s_off[threadIdx.x] - o0, e = s_off[threadIdx.x + 1] - o0;
+      for (u32 i = b; i < e; ++i) s_owner[i] = (u8)threadIdx.x;
     }
   }
-  if (!staged) return;
   __syncthreads();
-  for (u32 i = threadIdx.x; i < o1 - o0; i += kWtTPB) {
-    const u32 v = s_out[i];
-    key[o0 + i] = v;
-    plane[o0 + i] = (u8)(v >> kStepLeafShift);
+  // four steps per thread and round, every pool lookup of the round in flight before the first is used
+  constexpr int kU = 4;
+  for (u32 jb = o0 + threadIdx.x; jb < o1; jb += kWtTPB * kU) {
+    u32 addr[kU], extra[kU], w[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const u32 j = jb + (u32)u * kWtTPB;
+      addr[u] = 0; extra[u] = 0;
+      if (j < o1) {
+        u32 lo;
+        if (owned) lo = s_owner[j - o0];
+        else {                                              // the last run whose first step is <= j owns j
+          lo = 0;
+          u32 hi = cnt;
+          while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= j) lo = mid; else hi = mid; }
+        }
+        const u32 i = j - s_off[lo];
+        const u32 meta = s_meta[lo];
+        const u32 ns = meta & 255u;
+        const bool sym = i < ns;
+        addr[u] = (sym ? s_sym[lo] : s_len[lo] - ns) + i;
+        extra[u] = sym ? (i > ((meta >> 8) & 255u) ? 1u : 0u) << kStepGapShift : (meta >> 16) << kStepLeafShift;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) w[u] = t.pool[addr[u]] | extra[u];       // past the end: pool[0], not stored
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const u32 j = jb + (u32)u * kWtTPB;
+      if (j < o1) { key[j] = w[u]; plane[j] = (u8)(w[u] >> kStepLeafShift); }
+    }
   }
 }
 
@@ -143,41 +220,55 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
                                                       u32* __restrict__ group_start) {
   __shared__ u32 scratch[kWtTPB / kWave + 1];
   const u32 base = blockIdx.x * kWtTile;
-  u32 coded = 0;
+  // all loads first: sixteen independent pairs in flight per thread instead of one at a time
+  u32 k[kWtE], kp[kWtE];
+#pragma unroll
   for (int e = 0; e < kWtE; ++e) {
     const u32 j = base + e * kWtTPB + threadIdx.x;
-    if (j >= n) break;
-    const u32 k = key[j];
-    const u32 g = (k >> kStepGroupShift) & kStepGroupMask;
-    const u32 kp = j ? key[j - 1] : 0u;
-    const bool first = j == 0 || ((kp >> kStepGroupShift) & kStepGroupMask) != g;
-    if (first) group_start[g] = j;
-    const u32 bit = k & 1u;
-    const u8 type = group_type[g];
-    u8 c;
-    if (type == bwtc::wavelet::kRoot || type == bwtc::wavelet::kInteger) {
-      c = (u8)bit;
-    } else {
-      const u32 gap = (k >> kStepGapShift) & 1u;
-      const u32 prev = first ? (bit ^ 1u) : (kp & 1u);
-      bool keep = true;
-      if (type == bwtc::wavelet::kBothLeaves) keep = gap != 0;
-      else if (type == bwtc::wavelet::kLeftLeaf) keep = (prev | gap) != 0;
-      c = keep ? (u8)(bit | (gap << 1)) : kWtSkip;
+    k[e] = j < n ? key[j] : 0u;
+    kp[e] = (j < n && j) ? key[j - 1] : 0u;
+  }
+  u8 type[kWtE];
+#pragma unroll
+  for (int e = 0; e < kWtE; ++e) type[e] = group_type[(k[e] >> kStepGroupShift) & kStepGroupMask];   // k = 0 past the end: group 0 exists
+  u32 coded = 0;
+#pragma unroll
+  for (int e = 0; e < kWtE; ++e) {
+    const u32 j = base + e * kWtTPB + threadIdx.x;
+    if (j < n) {
+      const u32 g = (k[e] >> kStepGroupShift) & kStepGroupMask;
+      const bool first = j == 0 || ((kp[e] >> kStepGroupShift) & kStepGroupMask) != g;
+      if (first) group_start[g] = j;
+      const u32 bit = k[e] & 1u;
+      u8 c;
+      if (type[e] == bwtc::wavelet::kRoot || type[e] == bwtc::wavelet::kInteger) {
+        c = (u8)bit;
+      } else {
+        const u32 gap = (k[e] >> kStepGapShift) & 1u;
+        const u32 prev = first ? (bit ^ 1u) : (kp[e] & 1u);
+        bool keep = true;
+        if (type[e] == bwtc::wavelet::kBothLeaves) keep = gap != 0;
+        else if (type[e] == bwtc::wavelet::kLeftLeaf) keep = (prev | gap) != 0;
+        c = keep ? (u8)(bit | (gap << 1)) : kWtSkip;
+      }
+      code[j] = c;
+      coded += c != kWtSkip;
     }
-    code[j] = c;
-    coded += c != kWtSkip;
   }
   u32 total;
   block_scan_excl_add<kWtTPB>(coded, scratch, &total);
   if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
 }
 
-// keeps the coded elements, in order, one byte each
-__global__ __launch_bounds__(kWtTPB) void k_wt_compact(const u8* __restrict__ code, u32 n,
-                                                       const u32* __restrict__ tile_off,
-                                                       u8* __restrict__ out) {
+// Keeps the coded elements, in order, and packs them: element i of the block's coded sequence in
+// bits 2(i % 16).. of word i / 16.  A tile's survivors are gathered in LDS and the words they fill
+// are assembled from there; the words a tile shares with its neighbours (its first and last) are
+// OR-ed into the zeroed output, the others stored.
+__global__ __launch_bounds__(kWtTPB) void k_wt_compact_pack(const u8* __restrict__ code, u32 n,
+                                                            const u32* __restrict__ tile_off,
+                                                            u32* __restrict__ packed) {
   __shared__ u32 scratch[kWtTPB / kWave + 1];
+  __shared__ u8 s_val[kWtTile];
   const u32 base = blockIdx.x * kWtTile + threadIdx.x * kWtE;
   u8 c[kWtE];
   u32 mine = 0;
@@ -193,27 +284,23 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_compact(const u8* __restrict__ co
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) mine += c[e] != kWtSkip;
   u32 total;
-  u32 o = tile_off[blockIdx.x] + block_scan_excl_add<kWtTPB>(mine, scratch, &total);
+  u32 o = block_scan_excl_add<kWtTPB>(mine, scratch, &total);
 #pragma unroll
-  for (int e = 0; e < kWtE; ++e) if (c[e] != kWtSkip) out[o++] = c[e];
-}
-
-// 16 coded elements -> one 32-bit word, 2 bits each, element i in bits 2i..2i+1
-__global__ __launch_bounds__(kWtTPB) void k_wt_pack(const u8* __restrict__ in, u32 n,
-                                                    u32* __restrict__ out) {
-  const u32 w = blockIdx.x * kWtTPB + threadIdx.x;
-  const u32 base = w * 16u;
-  if (base >= n) return;
-  u32 word = 0;
-  if (base + 16u <= n) {
-    const uint4 v = *reinterpret_cast<const uint4*>(in + base);
-    const u32 q[4] = {v.x, v.y, v.z, v.w};
+  for (int e = 0; e < kWtE; ++e) if (c[e] != kWtSkip) s_val[o++] = c[e];
+  __syncthreads();
+  if (total == 0) return;
+  const u32 G = tile_off[blockIdx.x];                   // coded elements before the tile
+  const u32 w0 = G >> 4, w1 = (G + total - 1u) >> 4;
+  for (u32 w = w0 + threadIdx.x; w <= w1; w += kWtTPB) {
+    u32 word = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) word |= ((q[e >> 2] >> (8 * (e & 3))) & 3u) << (2 * e);
-  } else {
-    for (u32 e = 0; base + e < n; ++e) word |= (u32)(in[base + e] & 3u) << (2 * e);
+    for (int e = 0; e < 16; ++e) {
+      const u32 i = (w << 4) + (u32)e - G;              // wraps below zero for elements of the previous tile
+      if (i < total) word |= (u32)(s_val[i] & 3u) << (2 * e);
+    }
+    if (w == w0 || w == w1) atomicOr(&packed[w], word);
+    else packed[w] = word;
   }
-  out[w] = word;
 }
 
 // coded elements before the first element of every group
@@ -324,7 +411,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
 
   // expand
   u32* d_cnt = ptr32(o_cnt);
-  hipLaunchKernelGGL(k_wt_count, dim3(ceil_div((u64)n_runs + 1, kWtTPB)), dim3(kWtTPB), 0, st,
+  hipLaunchKernelGGL(k_wt_count, dim3(ceil_div((u64)n_runs + 1, kWtTPB * kWtCountE)), dim3(kWtTPB), 0, st,
                      d_run_start, d_run_sym, n_runs, t, d_cnt);
   exclusive_scan_u32(d_cnt, (u64)n_runs + 1, ptr32(o_cnt_partial), st);
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_cnt + n_runs, 4, hipMemcpyDeviceToHost, st));
@@ -349,8 +436,8 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
   hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB)), dim3(kWtTPB), 0, st, d_gstart,
                      n_groups, n, d_code, d_tile, ptr32(o_gpos));
-  u8* d_compact = base + o_compact;
-  hipLaunchKernelGGL(k_wt_compact, dim3(tiles), dim3(kWtTPB), 0, st, d_code, n, d_tile, d_compact);
+  BWTC_HIP_TRY(hipMemsetAsync(base + o_packed, 0, ((u64)ceil_div(n, 16) + 1) * 4ull, st));
+  hipLaunchKernelGGL(k_wt_compact_pack, dim3(tiles), dim3(kWtTPB), 0, st, d_code, n, d_tile, ptr32(o_packed));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_tile + tiles, 4, hipMemcpyDeviceToHost, st));
   coded_pos->assign((size_t)n_groups + 1, 0);
   BWTC_HIP_TRY(hipMemcpyAsync(coded_pos->data(), ptr32(o_gpos), n_groups * 4ull, hipMemcpyDeviceToHost, st));
@@ -360,8 +447,6 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 words = ceil_div(n_coded, 16);
   if (!codes->reserve(words * 4ull + 16)) return -2;
   if (words) {
-    hipLaunchKernelGGL(k_wt_pack, dim3(ceil_div(words, kWtTPB)), dim3(kWtTPB), 0, st, d_compact, n_coded,
-                       ptr32(o_packed));
     if (async_copy) {
       // the packed streams go to the host on a stream of their own, under whatever the compute
       // stream does next (the next block's transform); e.codes_wait() before anybody reads them,

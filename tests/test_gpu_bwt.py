@@ -142,6 +142,33 @@ def test_degenerate_blocks(hip_ctx, oracle):
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
 
 
+def test_gram_coded_initial_keys_vs_oracle(oracle):
+    """Blocks of 4 Mi suffixes and more make their initial sort key from dense gram codes when that
+    saves radix passes (bwt_engine.hip, K2g).  Alphabets and shapes that steer the plan differently
+    -- text, text with zero bytes (the terminator then has a code of its own), a sparse two-symbol
+    block (22-character grams), a skewed 200-symbol alphabet (2-character grams), a noisy period,
+    a block ending in a run of its smallest symbol -- all against the reference's sorter."""
+    from bwtc_amd import hip
+    size = 5 << 20
+    rng = np.random.default_rng(2024)
+    text = synth.gen_text(size, 11)
+    with_zeros = text.copy()
+    with_zeros[with_zeros == 32] = 0
+    sparse = (rng.random(size) < 0.03).astype(np.uint8) * 7
+    zipf = np.minimum(rng.zipf(1.3, size), 200).astype(np.uint8)
+    period = np.tile(np.frombuffer(b"abracad", np.uint8), size // 7 + 1)[:size].copy()
+    period[rng.integers(0, size, 200)] = 122
+    tail = text.copy()
+    tail[-100:] = text.min()
+    blocks = [("text", text), ("with_zeros", with_zeros), ("sparse", sparse), ("zipf", zipf),
+              ("period", period), ("tail", tail)]
+    with hip.Context(0, size) as ctx:
+        for name, d in blocks:
+            a = ctx.bwt_block(d, 5)
+            b = oracle.oracle_bwt_block(d, 5)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), name
+
+
 def test_full_size_text_roundtrip(hip_ctx, oracle):
     # 64 MiB text block: too big for the oracle's sorter, so check the size-independent
     # properties: the inverse transform reproduces the input (and every LF power lies on the
