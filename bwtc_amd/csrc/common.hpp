@@ -75,10 +75,11 @@ __device__ __forceinline__ void wave_digit_rank(u32 d, bool valid, u32* rank, u3
   u32 nlo = ~(u32)vb, nhi = ~(u32)(vb >> 32);
 #pragma unroll
   for (int b = 0; b < BITS; ++b) {
-    const u32 x = (u32)__builtin_amdgcn_sbfe((int)d, (u32)b, 1u);
+    u32 x;                                // bit b of d as 0 / -1; spelled out, or the compiler makes a shift pair of it
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(x) : "v"(d), "n"(b));
     const u64 bal = __ballot(x != 0u);
-    nlo |= (u32)bal ^ x;
-    nhi |= (u32)(bal >> 32) ^ x;
+    nlo = __builtin_amdgcn_bitop3_b32(nlo, (u32)bal, x, 0xF6);           // nlo | (bal ^ x), one v_bitop3_b32
+    nhi = __builtin_amdgcn_bitop3_b32(nhi, (u32)(bal >> 32), x, 0xF6);
   }
   const u32 mlo = ~nlo, mhi = ~nhi;
   *rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));

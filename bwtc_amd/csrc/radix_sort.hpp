@@ -190,14 +190,27 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   __syncthreads();
 
   const u32 tile_out = SKIP ? tile_valid : tile_n;
-  for (u32 i = tid; i < tile_out; i += kRadixTPB) {
-    const K kk = s_key[i];
-    const u32 dst = s_gofs[radix_digit(kk, shift)] + i;
-    // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
-    // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
-    kout[dst] = kk;
-    if (values_mode != 2) vout[dst] = s_val[i];
-    if (PLANE) plane[dst] = (u8)radix_digit(kk, shift + kRadixBits);
+  // all LDS reads of a thread's E items first, then the offsets, then the stores (a loop over i
+  // ran two dependent LDS latencies per item, one item at a time)
+  K kk[E];
+  u32 vv[E], dst[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const u32 i = tid + (u32)e * kRadixTPB;
+    kk[e] = i < tile_out ? s_key[i] : (K)0;
+    vv[e] = (i < tile_out && values_mode != 2) ? s_val[i] : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) dst[e] = s_gofs[radix_digit(kk[e], shift)] + tid + (u32)e * kRadixTPB;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (tid + (u32)e * kRadixTPB < tile_out) {
+      // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
+      // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
+      kout[dst[e]] = kk[e];
+      if (values_mode != 2) vout[dst[e]] = vv[e];
+      if (PLANE) plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
+    }
   }
 }
 
