@@ -110,6 +110,32 @@ __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ s
 //     inside every group of equal keys, the suffixes shorter than k first and
 //     shortest-first -- exactly "proper prefix sorts first" -- without spending key bits.
 // ---------------------------------------------------------------------------------------
+// Dense codes of T[i_base .. i_base + count) into s_code, for a workgroup of 256 threads and
+// count <= 2040: aligned words of T, at most two per thread and both in flight, instead of a loop
+// of byte loads (each a memory latency of its own).  T is zero padded (and its region longer still).
+__device__ __forceinline__ void stage_codes(const u8* __restrict__ T, const u8* s_lut, u8* s_code,
+                                            u32 i_base, u32 count) {
+  const u32 a0 = i_base & ~3u, sh = i_base - a0;
+  const u32 nw = (sh + count + 3u) / 4u;
+  u32 w[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const u32 x = threadIdx.x + 256u * e;
+    w[e] = x < nw ? *reinterpret_cast<const u32*>(T + a0 + 4u * x) : 0u;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const u32 x = threadIdx.x + 256u * e;
+    if (x < nw) {
+#pragma unroll
+      for (u32 b = 0; b < 4u; ++b) {
+        const u32 t = 4u * x + b - sh;                    // wraps for the bytes before i_base
+        if (t < count) s_code[t] = s_lut[(w[e] >> (8u * b)) & 255u];
+      }
+    }
+  }
+}
+
 template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
   if (J0 >= n) return;
   const u32 cntw = min(kTile, n - J0);              // its slots
   const u32 i_base = n - J0 - cntw;                 // smallest suffix of the tile (its last slot)
-  for (u32 t = threadIdx.x; t < cntw + (u32)k; t += 256u) s_code[t] = s_lut[T[i_base + t]];   // T is zero padded
+  stage_codes(T, s_lut, s_code, i_base, cntw + (u32)k);
   __syncthreads();
   const u32 o = 4u * threadIdx.x;                   // this thread's suffixes: i_base + o .. + 3
   if (o < cntw) {
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
   const u32 cntw = min(kTile, n - J0);
   const u32 i_base = n - J0 - cntw;
   const u32 span = cntw + (u32)((G - 1) * g);        // gram starts this tile looks at (G g <= 64)
-  for (u32 t = threadIdx.x; t < span + (u32)g; t += 256u) s_code[t] = s_lut[T[i_base + t]];   // T is zero padded
+  stage_codes(T, s_lut, s_code, i_base, span + (u32)g);
   __syncthreads();
   {
     // span <= 1024 + 60: at most five gram starts per thread, strided, so that the five table
@@ -345,32 +371,52 @@ struct RrMasks {
   u32 chr[kRrE];       // bits 56..63 of its key (the carried character, when there is one)
 };
 
-// Masks of one wave chunk starting at list slot wbase.
+__device__ __forceinline__ u64 lane_value(u64 v, int l) { return (u64)__shfl((unsigned long long)v, l, kWave); }
+__device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kWave); }
+
+// Masks of one wave chunk starting at list slot wbase.  All of the chunk's keys and suffixes are
+// loaded before anything is compared (one iteration at a time, each with its own neighbour
+// loads, was eight memory latencies in a row per wave); the neighbours across an iteration's ends
+// are the adjacent iterations' end lanes, and only the two slots next to the whole chunk are
+// loaded on their own.
 template <typename K, bool INIT>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
                                          u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
                                          RrMasks<K, INIT>& f) {
+  K kc[kRrE];
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
     const u32 p = wbase + e * kWave + lane;
     const bool ok = p < m;
     const K kraw = ok ? key[p] : (K)0;
-    const K kc = kraw & kmask;
-    const u32 ic = ok ? idx[p] : 0u;
-    K kp = shfl_up1(kc);
-    K kn = shfl_down1(kc);
-    u32 ip = shfl_up1(ic);
-    if (lane == 0) { kp = (ok && p > 0) ? (key[p - 1] & kmask) : (K)0; if (INIT) ip = (ok && p > 0) ? idx[p - 1] : 0u; }
-    if (lane == kWave - 1) kn = (p + 1 < m) ? (key[p + 1] & kmask) : (K)0;
+    f.sfx[e] = ok ? idx[p] : 0u;
     f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw >> 56) : 0u;
-    bool h = ok && (p == 0 || kc != kp);
+    kc[e] = kraw & kmask;
+  }
+  K before = (K)0, after = (K)0;          // slots wbase - 1 and wbase + chunk (where they exist)
+  u32 ibefore = 0u;
+  if (lane == 0 && wbase > 0 && wbase < m) { before = key[wbase - 1] & kmask; if (INIT) ibefore = idx[wbase - 1]; }
+  if (lane == kWave - 1 && wbase + (u32)kRrChunk < m) after = key[wbase + kRrChunk] & kmask;
+#pragma unroll
+  for (int e = 0; e < kRrE; ++e) {
+    const u32 p = wbase + e * kWave + lane;
+    const bool ok = p < m;
+    const u32 ic = f.sfx[e];
+    K kp = shfl_up1(kc[e]);
+    K kn = shfl_down1(kc[e]);
+    u32 ip = shfl_up1(ic);
+    const K kprev_end = e > 0 ? lane_value(kc[e > 0 ? e - 1 : 0], kWave - 1) : before;
+    const u32 iprev_end = e > 0 ? lane_value(f.sfx[e > 0 ? e - 1 : 0], kWave - 1) : ibefore;
+    const K knext_first = e + 1 < kRrE ? lane_value(kc[e + 1 < kRrE ? e + 1 : e], 0) : after;
+    if (lane == 0) { kp = (ok && p > 0) ? kprev_end : (K)0; if (INIT) ip = (ok && p > 0) ? iprev_end : 0u; }
+    if (lane == kWave - 1) kn = (p + 1 < m) ? knext_first : (K)0;
+    bool h = ok && (p == 0 || kc[e] != kp);
     if (INIT) h = h || (ok && p > 0 && (u64)ip + short_len >= (u64)n);
-    bool hn = (p + 1 >= m) || kn != kc;           // is p+1 a head (or past the end)?
+    bool hn = (p + 1 >= m) || kn != kc[e];         // is p+1 a head (or past the end)?
     if (INIT) hn = hn || ((u64)ic + short_len >= (u64)n);
     f.head[e] = __ballot(h);
     f.valid[e] = __ballot(ok);
     f.act[e] = __ballot(ok && (!h || !hn));
-    f.sfx[e] = ic;
   }
 }
 
@@ -504,30 +550,44 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
   }
   const u64 lt = (1ull << lane) - 1ull;
   const u64 le = lt | (1ull << lane);
+  // first every load of the chunk (global slots, new ranks, characters), then the stores
+  u32 gs[kRrE], nrs[kRrE], grps[kRrE], qs[kRrE], cs[kRrE];
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
     const u32 base = wbase + e * kWave;
     const u32 p = base + lane;
     const u64 hd = f.head[e], ac = f.act[e];
+    gs[e] = 0; nrs[e] = 0; grps[e] = 0; qs[e] = 0; cs[e] = 0;
     if ((f.valid[e] >> lane) & 1ull) {
       const bool a = (ac >> lane) & 1ull;
       const u64 hm = hd & le;
       const u32 hp1 = hm ? base + top_bit(hm) + 1u : hp_run;   // head slot + 1
       const u32 s = f.sfx[e];
-      const u32 g = INIT ? p : aglob[p];
-      const u32 nr = INIT ? hp1 - 1u : aglob[hp1 - 1u];
-      const u32 grp = g_run + (u32)__popcll(ac & hd & le) - 1u;   // dense number of p's group (if active)
+      gs[e] = INIT ? p : aglob[p];
+      nrs[e] = INIT ? hp1 - 1u : aglob[hp1 - 1u];
+      grps[e] = g_run + (u32)__popcll(ac & hd & le) - 1u;      // dense number of p's group (if active)
+      qs[e] = q_run + (u32)__popcll(ac & lt);
+      if (EMIT == 1) cs[e] = f.chr[e];
+      if (EMIT == 2 && (!a || MODE != 2)) cs[e] = s ? em.T[s - 1u] : 0u;
+    }
+    q_run += (u32)__popcll(ac);
+    g_run += (u32)__popcll(ac & hd);
+    if (hd) hp_run = base + top_bit(hd) + 1u;
+  }
+#pragma unroll
+  for (int e = 0; e < kRrE; ++e) {
+    const u32 p = wbase + e * kWave + lane;
+    if ((f.valid[e] >> lane) & 1ull) {
+      const bool a = (f.act[e] >> lane) & 1ull;
+      const u32 s = f.sfx[e], g = gs[e], nr = nrs[e], grp = grps[e], c = cs[e];
       if (MODE == 2) {
         reinterpret_cast<u64*>(pair_s)[p] = ((u64)s << 32) | (u64)nr;
         pair_r[p] = a ? grp : 0xFFFFFFFFu;
         if (em.rec_plane) em.rec_plane[p] = (u8)(s >> em.rec_shift);
       } else if (MODE == 1) { pair_s[p] = s; pair_r[p] = nr; }
       else rank[s] = nr;
-      u32 c = 0;
-      if (EMIT == 1) c = f.chr[e];
-      if (EMIT == 2 && (!a || MODE != 2)) c = s ? em.T[s - 1u] : 0u;
       if (a) {
-        const u32 q = q_run + (u32)__popcll(ac & lt);
+        const u32 q = qs[e];
         aglob_out[q] = g;
         if (MODE != 2) {
           aidx_out[q] = s;
@@ -543,9 +603,6 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
         }
       }
     }
-    q_run += (u32)__popcll(ac);
-    g_run += (u32)__popcll(ac & hd);
-    if (hd) hp_run = base + top_bit(hd) + 1u;
   }
 }
 

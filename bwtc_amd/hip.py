@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbwtc_hip.so")
+# BWTC_HIP_LIB: another build of the library (development: tile-shape sweeps, scripts/dev/)
+LIB_PATH = os.environ.get("BWTC_HIP_LIB") or os.path.join(_HERE, "lib", "libbwtc_hip.so")
 
 _vp = ctypes.c_void_p
 _u32 = ctypes.c_uint32
