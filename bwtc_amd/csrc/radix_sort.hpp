@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 
 // PLANE: the pass also writes plane[dst] = the item's NEXT digit, one byte per item in output
 // order, so that the next pass's histogram kernel reads 1 byte per item instead of the key.
-template <typename K, bool SKIP, bool PLANE>
+// KEYS: keys only (no values staged: half the LDS of a 32-bit pair tile, twice the workgroups per CU).
+template <typename K, bool SKIP, bool PLANE, bool KEYS>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
     u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
   // tile slots, so the reorder staging (keys, then values) reuses their bytes; that keeps
   // the (u64,u32) kernel at 50 KiB = three workgroups per CU.
-  constexpr int kStageBytes = TILE * (int)(sizeof(K) + sizeof(u32));
+  constexpr int kStageBytes = TILE * (int)(sizeof(K) + (KEYS ? 0 : sizeof(u32)));
   constexpr int kCntBytes = kRadixWaves * kRadixBins * (int)sizeof(u32);
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStageBytes > kCntBytes ? kStageBytes : kCntBytes];
   K* s_key = reinterpret_cast<K*>(s_raw);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     if (SKIP && k[e] == ~(K)0) ok = false;
     // values_mode 1: first pass of a sort whose values are the items' own positions, nothing to
     // read; 2: keys only
-    v[e] = (!ok || values_mode == 2) ? 0u : values_mode == 1 ? (u32)(tile_base + slot) : vin[tile_base + slot];
+    v[e] = (!ok || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot) : vin[tile_base + slot];
     if (SKIP) okm |= (ok ? 1u : 0u) << e;
   }
   __syncthreads();
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (int e = 0; e < E; ++e) {
     if (BWTC_EXISTS(e)) {
       s_key[r[e]] = k[e];
-      if (values_mode != 2) s_val[r[e]] = v[e];
+      if (!KEYS) s_val[r[e]] = v[e];
     }
   }
 #undef BWTC_EXISTS
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (int e = 0; e < E; ++e) {
     const u32 i = tid + (u32)e * kRadixTPB;
     kk[e] = i < tile_out ? s_key[i] : (K)0;
-    vv[e] = (i < tile_out && values_mode != 2) ? s_val[i] : 0u;
+    vv[e] = (i < tile_out && !KEYS) ? s_val[i] : 0u;
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) dst[e] = s_gofs[radix_digit(kk[e], shift)] + tid + (u32)e * kRadixTPB;
@@ -208,38 +209,59 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
       // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
       // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
       kout[dst[e]] = kk[e];
-      if (values_mode != 2) vout[dst[e]] = vv[e];
+      if (!KEYS) vout[dst[e]] = vv[e];
       if (PLANE) plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
     }
   }
 }
 
 // Tile histogram from a digit plane (see PLANE above): same table as k_radix_hist<K, false>.
+// A workgroup takes TWO tiles, half its threads each: the kernel is a chain of latencies (clear
+// LDS, load, count, add up the copies, store) with little to do in between, so twice the bytes per
+// workgroup is close to twice the speed.
 template <typename K>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __restrict__ plane,
                                                                 u32* __restrict__ table, u64 n,
                                                                 u32 ntiles) {
-  constexpr int E = RadixCfg<K>::E;                 // bytes of the tile per thread
-  __shared__ u32 hist[kRadixBins * 16];
-  for (u32 i = threadIdx.x; i < kRadixBins * 16; i += kRadixTPB) hist[i] = 0;
-  __syncthreads();
-  const u64 base = (u64)blockIdx.x * (kRadixTPB * E) + (u64)threadIdx.x * E;
-  const u32 copy = threadIdx.x & 15u;
-  if (base + E <= n) {
-    u32 w[E / 4];
-    if (E == 8) { const uint2 t = *reinterpret_cast<const uint2*>(plane + base); w[0] = t.x; w[1] = t.y; }
-    else { const uint4 t = *reinterpret_cast<const uint4*>(plane + base); w[0] = t.x; w[1] = t.y; w[E / 4 - 2] = t.z; w[E / 4 - 1] = t.w; }
-#pragma unroll
-    for (int b = 0; b < E; ++b) atomicAdd(&hist[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
-  } else {
-    for (int b = 0; b < E; ++b) if (base + b < n) atomicAdd(&hist[(u32)plane[base + b] * 16u + copy], 1u);
+  constexpr int E = RadixCfg<K>::E;
+  constexpr int HALF = kRadixTPB / 2;
+  constexpr int B = 2 * E;                          // bytes of the tile per thread (16 or 32)
+  static_assert(B % 16 == 0, "whole 16-byte loads");
+  __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * 16];
+  {
+    uint4* z = reinterpret_cast<uint4*>(&hist[0][0]);
+    for (u32 i = threadIdx.x; i < 2u * kRadixBins * 16u / 4u; i += kRadixTPB) z[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  if (threadIdx.x < kRadixBins) {
-    u32 c = 0;
+  const u32 half = threadIdx.x / HALF, t = threadIdx.x % HALF;
+  const u32 tile = blockIdx.x * 2u + half;
+  if (tile < ntiles) {
+    const u64 base = (u64)tile * (kRadixTPB * E) + (u64)t * B;
+    const u32 copy = t & 15u;
+    u32* h = hist[half];
+    if (base + B <= n) {
+      uint4 q[B / 16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c += hist[threadIdx.x * 16u + r];
-    table[(u64)threadIdx.x * ntiles + blockIdx.x] = c;
+      for (int i = 0; i < B / 16; ++i) q[i] = *reinterpret_cast<const uint4*>(plane + base + 16 * i);
+#pragma unroll
+      for (int i = 0; i < B / 16; ++i) {
+        const u32 w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+      }
+    } else {
+      for (int b = 0; b < B; ++b) if (base + b < n) atomicAdd(&h[(u32)plane[base + b] * 16u + copy], 1u);
+    }
+  }
+  __syncthreads();
+  if (tile < ntiles) {
+    for (u32 bin = t; bin < (u32)kRadixBins; bin += HALF) {
+      const uint4* r4 = reinterpret_cast<const uint4*>(&hist[half][bin * 16u]);
+      u32 c = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const uint4 v = r4[r]; c += v.x + v.y + v.z + v.w; }
+      table[(u64)bin * ntiles + tile] = c;
+    }
   }
 }
 
@@ -310,18 +332,16 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
       const bool have_plane = plane0 && (!first || (plane0_ready && !skip));   // the previous pass (or the producer) left this pass's digits
       const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's
-      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3(ntiles), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles);
+      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles);
       else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-      if (skip) {
-        if (make_plane) hipLaunchKernelGGL((k_radix_scatter<K, true, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, plane1);
-        else hipLaunchKernelGGL((k_radix_scatter<K, true, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, (u8*)nullptr);
-      } else {
-        if (make_plane) hipLaunchKernelGGL((k_radix_scatter<K, false, true>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, plane1);
-        else hipLaunchKernelGGL((k_radix_scatter<K, false, false>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, (u8*)nullptr);
-      }
+#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr)
+      if (keys_only) { if (make_plane) BWTC_SCATTER(false, true, true); else BWTC_SCATTER(false, false, true); }   // never with holes
+      else if (skip) { if (make_plane) BWTC_SCATTER(true, true, false); else BWTC_SCATTER(true, false, false); }
+      else { if (make_plane) BWTC_SCATTER(false, true, false); else BWTC_SCATTER(false, false, false); }
+#undef BWTC_SCATTER
       { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
       if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
       K* tk = kin; kin = kout; kout = tk;

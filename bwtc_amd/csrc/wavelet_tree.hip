@@ -135,7 +135,6 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
                                                       u32* __restrict__ key, u8* __restrict__ plane) {
-  __shared__ u32 s_first[257];
   __shared__ u32 s_off[kWtTPB + 1];
   __shared__ u32 s_sym[kWtTPB];        // pool offset of the run's symbol steps
   __shared__ u32 s_len[kWtTPB];        // pool offset of its length steps
@@ -146,22 +145,26 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   const u32 cnt = min((u32)kWtTPB, n_runs - r0);
   bool uniform; u32 sec_first;
   u32 s = wt_section_uniform(t.first_run, t.nsec, r0, cnt, &uniform, &sec_first);
-  if (!uniform)
-    for (u32 i = threadIdx.x; i <= t.nsec; i += kWtTPB) s_first[i] = t.first_run[i];
-  s_off[threadIdx.x] = off[min(r, n_runs)];                 // off[n_runs] = total
-  if (threadIdx.x == 0) s_off[kWtTPB] = off[min(r0 + (u32)kWtTPB, n_runs)];
-  __syncthreads();
-  const u32 o0 = s_off[0], o1 = s_off[cnt];
-  const bool owned = o1 - o0 <= kWtOwnerWin;
+  // Everything a run needs is looked up before the first barrier, in two rounds of independent
+  // loads (the run's own words and offsets, then the table entries they select).
+  const u32 rr = min(r, n_runs - 1u);
+  const u32 my_off = off[min(r, n_runs)];                   // off[n_runs] = total
+  const u32 end_off = threadIdx.x == 0 ? off[min(r0 + (u32)kWtTPB, n_runs)] : 0u;
+  const u32 c = run_sym[rr];
+  const u32 cp = run_sym[rr ? rr - 1u : 0u];
+  const u32 len = run_start[rr + 1] - run_start[rr];
+  if (!uniform) {                                           // a section border inside the workgroup: the lanes search for themselves
+    u32 lo = 0, hi = t.nsec;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (t.first_run[mid] <= rr) lo = mid; else hi = mid; }
+    s = lo;
+    sec_first = t.first_run[lo];
+  }
+  const uint2 sy = t.symtab[s * 256u + c];
+  const u64 code_c = t.symcode[s * 256u + c], code_p = t.symcode[s * 256u + cp];
+  const uint2 led = t.lendense[(u64)s * kWtLenDense + min(len, kWtLenDense - 1u)];
+  s_off[threadIdx.x] = my_off;
+  if (threadIdx.x == 0) s_off[kWtTPB] = end_off;
   if (r < n_runs) {
-    if (!uniform) { s = wt_section_of(s_first, t.nsec, r); sec_first = s_first[s]; }
-    // every lookup unconditional, so that they are in flight together
-    const u32 c = run_sym[r];
-    const u32 cp = run_sym[r ? r - 1u : 0u];
-    const u32 len = run_start[r + 1] - run_start[r];
-    const uint2 sy = t.symtab[s * 256u + c];
-    const u64 code_c = t.symcode[s * 256u + c], code_p = t.symcode[s * 256u + cp];
-    const uint2 led = t.lendense[(u64)s * kWtLenDense + min(len, kWtLenDense - 1u)];
     // steps at depth > (common prefix with the previous run's code) carry the gap flag
     const u32 common = r > sec_first ? (u32)__clzll(code_c ^ code_p) : 0u;
     u32 len_off = 0;
@@ -169,10 +172,13 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
     s_sym[threadIdx.x] = sy.x;
     s_len[threadIdx.x] = len_off;
     s_meta[threadIdx.x] = (sy.y & 255u) | (min(common, 64u) << 8) | (((sy.y >> 8) & 255u) << 16);
-    if (owned) {
-      const u32 b = s_off[threadIdx.x] - o0, e = s_off[threadIdx.x + 1] - o0;
-      for (u32 i = b; i < e; ++i) s_owner[i] = (u8)threadIdx.x;
-    }
+  }
+  __syncthreads();
+  const u32 o0 = s_off[0], o1 = s_off[cnt];
+  const bool owned = o1 - o0 <= kWtOwnerWin;
+  if (owned && r < n_runs) {
+    const u32 b = s_off[threadIdx.x] - o0, e = s_off[threadIdx.x + 1] - o0;
+    for (u32 i = b; i < e; ++i) s_owner[i] = (u8)threadIdx.x;
   }
   __syncthreads();
   // four steps per thread and round, every pool lookup of the round in flight before the first is used
