@@ -340,12 +340,23 @@ struct FusedChain {
 };
 
 // `words` 16-element words of every busy lane; each stands on a word boundary with that many
-// words of its current group ahead.  The model half is runWords<true, true, true>, the coder half
-// wavelet_rc.cpp's runWords; the probability goes from one to the other in a register.
+// words of its current group ahead.  The coder half is wavelet_rc.cpp's runWords; the probability
+// goes from the model to it in a register.
+//
+// The model half keeps the fifteen predictors of the sixteen lanes as 16-bit values, two slots to
+// a register (R[k]: slot 2k in elements 0..15, slot 2k+1 in 16..31).  A lane's predictor is then
+// picked by four two-register word permutes (index = slot's low two bits and the lane) and three
+// blends on the slot's upper two bits, and put back by eight word compares + blends -- 30
+// operations where the form of runWords (a compare, a masked move and an OR per slot to select,
+// a masked move per slot to update) takes 60; the loop is bound by the number of vector
+// operations, not by a dependency chain.
 BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask) {
-  constexpr int kLo = 0, kHi = 15;
-  __m512i Q[kSlots];
-  for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_load_si512(L.q[s]);
+  __m512i R[8];
+  for (int k = 0; k < 8; ++k) {
+    const __m256i a = _mm512_cvtepi32_epi16(_mm512_load_si512(L.q[2 * k]));
+    const __m256i b = 2 * k + 1 < kSlots ? _mm512_cvtepi32_epi16(_mm512_load_si512(L.q[2 * k + 1])) : _mm256_setzero_si256();
+    R[k] = _mm512_inserti64x4(_mm512_castsi256_si512(a), b, 1);
+  }
   __m512i mc = _mm512_load_si512(L.mc), gc = _mm512_load_si512(L.gc), ic = _mm512_load_si512(L.ic);
   __m512i lo = _mm512_load_si512(L.lo), size = _mm512_load_si512(L.size);
   const __m512i zero = _mm512_setzero_si512(), one = _mm512_set1_epi32(1), two = _mm512_set1_epi32(2);
@@ -356,13 +367,24 @@ BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask
   const __mmask16 kBusy = static_cast<__mmask16>(busy_mask);
   const __m512i floorV = _mm512_mask_blend_epi32(kInt, two, _mm512_set1_epi32(100));
   const __m512i topV = _mm512_sub_epi32(_mm512_set1_epi32(4096), floorV);
-  const __m512i five = _mm512_set1_epi32(5), c8 = _mm512_set1_epi32(8), c12 = _mm512_set1_epi32(12);
+  const __m512i c8 = _mm512_set1_epi32(8), c12 = _mm512_set1_epi32(12);
+  const __m512i four = _mm512_set1_epi32(4);
+  const __m512i Tdelay = _mm512_setr_epi32(4, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 5, 5, 5, 5);
   const __m512i T8 = _mm512_setr_epi32(0, 4, 0, 4, 1, 4, 2, 4, 3, 5, 3, 6, 3, 7, 3, 7);
   const __m512i T4 = _mm512_setr_epi32(0, 2, 0, 2, 1, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0);
   const __m512i T3 = _mm512_setr_epi32(0, 1, 0, 2, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
   const __m512i c4095 = _mm512_set1_epi32(4095), c2048 = _mm512_set1_epi32(2048), c510 = _mm512_set1_epi32(510);
   const __m512i top = _mm512_set1_epi32(static_cast<int>(0xFF000000u));
   const __m512i lane_id = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
+  // 16-bit constants: the lane number of every element, and per register the two slots it holds
+  alignas(64) uint16_t iota_w[32], slots_w[8][32];
+  for (int i = 0; i < 32; ++i) {
+    iota_w[i] = static_cast<uint16_t>(i & 15);
+    for (int k = 0; k < 8; ++k) slots_w[k][i] = static_cast<uint16_t>(2 * k + (i >> 4));
+  }
+  const __m512i iotaW = _mm512_load_si512(iota_w), c48w = _mm512_set1_epi16(0x30);
+  __m512i slotsW[8];
+  for (int k = 0; k < 8; ++k) slotsW[k] = _mm512_load_si512(slots_w[k]);
   alignas(64) uint32_t in[kLanes];
   alignas(64) uint32_t ev[16 * kLanes * 4 + 64];
   for (uint64_t w = 0; w < words; ++w) {
@@ -374,7 +396,7 @@ BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask
     __m512i W = _mm512_load_si512(in);
     uint32_t n = 0;
     for (int step = 0; step < 16; ++step) {
-      // ---- model: the lane's predictor and its move (runWords<true, true, true>)
+      // ---- model: the lane's predictor and its move
       const __m512i v = _mm512_and_si512(W, _mm512_set1_epi32(3));
       W = _mm512_srli_epi32(W, 2);
       const __mmask16 kBit = _mm512_test_epi32_mask(v, one);
@@ -382,21 +404,19 @@ BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask
       __m512i slot = mc;
       slot = _mm512_mask_add_epi32(slot, kGap, gc, c8);
       slot = _mm512_mask_add_epi32(slot, kInt, ic, c12);
-      __mmask16 m[kSlots];
-      __m512i part[16];
-      part[15] = zero;
-      for (int s = kLo; s < kHi; ++s) {
-        m[s] = _mm512_cmpeq_epi32_mask(slot, _mm512_set1_epi32(s));
-        part[s] = _mm512_maskz_mov_epi32(m[s], Q[s]);
-      }
-      for (int width = 8; width >= 1; width >>= 1)
-        for (int k = 0; k < width; ++k) part[k] = _mm512_or_si512(part[k], part[k + width]);
-      const __m512i pr = part[0];
-      const __m512i delay = _mm512_mask_sub_epi32(five, m[0] | m[7], five, one);
+      const __m512i slotW = _mm512_broadcast_i64x4(_mm512_cvtepi32_epi16(slot));         // the lanes' slots, in both halves
+      const __m512i idx = _mm512_or_si512(_mm512_and_si512(_mm512_slli_epi16(slotW, 4), c48w), iotaW);
+      const __m512i p0 = _mm512_permutex2var_epi16(R[0], idx, R[1]), p1 = _mm512_permutex2var_epi16(R[2], idx, R[3]);
+      const __m512i p2 = _mm512_permutex2var_epi16(R[4], idx, R[5]), p3 = _mm512_permutex2var_epi16(R[6], idx, R[7]);
+      const __mmask32 k4 = _mm512_test_epi32_mask(slot, four), k8 = _mm512_test_epi32_mask(slot, c8);
+      const __m512i prW = _mm512_mask_blend_epi16(k8, _mm512_mask_blend_epi16(k4, p0, p1), _mm512_mask_blend_epi16(k4, p2, p3));
+      const __m512i pr = _mm512_cvtepu16_epi32(_mm512_castsi512_si256(prW));
+      const __m512i delay = _mm512_permutexvar_epi32(slot, Tdelay);          // 4 for the main model's two end states, else 5
       const __m512i up = _mm512_add_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(topV, pr), delay));
       const __m512i down = _mm512_sub_epi32(pr, _mm512_srlv_epi32(_mm512_sub_epi32(pr, floorV), delay));
       const __m512i moved = _mm512_mask_blend_epi32(kBit, down, up);
-      for (int s = kLo; s < kHi; ++s) Q[s] = _mm512_mask_mov_epi32(Q[s], m[s], moved);
+      const __m512i movedW = _mm512_broadcast_i64x4(_mm512_cvtepi32_epi16(moved));
+      for (int k = 0; k < 8; ++k) R[k] = _mm512_mask_blend_epi16(_mm512_cmpeq_epi16_mask(slotW, slotsW[k]), R[k], movedW);
       const __m512i bit = _mm512_and_si512(v, one);
       mc = _mm512_mask_mov_epi32(mc, kMainMoves, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(mc, 1), bit), T8));
       gc = _mm512_mask_mov_epi32(gc, kGap, _mm512_permutexvar_epi32(_mm512_add_epi32(_mm512_slli_epi32(gc, 1), bit), T4));
@@ -422,7 +442,10 @@ BWTC_AVX512 void runFusedWords(FusedLanes& L, uint64_t words, uint32_t busy_mask
     }
     for (uint32_t k = 0; k < n; ++k) { const uint32_t e = ev[k]; *L.outp[e >> 8]++ = static_cast<uint8_t>(e); }
   }
-  for (int s = kLo; s < kHi; ++s) _mm512_store_si512(L.q[s], Q[s]);
+  for (int k = 0; k < 8; ++k) {
+    _mm512_store_si512(L.q[2 * k], _mm512_cvtepu16_epi32(_mm512_castsi512_si256(R[k])));
+    if (2 * k + 1 < kSlots) _mm512_store_si512(L.q[2 * k + 1], _mm512_cvtepu16_epi32(_mm512_extracti64x4_epi64(R[k], 1)));
+  }
   _mm512_store_si512(L.mc, mc);
   _mm512_store_si512(L.gc, gc);
   _mm512_store_si512(L.ic, ic);
