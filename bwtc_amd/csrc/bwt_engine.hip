@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
   __syncthreads();
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
     keys[J0 + j] = s_key[j];
-    idx[J0 + j] = n - 1u - (J0 + j);
+    if (idx) idx[J0 + j] = n - 1u - (J0 + j);        // nullptr: the sort's first pass makes the values up
     if (plane) plane[J0 + j] = (u8)s_key[j];         // the first radix pass's digits (radix_sort.hpp, planes)
   }
 }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
   __syncthreads();
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
     keys[J0 + j] = s_key[j];
-    idx[J0 + j] = n - 1u - (J0 + j);
+    if (idx) idx[J0 + j] = n - 1u - (J0 + j);
     if (plane) plane[J0 + j] = (u8)s_key[j];
   }
 }
@@ -465,7 +465,19 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
   const u32 b = wave * per;
   const u32 e = min(b + per, ntiles);
   u32 sa = 0, sb = 0, sc = 0;
-  for (u32 i = b + lane; i < e; i += kWave) { sa += aggA[i]; sb += aggB[i]; sc = max(sc, aggC[i]); }
+  // four rows of 64 entries per trip, their twelve loads in flight together (this one workgroup
+  // walks 131 072 tile aggregates for a 256 MiB block: one row per trip was 128 latencies in a row)
+  for (u32 i0 = b + lane; i0 < e; i0 += 4u * kWave) {
+    u32 a[4], bb[4], c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = i0 + (u32)r * kWave;
+      const bool ok = i < e;
+      a[r] = ok ? aggA[i] : 0u; bb[r] = ok ? aggB[i] : 0u; c[r] = ok ? aggC[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sa += a[r]; sb += bb[r]; sc = max(sc, c[r]); }
+  }
   sa = wave_scan_add(sa, lane); sb = wave_scan_add(sb, lane); sc = wave_scan_max(sc, lane);
   if (lane == kWave - 1) { s_tot[0][wave] = sa; s_tot[1][wave] = sb; s_tot[2][wave] = sc; }
   __syncthreads();
@@ -474,20 +486,28 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
     if (w < wave) { ca += s_tot[0][w]; cb += s_tot[1][w]; cc = max(cc, s_tot[2][w]); }
     ta += s_tot[0][w]; tb += s_tot[1][w];
   }
-  for (u32 i0 = b; i0 < e; i0 += kWave) {
-    const u32 i = i0 + lane;
-    const bool ok = i < e;
-    const u32 va = ok ? aggA[i] : 0u, vb = ok ? aggB[i] : 0u, vc = ok ? aggC[i] : 0u;
-    const u32 ia = wave_scan_add(va, lane), ib = wave_scan_add(vb, lane), ic = wave_scan_max(vc, lane);
-    const u32 pc = __shfl_up(ic, 1, kWave);
-    if (ok) {
-      aggA[i] = ca + ia - va;
-      aggB[i] = cb + ib - vb;
-      aggC[i] = max(cc, lane ? pc : 0u);
+  for (u32 i0 = b; i0 < e; i0 += 4u * kWave) {
+    u32 va[4], vb[4], vc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = i0 + (u32)r * kWave + lane;
+      const bool ok = i < e;
+      va[r] = ok ? aggA[i] : 0u; vb[r] = ok ? aggB[i] : 0u; vc[r] = ok ? aggC[i] : 0u;
     }
-    ca += __shfl(ia, kWave - 1, kWave);
-    cb += __shfl(ib, kWave - 1, kWave);
-    cc = max(cc, __shfl(ic, kWave - 1, kWave));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = i0 + (u32)r * kWave + lane;
+      const u32 ia = wave_scan_add(va[r], lane), ib = wave_scan_add(vb[r], lane), ic = wave_scan_max(vc[r], lane);
+      const u32 pc = __shfl_up(ic, 1, kWave);
+      if (i < e) {
+        aggA[i] = ca + ia - va[r];
+        aggB[i] = cb + ib - vb[r];
+        aggC[i] = max(cc, lane ? pc : 0u);
+      }
+      ca += __shfl(ia, kWave - 1, kWave);
+      cb += __shfl(ib, kWave - 1, kWave);
+      cc = max(cc, __shfl(ic, kWave - 1, kWave));
+    }
   }
   if (threadIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
 }
@@ -993,6 +1013,8 @@ void BwtEngine::release() {
   }
   if (d_wt) (void)hipFree(d_wt);
   if (h_wt) (void)hipHostFree(h_wt);
+  if (h_stats) (void)hipHostFree(h_stats);
+  h_stats = nullptr; h_stats_bytes = 0;
   d_wt = nullptr; h_wt = nullptr; wt_bytes = 0; h_wt_bytes = 0;
   if (ev_wait) (void)hipEventDestroy(ev_wait);
   ev_wait = nullptr;
@@ -1068,7 +1090,7 @@ static bool can_carry(u32 n) { return rank_bits(n) + bit_width_u64(n / 2 ? n / 2
 
 template <typename K>
 void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                           bool probe_it, int bit_lo, u64 n_holes, bool plane_ready) {
+                           bool probe_it, int bit_lo, u64 n_holes, bool plane_ready, bool values_descend) {
   if (use_sweep && n_holes == 0) {
     SweepWs ws;
     ws.hist_all = d_sweep;
@@ -1081,7 +1103,8 @@ void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K**
   } else {
     radix_sort_pairs<K>(k0, k1, v0, v1, n, nbits, d_table, d_partial, stream, ks, vs,
                         probe_it ? &probe : nullptr, bit_lo, false, false, n_holes,
-                        digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr, plane_ready && digit_planes);
+                        digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr, plane_ready && digit_planes,
+                        values_descend);
   }
 }
 
@@ -1279,6 +1302,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
   int rc = 0;
   u8* key_plane = digit_planes && !use_sweep ? d_P0 : nullptr;     // the key makers leave the first pass's digits
+  // slot j holds suffix n-1-j: the sort's first pass can make that up instead of reading it
+  const bool implied_idx = !use_sweep && n > 1;
+  u32* idx_out = implied_idx ? nullptr : d_V0;
   if (plan.wide) {
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
@@ -1290,15 +1316,15 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       short_len = (u32)(gp.g * gp.G);
       h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const u32*)d_rank, ka, d_V0, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
+                         (const u32*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
     } else {
       u64 top = 1;
       for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
       hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                         d_V0, n, plan.k, plan.sigma, top, key_plane);
+                         idx_out, n, plan.k, plan.sigma, top, key_plane);
     }
     u64* ks = nullptr; u32* vs = nullptr;
-    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr);
+    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
     rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
@@ -1309,9 +1335,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     u32 top = 1;
     for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
     hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                       d_V0, n, plan.k, plan.sigma, top, key_plane);
+                       idx_out, n, plan.k, plan.sigma, top, key_plane);
     u32* ks = nullptr; u32* vs = nullptr;
-    sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr);
+    sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     rb.rec_keys = d_R1; rb.rec_free = d_R2;             // both 32-bit key arrays live in R1
     rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;

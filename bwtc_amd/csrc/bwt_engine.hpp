@@ -24,6 +24,7 @@
 #include <map>
 #include <memory>
 #include <utility>
+#include <functional>
 #include <vector>
 
 namespace bwtc_hip {
@@ -128,6 +129,10 @@ struct BwtEngine {
   u64 wt_bytes = 0;
   u8* h_wt = nullptr;      // pinned: tables up, packed streams down
   u64 h_wt_bytes = 0;
+  u8* h_stats = nullptr;   // pinned: the run scanner's statistics come down in two copies and one wait
+  u64 h_stats_bytes = 0;
+  int reserve_stats(u64 bytes);
+  std::vector<u32> long_count;   // host scratch of the run statistics: counts of long run lengths, all zero between calls
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
   // run arrays of the 'B' coder's scanner, two buffers: block i is scanned while block i-1's runs still
   // wait for their stream kernels (wavelet_encoder.hip)
@@ -182,7 +187,7 @@ struct BwtEngine {
   // radix sort front door: picks the chained single-read passes or the classic ones
   template <typename K>
   void sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
-                  bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false);
+                  bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false, bool values_descend = false);
   // one ranking step of the suffix sorter (bwt_engine.hip)
   struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
   struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; };
@@ -221,8 +226,10 @@ struct WaveletSectionStats {
   std::vector<u32> first_run;                                 // first run of every section, + total
 };
 // d_run_start / d_run_sym: where the runs go (null: the transform's workspace, e.d_R1 / e.d_R2)
+// while_waiting: host work to do after the scanner's kernels and copies are queued, before the wait for them
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
-                                 WaveletSectionStats* out, u32* d_run_start = nullptr, u8* d_run_sym = nullptr);
+                                 WaveletSectionStats* out, u32* d_run_start = nullptr, u8* d_run_sym = nullptr,
+                                 const std::function<void()>* while_waiting = nullptr);
 
 // Steps of all runs of the block sorted into coding order, skipped bits dropped, the packed
 // streams copied into `codes` (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
@@ -243,7 +250,8 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes);
 // everything that does not depend on earlier blocks, _queue hands the block to the workers with
 // the carried model state after the previous block and reports the state after this one.
 int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
-                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket);
+                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket,
+                           const std::function<void()>* while_scanning = nullptr);
 int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out);
 void wavelet_pipeline_release(BwtEngine& e);
 

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 namespace bwtc_hip {
@@ -97,8 +98,9 @@ __device__ __forceinline__ u32 gamma_bits(u32 len) { return 2u * (31u - (u32)__c
 // and is settled by k_open_runs (one run per tile) once run_start[] is complete.
 // Replaces k_runs_emit + k_run_stats + k_run_length_dist (three sweeps) by one.
 // ---------------------------------------------------------------------------------------
-constexpr u32 kLenDense = 4096;
+constexpr u32 kLenDense = 512;     // the table comes to the host with every block: 4096 entries per section were 1.3 MB of copy and a 0.1 ms loop
 constexpr u32 kLenLds = 256;
+constexpr u32 kLongDirect = 1u << 20;   // host: run lengths below this are counted in a table
 constexpr u32 kNoRun = 0xFFFFFFFFu;
 
 struct RunStatsOut {
@@ -595,8 +597,10 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
 // appended to an overflow list; the host folds both into sorted (length, count) pairs.
 // ---------------------------------------------------------------------------------------
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
-                                 WaveletSectionStats* out, u32* d_run_start_arg, u8* d_run_sym_arg) {
+                                 WaveletSectionStats* out, u32* d_run_start_arg, u8* d_run_sym_arg,
+                                 const std::function<void()>* while_waiting) {
   hipStream_t st = e.stream;
+  const auto t_in = std::chrono::steady_clock::now();
   if (!freqs || !out) return -1;
   if ((u64)size > e.cap) return -1;
   BWTC_HIP_TRY(hipSetDevice(e.device));
@@ -605,7 +609,7 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
   out->run_freqs.assign((size_t)nsec * 256, 0);
   out->total_runs.assign(nsec, 0);
   out->dist.assign(nsec, std::vector<std::pair<u32, u32> >());
-  if (size == 0 || nsec == 0) return 0;
+  if (size == 0 || nsec == 0) { if (while_waiting) (*while_waiting)(); return 0; }
 
   u32* d_run_start = d_run_start_arg ? d_run_start_arg : static_cast<u32*>(e.d_R1);
   u8* d_run_sym = d_run_sym_arg ? d_run_sym_arg : static_cast<u8*>(e.d_R2);
@@ -644,25 +648,47 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
                      nsec, d_tile, d_run_start, d_run_sym, d_first_run, d_nruns, aligned, so, rtiles, tiles_per_wg);
   hipLaunchKernelGGL((k_open_runs<false, true>), dim3(ceil_div(rtiles, 256)), dim3(256), 0, st, d_run_start,
                      d_run_sym, d_first_run, nsec, rtiles, so);
-  BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_nruns, 4, hipMemcpyDeviceToHost, st));
-  std::vector<u32> first(nsec + 1), dense((size_t)nsec * kLenDense);
-  u32 n_over = 0;
-  BWTC_HIP_TRY(hipMemcpyAsync(out->run_freqs.data(), d_run_freqs, (size_t)nsec * 1024, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipMemcpyAsync(first.data(), d_first_run, (size_t)(nsec + 1) * 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipMemcpyAsync(dense.data(), d_dense, dense.size() * 4, hipMemcpyDeviceToHost, st));
-  BWTC_HIP_TRY(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, st));
+  // everything the host needs, into page-locked memory with two copies and one wait (copies into
+  // pageable vectors are staged by the runtime one after the other, the GPU idle in between)
+  const u64 sec_words = 2048 + 65536;                 // section starts, first runs, counts, runs per symbol
+  const u64 dense_words = (u64)nsec * kLenDense;
+  // ... and the head of the overflow list with them: how long it is is only known afterwards, and a
+  // second round trip for a few thousand long runs cost half a millisecond
+  const u32 over_head = std::min<u32>(over_cap, 1u << 16);
+  int rcs = e.reserve_stats((sec_words + dense_words + 2ull * over_head) * 4);
+  if (rcs) return rcs;
+  u32* h_sec = reinterpret_cast<u32*>(e.h_stats);
+  u32* h_dense = h_sec + sec_words;
+  u32* h_osec = h_dense + dense_words;
+  u32* h_olen = h_osec + over_head;
+  BWTC_HIP_TRY(hipMemcpyAsync(h_sec, d_sec, sec_words * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_dense, d_dense, dense_words * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_osec, d_over_sec, (size_t)over_head * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_olen, d_over_len, (size_t)over_head * 4, hipMemcpyDeviceToHost, st));
+  const auto tq = std::chrono::steady_clock::now();
+  if (while_waiting) (*while_waiting)();              // the GPU has a millisecond of scanning to do
+  const auto tw0 = std::chrono::steady_clock::now();
   BWTC_HIP_TRY(e.wait());
-  const u32 n_runs = e.h_small[0];
+  const auto tw1 = std::chrono::steady_clock::now();
+  const u32 n_over = h_sec[1025];
+  std::memcpy(out->run_freqs.data(), h_sec + 2048, (size_t)nsec * 1024);
+  std::vector<u32> first(h_sec + 512, h_sec + 512 + nsec + 1);
+  const u32* dense = h_dense;
+  const u32 n_runs = h_sec[1024];
   if (n_runs == 0 || n_runs > size) return -3;
   if (n_over > over_cap) return -2;
   std::vector<u32> osec(n_over), olen(n_over);
-  if (n_over) {
+  if (n_over && n_over <= over_head) {
+    std::memcpy(osec.data(), h_osec, (size_t)n_over * 4);
+    std::memcpy(olen.data(), h_olen, (size_t)n_over * 4);
+  } else if (n_over) {
     BWTC_HIP_TRY(hipMemcpyAsync(osec.data(), d_over_sec, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipMemcpyAsync(olen.data(), d_over_len, (size_t)n_over * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(e.wait());
   }
   BWTC_HIP_TRY(hipGetLastError());
   out->first_run = first;
+  if (n_over && e.long_count.empty()) e.long_count.assign(kLongDirect, 0);
   std::vector<std::vector<u32> > long_runs(nsec);
   for (u32 i = 0; i < n_over; ++i) long_runs[osec[i]].push_back(olen[i]);
   for (u32 s = 0; s < nsec; ++s) {
@@ -672,15 +698,31 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
       const u32 c = dense[(size_t)s * kLenDense + l];
       if (c) d.push_back(std::make_pair(l, c));
     }
+    // long runs: counted through a direct table where they fit it, so that only the DISTINCT
+    // lengths are sorted (a text block has some ten thousand runs of 512 bytes and more, few
+    // hundred different lengths; sorting the runs themselves took half a millisecond per block)
     std::vector<u32>& lr = long_runs[s];
-    std::sort(lr.begin(), lr.end());
-    for (size_t i = 0; i < lr.size();) {
+    const size_t first_long = d.size();
+    std::vector<u32> rest;
+    for (size_t i = 0; i < lr.size(); ++i) {
+      if (lr[i] < kLongDirect) { if (e.long_count[lr[i]]++ == 0) d.push_back(std::make_pair(lr[i], 0u)); }
+      else rest.push_back(lr[i]);
+    }
+    for (size_t i = first_long; i < d.size(); ++i) { d[i].second = e.long_count[d[i].first]; e.long_count[d[i].first] = 0; }
+    std::sort(rest.begin(), rest.end());
+    for (size_t i = 0; i < rest.size();) {
       size_t j = i;
-      while (j < lr.size() && lr[j] == lr[i]) ++j;
-      d.push_back(std::make_pair(lr[i], (u32)(j - i)));
+      while (j < rest.size() && rest[j] == rest[i]) ++j;
+      d.push_back(std::make_pair(rest[i], (u32)(j - i)));
       i = j;
     }
+    std::sort(d.begin() + first_long, d.end());
   }
+  if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "run statistics: queued in %.2f ms, hook %.2f ms, waited %.2f ms, %u long runs, tables read in %.2f ms\n",
+                 std::chrono::duration<double, std::milli>(tq - t_in).count(), std::chrono::duration<double, std::milli>(tw0 - tq).count(),
+                 std::chrono::duration<double, std::milli>(tw1 - tw0).count(), n_over,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
   return 0;
 }
 

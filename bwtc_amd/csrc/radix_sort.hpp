@@ -130,9 +130,11 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     bool ok = slot < tile_n;
     k[e] = ok ? kin[tile_base + slot] : (K)0;
     if (SKIP && k[e] == ~(K)0) ok = false;
-    // values_mode 1: first pass of a sort whose values are the items' own positions, nothing to
+    // values_mode 1 / 3: first pass of a sort whose values are the items' own positions (3: counted
+    // down from n - 1, the suffix sorter's descending slots), nothing to
     // read; 2: keys only
-    v[e] = (!ok || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot) : vin[tile_base + slot];
+    v[e] = (!ok || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot)
+                               : values_mode == 3 ? (u32)(n - 1u - (tile_base + slot)) : vin[tile_base + slot];
     if (SKIP) okm |= (ok ? 1u : 0u) << e;
   }
   __syncthreads();
@@ -319,7 +321,7 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
                                     K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
                                     int bit_lo = 0, bool values_are_positions = false, bool keys_only = false,
                                     u64 n_holes = 0, u8* plane0 = nullptr, u8* plane1 = nullptr,
-                                    bool plane0_ready = false) {
+                                    bool plane0_ready = false, bool values_descend = false) {
   K* kin = k0; K* kout = k1;
   u32* vin = v0; u32* vout = v1;
   if (n > 1 || n_holes) {
@@ -328,7 +330,8 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       const u64 n_in = first ? n + n_holes : n;
       const int skip = first && n_holes ? 1 : 0;
       const u32 ntiles = ceil_div(n_in, radix_tile<K>());
-      const int vmode = keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : 0;
+      // values_descend: item i's value is n - 1 - i (v0 need not be filled either)
+      const int vmode = keys_only ? 2 : (values_are_positions && shift == bit_lo) ? 1 : (values_descend && shift == bit_lo) ? 3 : 0;
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
       const bool have_plane = plane0 && (!first || (plane0_ready && !skip));   // the previous pass (or the producer) left this pass's digits
       const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's

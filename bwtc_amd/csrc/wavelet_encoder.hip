@@ -118,19 +118,25 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
   // streams are made below, their copy is left in flight.  (Blocks join the stream in order.)
   e.deferred_queue = true;                            // begun blocks join the stream later, or when they are needed
   int rc;
-  if (e.copy_job) {
+  // block i-2 joins the host pipeline while the GPU scans block i (its descriptors take the
+  // calling thread a few hundred microseconds to build)
+  int rc_queue = 0;
+  const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
+  const std::function<void()> join_earlier = [&e, &rc_queue, debug] {
+    if (!e.copy_job) return;
+    const auto t0 = std::chrono::steady_clock::now();
     std::shared_ptr<DeviceWaveletJob> ready;
     ready.swap(e.copy_job);
-    if (!ready->queued) {
-      rc = wavelet_encode_queue(e, ready->rank, e.wavelet_state, &e.wavelet_state);
-      if (rc) return rc;
-    }
-  }
+    if (!ready->queued) rc_queue = wavelet_encode_queue(e, ready->rank, e.wavelet_state, &e.wavelet_state);
+    if (debug) std::fprintf(stderr, "begin: block joined the host pipeline in %.2f ms (under the run scanner)\n",
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   std::shared_ptr<DeviceWaveletJob> prev = e.half_job;
   e.async_streams_copy = true;
-  rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket);   // scan(i), then streams(i-1)
+  rc = wavelet_encode_prepare(e, d_bwt, size, lf, n_lf, freqs, threads, out, out_cap, ticket, &join_earlier);   // scan(i), then streams(i-1)
   e.async_streams_copy = false;
   if (rc) return rc;
+  if (rc_queue) return rc_queue;
   if (prev && !prev->queued && !prev->copying) {      // no copy in flight (host route, empty block): it can join at once
     rc = wavelet_encode_queue(e, prev->rank, e.wavelet_state, &e.wavelet_state);
     if (rc) return rc;
@@ -177,7 +183,8 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
 // streams of THIS block are made later, see above; what is made here are the streams of the block
 // prepared before it.)
 int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
-                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket) {
+                           const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket,
+                           const std::function<void()>* while_scanning) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
   // bounded number of blocks under way; only ..._end frees a place, so waiting here could never help
   if (e.jobs.size() >= e.max_inflight) return -6;
@@ -198,8 +205,11 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
   if (rc) return rc;
   job.run_buf = e.next_run_buf;
   e.next_run_buf ^= 1;
-  rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st, e.d_run_start[job.run_buf], e.d_run_sym[job.run_buf]);
+  const bool debug_t = std::getenv("BWTC_HIP_DEBUG") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  rc = wavelet_section_stats_device(e, d_bwt, size, freqs, &st, e.d_run_start[job.run_buf], e.d_run_sym[job.run_buf], while_scanning);
   if (rc) return rc;
+  const auto tp1 = std::chrono::steady_clock::now();
   const u32 nsec = (u32)st.sections.size();
   rec.push_back((uint8_t)(nsec == 256 ? 0 : nsec));
   for (u32 s = 0; s < nsec; ++s) bwtc::utils::packInteger(st.sections[s], rec);
@@ -224,8 +234,13 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
     job.plan_future = std::async(std::launch::async, [jp, want_plan] { return want_plan && bwtc::wavelet::planStreams(jp->host_secs, &jp->plan); });
   }
   // the block prepared before this one: its streams, now that its plan has had the time of a transform
+  const auto tp2 = std::chrono::steady_clock::now();
   rc = wavelet_finish_pending_half(e, e.async_streams_copy);
   if (rc) return rc;
+  if (debug_t)
+    std::fprintf(stderr, "prepare: run scanner + statistics %.2f ms, planner started in %.2f ms, streams of the previous block %.2f ms\n",
+                 std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp2).count());
   e.half_job = jobp;
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;

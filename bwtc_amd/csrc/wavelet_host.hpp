@@ -60,7 +60,7 @@ constexpr uint32_t kStepGapShift = 1;      //   bit 1 = gap flag (symbol-tree st
 constexpr uint32_t kStepLeafShift = 2;     //   bits 2..9 = rank of the symbol leaf (integer steps),
 constexpr uint32_t kStepGroupShift = 10;   //   bits 10..31 = group number (block-wide)
 constexpr uint32_t kMaxGroups = 1u << 22;
-constexpr uint32_t kLenDense = 4096;       // run lengths below this are looked up in a dense table
+constexpr uint32_t kLenDense = 512;        // run lengths below this are looked up in a dense table (uploaded with every block: 4 KiB per section)
 
 enum GroupType { kRoot = 0, kBothLeaves = 1, kLeftLeaf = 2, kInner = 3, kInteger = 4 };
 

@@ -28,6 +28,9 @@
 #include "scan.hpp"
 #include "wavelet_host.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -345,12 +348,23 @@ int BwtEngine::reserve_wavelet(u64 device_bytes, u64 host_bytes) {
   return 0;
 }
 
+int BwtEngine::reserve_stats(u64 bytes) {
+  if (bytes <= h_stats_bytes) return 0;
+  if (h_stats) (void)hipHostFree(h_stats);
+  h_stats = nullptr; h_stats_bytes = 0;
+  const u64 want = align_up(bytes + bytes / 8, 1u << 16);
+  BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stats), want, hipHostMallocDefault));
+  h_stats_bytes = want;
+  return 0;
+}
+
 // Runs of the block are in d_run_start / d_run_sym as wavelet_section_stats_device left them.  On success coded_pos has plan.group_type.size() + 1 entries and `codes` holds the
 // packed elements.
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
                            PinnedBytes* codes, bool async_copy) {
   hipStream_t st = e.stream;
+  const auto t_entry = std::chrono::steady_clock::now();
   const u32 nsec = (u32)plan.sections.size();
   const u32 n_groups = (u32)plan.group_type.size();
   if (nsec == 0 || nsec > 256 || first_run.size() != nsec + 1 || n_runs == 0) return -1;
@@ -386,7 +400,8 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u64 n_tiles_cap = (u64)ceil_div(cap, kWtTile) + 1;
   const u64 o_tile = take(n_tiles_cap * 4);
   const u64 o_tile_partial = take(((u64)ceil_div(n_tiles_cap, kScanTile) + 1) * 4);
-  int rc = e.reserve_wavelet(at, tables_end);
+  const u64 h_gpos = align_up(tables_end, 256);            // the groups' coded positions come down into the pinned buffer too
+  int rc = e.reserve_wavelet(at, h_gpos + (n_groups + 1) * 4ull);
   if (rc) return rc;
   u8* base = static_cast<u8*>(e.d_wt);
   auto ptr32 = [&](u64 o) { return reinterpret_cast<u32*>(base + o); };
@@ -415,6 +430,9 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   t.pool = ptr32(o_pool);
   const u8* d_gtype = base + o_gtype;
 
+  if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "streams: tables of %llu bytes staged and queued %.2f ms after entry\n", (unsigned long long)tables_end,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
   // expand
   u32* d_cnt = ptr32(o_cnt);
   hipLaunchKernelGGL(k_wt_count, dim3(ceil_div((u64)n_runs + 1, kWtTPB * kWtCountE)), dim3(kWtTPB), 0, st,
@@ -445,9 +463,10 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   BWTC_HIP_TRY(hipMemsetAsync(base + o_packed, 0, ((u64)ceil_div(n, 16) + 1) * 4ull, st));
   hipLaunchKernelGGL(k_wt_compact_pack, dim3(tiles), dim3(kWtTPB), 0, st, d_code, n, d_tile, ptr32(o_packed));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_tile + tiles, 4, hipMemcpyDeviceToHost, st));
-  coded_pos->assign((size_t)n_groups + 1, 0);
-  BWTC_HIP_TRY(hipMemcpyAsync(coded_pos->data(), ptr32(o_gpos), n_groups * 4ull, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(e.h_wt + h_gpos, ptr32(o_gpos), n_groups * 4ull, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(e.wait());
+  coded_pos->assign((size_t)n_groups + 1, 0);
+  std::memcpy(coded_pos->data(), e.h_wt + h_gpos, n_groups * 4ull);
   const u32 n_coded = e.h_small[0];
   if (n_coded > n) return -3;
   const u32 words = ceil_div(n_coded, 16);
