@@ -183,15 +183,21 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
 //     b = log2(present) bits instead of g log2(sigma): 12 characters of that text take 48 key bits
 //     = 6 radix passes instead of 64 bits = 8 passes, and the order of the keys is the same
 //     (the numbering is monotone in the gram's value, which is its characters as a base-sigma
-//     number).  Four small passes: mark the grams that occur (byte map, plain stores: every
-//     writer stores the same 1), count and number them, then make the keys with one table lookup
-//     per text position.  Grams that start in the padding are the all-zero gram, which position
-//     n-1 (the terminator and padding) marks.
+//     number).  Small passes before the keys: mark the grams that occur in a byte map, pack it
+//     into a bitmap, and one workgroup turns that into a rank table (word, grams before it) --
+//     640 KB for the text alphabet's 4-grams, resident in L2, where a table of codes indexed by
+//     the gram's value spread the few ten thousand present grams over 3.5 MB of cache lines; the
+//     key maker numbers a gram with one 16-byte lookup and a popcount.  Grams that start in the
+//     padding are the all-zero gram, which position n-1 (the terminator and padding) marks.
 // ---------------------------------------------------------------------------------------
-constexpr u32 kGramMaxU = 1u << 22;         // largest gram universe (byte map 4 MiB, code table 16 MiB)
+constexpr u32 kGramMaxU = 1u << 22;         // largest gram universe: 64 Ki bitmap words, a table of 1 MiB
 constexpr u32 kGramTile = 4096;
 constexpr u32 kGramMinN = 1u << 22;         // smaller blocks keep the plain base-sigma key
 
+// Marks the grams that occur in a byte map: a look at the byte, a plain store of 1 where it is
+// still 0 (every writer stores the same value; a bitmap would need an atomic OR per new bit, and
+// with the lookups served by each CU's own L1 the same hot words were OR-ed from everywhere:
+// three times slower).
 __global__ __launch_bounds__(256) void k_gram_mark(const u8* __restrict__ T, const u8* __restrict__ lut,
                                                    u32 n, int g, u32 sigma, u32 top,
                                                    u8* __restrict__ present) {
@@ -234,53 +240,64 @@ __global__ __launch_bounds__(256) void k_gram_mark(const u8* __restrict__ T, con
   }
 }
 
-// present grams per 4096 values -> cnt[tile]
-__global__ __launch_bounds__(256) void k_gram_count(const u8* __restrict__ present, u32 U, u32* __restrict__ cnt) {
-  __shared__ u32 scratch[256 / kWave + 1];
-  const u32 o = blockIdx.x * kGramTile + 16u * threadIdx.x;
-  u32 c = 0;
-  if (o < U) {                                         // the map is allocated in whole tiles, zero beyond U
-    const uint4 v = *reinterpret_cast<const uint4*>(present + o);
-    c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);     // bytes are 0 or 1
+// 64 bytes of the map (each 0 or 1) -> one bitmap word
+__global__ __launch_bounds__(256) void k_gram_pack(const u8* __restrict__ present, u32 nwords,
+                                                   unsigned long long* __restrict__ bits) {
+  const u32 w = blockIdx.x * 256u + threadIdx.x;
+  if (w >= nwords) return;                              // the map is allocated and cleared in whole words
+  const uint4* p = reinterpret_cast<const uint4*>(present + 64ull * w);
+  unsigned long long out = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint4 v = p[q];
+    const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)     // four bytes b0..b3 -> b0 | b1 << 1 | b2 << 2 | b3 << 3 in the product's top byte
+      out |= (unsigned long long)((x[k] * 0x01020408u) >> 24 & 15u) << (16 * q + 4 * k);
   }
-  u32 total;
-  block_scan_excl_add<256>(c, scratch, &total);
-  if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+  bits[w] = out;
 }
 
-// exclusive scan of at most 1024 tile counts, in place; the total goes to *distinct
-__global__ __launch_bounds__(1024) void k_gram_scan(u32* __restrict__ cnt, u32 ntiles, u32* __restrict__ distinct) {
+// One workgroup: the bitmap's words with the number of present grams before each ->
+// table[w] = {bits low, bits high, grams before, 0}; the code of gram v is
+// table[v >> 6].z + popcount(bits below bit v & 63).  At most 65 536 words.
+__global__ __launch_bounds__(1024) void k_gram_table(const unsigned long long* __restrict__ present, u32 nwords,
+                                                     uint4* __restrict__ table, u32* __restrict__ distinct) {
   __shared__ u32 scratch[1024 / kWave + 1];
-  const u32 v = threadIdx.x < ntiles ? cnt[threadIdx.x] : 0u;
+  const u32 per = ((nwords + 1023u) / 1024u + 7u) & ~7u;   // consecutive words per thread (<= 64), in batches of eight loads
+  const u32 w0 = threadIdx.x * per;
+  u32 mine = 0;
+  for (u32 i = 0; i < per; i += 8u) {
+    unsigned long long b[8];
+#pragma unroll
+    for (u32 k = 0; k < 8u; ++k) b[k] = w0 + i + k < nwords ? present[w0 + i + k] : 0ull;
+#pragma unroll
+    for (u32 k = 0; k < 8u; ++k) mine += (u32)__popcll(b[k]);
+  }
   u32 total;
-  const u32 ex = block_scan_excl_add<1024>(v, scratch, &total);
-  if (threadIdx.x < ntiles) cnt[threadIdx.x] = ex;
+  u32 run = block_scan_excl_add<1024>(mine, scratch, &total);
+  for (u32 i = 0; i < per; i += 8u) {
+    unsigned long long b[8];
+#pragma unroll
+    for (u32 k = 0; k < 8u; ++k) b[k] = w0 + i + k < nwords ? present[w0 + i + k] : 0ull;
+#pragma unroll
+    for (u32 k = 0; k < 8u; ++k) {
+      if (w0 + i + k < nwords) table[w0 + i + k] = make_uint4((u32)b[k], (u32)(b[k] >> 32), run, 0u);
+      run += (u32)__popcll(b[k]);
+    }
+  }
   if (threadIdx.x == 0) *distinct = total;
 }
 
-// code[v] = number of present grams below v (for a gram that is absent: the code of the next present one)
-__global__ __launch_bounds__(256) void k_gram_codes(const u8* __restrict__ present, u32 U,
-                                                    const u32* __restrict__ tile_off, u32* __restrict__ code) {
-  __shared__ u32 scratch[256 / kWave + 1];
-  const u32 o = blockIdx.x * kGramTile + 16u * threadIdx.x;
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (o < U) v = *reinterpret_cast<const uint4*>(present + o);
-  const u32 w[4] = {v.x, v.y, v.z, v.w};
-  const u32 mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-  u32 total;
-  u32 run = tile_off[blockIdx.x] + block_scan_excl_add<256>(mine, scratch, &total);
-  if (o >= U) return;
-  u32 out[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { out[e] = run; run += (w[e >> 2] >> (8 * (e & 3))) & 1u; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<uint4*>(code + o + 4 * q) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+__device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v) {
+  const uint4 e = table[v >> 6];
+  const unsigned long long bits = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+  return e.z + (u32)__popcll(bits & ((1ull << (v & 63u)) - 1ull));
 }
 
 // keys of G grams of g characters, b bits per gram code; slots in descending suffix order as in k_make_keys
 __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T, const u8* __restrict__ lut,
-                                                        const u32* __restrict__ gcode,
+                                                        const uint4* __restrict__ gtable,
                                                         u64* __restrict__ keys, u32* __restrict__ idx, u32 n,
                                                         int g, int G, int b, u32 sigma, u32 top,
                                                         u8* __restrict__ plane) {
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     }
     u32 cd[5];
 #pragma unroll
-    for (int e = 0; e < 5; ++e) cd[e] = threadIdx.x + 256u * e < span ? gcode[v[e]] : 0u;
+    for (int e = 0; e < 5; ++e) cd[e] = threadIdx.x + 256u * e < span ? gram_code(gtable, v[e]) : 0u;
 #pragma unroll
     for (int e = 0; e < 5; ++e) if (threadIdx.x + 256u * e < span) s_g[threadIdx.x + 256u * e] = cd[e];
   }
@@ -1226,18 +1243,18 @@ int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan*
   u64 U = plan.sigma;
   while (U * plan.sigma <= kGramMaxU && U * plan.sigma <= (u64)cap / 2 && g < 32) { U *= plan.sigma; ++g; }
   if (g < 2) return 0;
-  const u32 ntiles = ceil_div((u32)U, kGramTile);          // <= 1024
-  u8* present = reinterpret_cast<u8*>(d_SA);
-  u32* code = d_rank;
+  const u32 nwords = ceil_div((u32)U, 64u);                // <= 65536
+  u8* present = reinterpret_cast<u8*>(d_SA);               // byte map, then (behind it) the bitmap
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(present + 64ull * nwords);
+  uint4* table = reinterpret_cast<uint4*>(d_rank);
   u32 top = 1;
   for (int t = 1; t < g; ++t) top *= plan.sigma;
-  BWTC_HIP_TRY(hipMemsetAsync(present, 0, (u64)ntiles * kGramTile, st));
+  BWTC_HIP_TRY(hipMemsetAsync(present, 0, 64ull * nwords, st));
   hipLaunchKernelGGL(k_gram_mark, dim3(std::min<u32>(ceil_div(n, kGramTile), 4096u)), dim3(256), 0, st,
                      (const u8*)d_T, d_lut, n, g, plan.sigma, top, present);
-  hipLaunchKernelGGL(k_gram_count, dim3(ntiles), dim3(256), 0, st, (const u8*)present, (u32)U, d_aggA);
-  hipLaunchKernelGGL(k_gram_scan, dim3(1), dim3(1024), 0, st, d_aggA, ntiles, d_small + kSmallGram);
-  hipLaunchKernelGGL(k_gram_codes, dim3(ntiles), dim3(256), 0, st, (const u8*)present, (u32)U,
-                     (const u32*)d_aggA, code);
+  hipLaunchKernelGGL(k_gram_pack, dim3(ceil_div(nwords, 256u)), dim3(256), 0, st, (const u8*)present, nwords, bits);
+  hipLaunchKernelGGL(k_gram_table, dim3(1), dim3(1024), 0, st, (const unsigned long long*)bits, nwords, table,
+                     d_small + kSmallGram);
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallGram, d_small + kSmallGram, 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(wait());
   const u32 distinct = h_small[kSmallGram];
@@ -1316,7 +1333,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       short_len = (u32)(gp.g * gp.G);
       h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const u32*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
+                         (const uint4*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
     } else {
       u64 top = 1;
       for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
