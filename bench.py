@@ -233,6 +233,26 @@ def main():
     drain_ms = 1e3 * (time.perf_counter() - t0)
     comp_bytes = comp[0]
 
+    # the spec peak beside what a plain device copy reaches on this box
+    copy_gbs = None
+    if rank == 0:
+        try:
+            nb = 1 << 30
+            a = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b.copy_(a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9       # bytes read + bytes written
+            del a, b
+        except Exception:                                                    # never a reason to lose the bench line
+            copy_gbs = None
+
     if rank == 0:
         kt = ctx.kernel_timers()
         st = ctx.stats()
@@ -256,7 +276,10 @@ def main():
             whole_bytes = st.n * (97.0 + 100.0 * r_eff)
             roof = {"bound": "hbm", "kernel": "k_radix_scatter<u64> (+<u32> passes of the suffix sorter)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "device_copy_GBps": round(copy_gbs, 1) if copy_gbs else None,
+                    "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                    "traffic": traffic,
                     "traffic_source": traffic_src,
                     "launches": kt["scatter_launches"],
                     "avg_launch_us": round(1e3 * kt["scatter_ms"] / kt["scatter_launches"], 1),
