@@ -140,7 +140,8 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
                                                    const u8* __restrict__ lut,
                                                    K* __restrict__ keys, u32* __restrict__ idx,
-                                                   u32 n, int k, u32 sigma, K top, u8* __restrict__ plane) {
+                                                   u32 n, int k, u32 sigma, K top, u8* __restrict__ plane,
+                                                   int idx_hi) {
   // A workgroup makes 1024 consecutive slots.  The dense codes of its stretch of T are staged in
   // LDS once; a thread builds four consecutive suffixes' keys -- the first from k characters, the
   // next three by rolling one character out and one in (top = sigma^(k-1)), k+3 LDS bytes instead
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(256) void k_make_keys(const u8* __restrict__ T,
   }
   __syncthreads();
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
-    keys[J0 + j] = s_key[j];
+    K key = s_key[j];
+    // idx_hi: the upper bits of the suffix number ride in bits 48.. of the (at most 48-bit) key
+    if (sizeof(K) == 8 && idx_hi) key |= (K)((u64)((n - 1u - (J0 + j)) >> 16) << 48);
+    keys[J0 + j] = key;
     if (idx) idx[J0 + j] = n - 1u - (J0 + j);        // nullptr: the sort's first pass makes the values up
     if (plane) plane[J0 + j] = (u8)s_key[j];         // the first radix pass's digits (radix_sort.hpp, planes)
   }
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
                                                         const uint4* __restrict__ gtable,
                                                         u64* __restrict__ keys, u32* __restrict__ idx, u32 n,
                                                         int g, int G, int b, u32 sigma, u32 top,
-                                                        u8* __restrict__ plane) {
+                                                        u8* __restrict__ plane, int idx_hi) {
   constexpr u32 kTile = 1024;
   __shared__ u8 s_lut[256];
   __shared__ u8 s_code[kTile + 128];
@@ -343,7 +347,9 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
   }
   __syncthreads();
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
-    keys[J0 + j] = s_key[j];
+    u64 key = s_key[j];
+    if (idx_hi) key |= (u64)((n - 1u - (J0 + j)) >> 16) << 48;
+    keys[J0 + j] = key;
     if (idx) idx[J0 + j] = n - 1u - (J0 + j);
     if (plane) plane[J0 + j] = (u8)s_key[j];
   }
@@ -398,21 +404,32 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loaded on their own.
 template <typename K, bool INIT>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
-                                         u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
+                                         u32 m, u32 n, u32 short_len, K kmask, u32 split, u32 wbase, u32 lane,
                                          RrMasks<K, INIT>& f) {
+  // split (initial ranking of 64-bit keys only): a suffix number's upper bits sit in bits 48.. of
+  // its key and idx[] holds 16-bit lower halves (the sort moved 10 bytes per item instead of 12)
+  const unsigned short* idx16 = reinterpret_cast<const unsigned short*>(idx);
+  auto suffix_of = [&](K kraw, u32 p) -> u32 {
+    if (sizeof(K) == 8 && split) return ((u32)((u64)kraw >> 48) << 16) | (u32)idx16[p];
+    return idx[p];
+  };
   K kc[kRrE];
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
     const u32 p = wbase + e * kWave + lane;
     const bool ok = p < m;
     const K kraw = ok ? key[p] : (K)0;
-    f.sfx[e] = ok ? idx[p] : 0u;
+    f.sfx[e] = ok ? suffix_of(kraw, p) : 0u;
     f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw >> 56) : 0u;
     kc[e] = kraw & kmask;
   }
   K before = (K)0, after = (K)0;          // slots wbase - 1 and wbase + chunk (where they exist)
   u32 ibefore = 0u;
-  if (lane == 0 && wbase > 0 && wbase < m) { before = key[wbase - 1] & kmask; if (INIT) ibefore = idx[wbase - 1]; }
+  if (lane == 0 && wbase > 0 && wbase < m) {
+    const K braw = key[wbase - 1];
+    before = braw & kmask;
+    if (INIT) ibefore = suffix_of(braw, wbase - 1);
+  }
   if (lane == kWave - 1 && wbase + (u32)kRrChunk < m) after = key[wbase + kRrChunk] & kmask;
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
@@ -442,7 +459,7 @@ __device__ __forceinline__ u32 top_bit(u64 v) { return 63u - (u32)__clzll((unsig
 template <typename K, bool INIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
                                                           const u32* __restrict__ idx, u32 m,
-                                                          u32 n, u32 short_len, K kmask,
+                                                          u32 n, u32 short_len, K kmask, u32 split,
                                                           u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
                                                           u32* __restrict__ aggC) {
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
+  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, split, wbase, lane, f);
   u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
@@ -560,7 +577,7 @@ struct RrEmit {
 template <typename K, bool INIT, int MODE, int EMIT>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
-    u32 n, u32 short_len, K kmask, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
+    u32 n, u32 short_len, K kmask, u32 split, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
     u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out,
     u32* __restrict__ pair_s, u32* __restrict__ pair_r, RrEmit em) {
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
+  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, split, wbase, lane, f);
   {
     u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
@@ -960,6 +977,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_WINDOW_BITS") && std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")) > 0)
       window_bits = std::min(24, std::atoi(std::getenv("BWTC_HIP_WINDOW_BITS")));
     digit_planes = !(std::getenv("BWTC_HIP_PLANES") && std::getenv("BWTC_HIP_PLANES")[0] == '0');
+    split_index = !(std::getenv("BWTC_HIP_SPLIT_INDEX") && std::getenv("BWTC_HIP_SPLIT_INDEX")[0] == '0');
     if (const char* gr = std::getenv("BWTC_HIP_GRAMS")) {       // 0: base-sigma keys only; N > 0: N grams per key
       gram_keys = gr[0] != '0';
       gram_count_override = std::atoi(gr);
@@ -1149,12 +1167,12 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
 // that hold ks / vs (free once the apply kernel has run).
 template <typename K, bool INIT>
 int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
-                         RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res) {
+                         RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split) {
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
   hipLaunchKernelGGL((k_rerank_reduce<K, INIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
-                     short_len, kmask, d_aggA, d_aggB, d_aggC);
+                     short_len, kmask, split, d_aggA, d_aggB, d_aggC);
   hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, counts);
   // how much stays active decides the route, so the counts are read before the apply kernel
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
@@ -1175,7 +1193,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
 
 #define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
   hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,      \
-                     (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out, \
+                     (const u32*)rb.aglob, m, n, short_len, kmask, split, d_aggA, d_aggB, d_aggC, d_rank, sa_out, \
                      AIDX, rb.aglob_next, d_GRP, PS, PR, re)
   if (dense) {
     u32* tri_key = reinterpret_cast<u32*>(recA);
@@ -1332,27 +1350,41 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       key_bits = gp.b * gp.G;
       short_len = (u32)(gp.g * gp.G);
       h = (u64)short_len;
+    }
+    // Keys of at most 48 bits leave room for the upper bits of the suffix number: the passes of
+    // the initial sort then carry (u64 key, u16 low half) = 10 bytes per item instead of 12.
+    const int split = (split_index && implied_idx && key_bits <= 48 && n <= (1u << 29)) ? 1 : 0;
+    if (gp.G > 0) {
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const uint4*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane);
+                         (const uint4*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split);
     } else {
       u64 top = 1;
       for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
       hipLaunchKernelGGL(k_make_keys<u64>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                         idx_out, n, plan.k, plan.sigma, top, key_plane);
+                         idx_out, n, plan.k, plan.sigma, top, key_plane, split);
     }
     u64* ks = nullptr; u32* vs = nullptr;
-    sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
+    if (split) {
+      unsigned short* vs16 = nullptr;
+      radix_sort_pairs<u64, unsigned short>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
+                                            n, key_bits, d_table, d_partial, stream, &ks, &vs16, &probe, 0, false, false, 0,
+                                            digit_planes ? d_P0 : nullptr, digit_planes ? d_P1 : nullptr,
+                                            key_plane != nullptr, true);
+      vs = reinterpret_cast<u32*>(vs16);
+    } else {
+      sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
+    }
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
     rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
-    rc = rank_step<u64, true>(ks, vs, n, n, short_len, ~0ull, rb, re, emit, h, &res);
+    rc = rank_step<u64, true>(ks, vs, n, n, short_len, split ? ((1ull << 48) - 1ull) : ~0ull, rb, re, emit, h, &res, (u32)split);
   } else {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
     u32 top = 1;
     for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
     hipLaunchKernelGGL(k_make_keys<u32>, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut, ka,
-                       idx_out, n, plan.k, plan.sigma, top, key_plane);
+                       idx_out, n, plan.k, plan.sigma, top, key_plane, 0);
     u32* ks = nullptr; u32* vs = nullptr;
     sort_pairs<u32>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
     BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));

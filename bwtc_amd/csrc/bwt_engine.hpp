@@ -193,10 +193,11 @@ struct BwtEngine {
   struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; };
   template <typename K, bool INIT>
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
-                struct RrEmit re, bool emit, u64 h_next, RankResult* res);
+                struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
+  bool split_index = true;   // BWTC_HIP_SPLIT_INDEX=0: the initial sort always carries 32-bit suffix numbers
   bool gram_keys = true;     // BWTC_HIP_GRAMS=0: initial keys are always base-sigma numbers (no dense gram codes)
   int gram_count_override = 0;
   struct GramPlan { int g = 0, G = 0, b = 0; u32 top = 0; };

@@ -82,21 +82,23 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 // PLANE: the pass also writes plane[dst] = the item's NEXT digit, one byte per item in output
 // order, so that the next pass's histogram kernel reads 1 byte per item instead of the key.
 // KEYS: keys only (no values staged: half the LDS of a 32-bit pair tile, twice the workgroups per CU).
-template <typename K, bool SKIP, bool PLANE, bool KEYS>
+// V: the values' type in memory, u32 or u16 (the suffix sorter's initial sort keeps the upper bits
+// of a suffix number in spare bits of its key, so that a pass moves 10 bytes per item instead of 12).
+template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
-    const K* __restrict__ kin, const u32* __restrict__ vin, K* __restrict__ kout,
-    u32* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
+    const K* __restrict__ kin, const V* __restrict__ vin, K* __restrict__ kout,
+    V* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
     u8* __restrict__ plane) {
   constexpr int E = RadixCfg<K>::E;
   constexpr int TILE = kRadixTPB * E;
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
   // tile slots, so the reorder staging (keys, then values) reuses their bytes; that keeps
   // the (u64,u32) kernel at 50 KiB = three workgroups per CU.
-  constexpr int kStageBytes = TILE * (int)(sizeof(K) + (KEYS ? 0 : sizeof(u32)));
+  constexpr int kStageBytes = TILE * (int)(sizeof(K) + (KEYS ? 0 : sizeof(V)));
   constexpr int kCntBytes = kRadixWaves * kRadixBins * (int)sizeof(u32);
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStageBytes > kCntBytes ? kStageBytes : kCntBytes];
   K* s_key = reinterpret_cast<K*>(s_raw);
-  u32* s_val = reinterpret_cast<u32*>(s_raw + TILE * sizeof(K));
+  V* s_val = reinterpret_cast<V*>(s_raw + TILE * sizeof(K));
   u32 (*s_cnt)[kRadixBins] = reinterpret_cast<u32 (*)[kRadixBins]>(s_raw);
   __shared__ u32 s_base[kRadixBins];               // first tile slot of each digit
   __shared__ u32 s_gofs[kRadixBins];               // global base minus tile slot
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   for (int e = 0; e < E; ++e) {
     if (BWTC_EXISTS(e)) {
       s_key[r[e]] = k[e];
-      if (!KEYS) s_val[r[e]] = v[e];
+      if (!KEYS) s_val[r[e]] = (V)v[e];
     }
   }
 #undef BWTC_EXISTS
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
       // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
       // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
       kout[dst[e]] = kk[e];
-      if (!KEYS) vout[dst[e]] = vv[e];
+      if (!KEYS) vout[dst[e]] = (V)vv[e];
       if (PLANE) plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
     }
   }
@@ -315,15 +317,15 @@ struct ScatterProbe {
 // plane0 / plane1 (optional, n bytes each, 16-byte aligned): digit planes; every pass but the
 // last leaves the next pass's digits there and the next histogram is taken from them.
 // plane0_ready: the producer of the keys already left the first pass's digits in plane0.
-template <typename K>
-static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits,
+template <typename K, typename V = u32>
+static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits,
                                     u32* table, u32* partial, hipStream_t st,
-                                    K** k_sorted, u32** v_sorted, ScatterProbe* probe = nullptr,
+                                    K** k_sorted, V** v_sorted, ScatterProbe* probe = nullptr,
                                     int bit_lo = 0, bool values_are_positions = false, bool keys_only = false,
                                     u64 n_holes = 0, u8* plane0 = nullptr, u8* plane1 = nullptr,
                                     bool plane0_ready = false, bool values_descend = false) {
   K* kin = k0; K* kout = k1;
-  u32* vin = v0; u32* vout = v1;
+  V* vin = v0; V* vout = v1;
   if (n > 1 || n_holes) {
     bool first = true;
     for (int shift = bit_lo; shift < nbits || (first && n_holes); shift += kRadixBits) {
@@ -340,15 +342,15 @@ static inline void radix_sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int n
       else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr)
+#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr)
       if (keys_only) { if (make_plane) BWTC_SCATTER(false, true, true); else BWTC_SCATTER(false, false, true); }   // never with holes
       else if (skip) { if (make_plane) BWTC_SCATTER(true, true, false); else BWTC_SCATTER(true, false, false); }
       else { if (make_plane) BWTC_SCATTER(false, true, false); else BWTC_SCATTER(false, false, false); }
 #undef BWTC_SCATTER
       { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
-      if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(u32))));
+      if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(V))));
       K* tk = kin; kin = kout; kout = tk;
-      u32* tv = vin; vin = vout; vout = tv;
+      V* tv = vin; vin = vout; vout = tv;
       first = false;
     }
   }

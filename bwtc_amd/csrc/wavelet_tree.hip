@@ -446,7 +446,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
                      d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), base + o_code);
   // sort by (group, leaf rank), keys only; the bit and the gap flag ride along in the word
   u32* ks = nullptr; u32* vs = nullptr;
-  radix_sort_pairs<u32>(ptr32(o_k0), ptr32(o_k1), nullptr, nullptr, n, key_bits,
+  radix_sort_pairs<u32, u32>(ptr32(o_k0), ptr32(o_k1), (u32*)nullptr, (u32*)nullptr, n, key_bits,
                         ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, false, true,
                         0, base + o_code, base + o_compact, true);     // planes: both byte arrays are free until the select kernel
   // select + compact + pack
