@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
                                                                 u32 ntiles) {
   constexpr int E = RadixCfg<K>::E;
   constexpr int HALF = kRadixTPB / 2;
-  constexpr int B = 2 * E;                          // bytes of the tile per thread (16 or 32)
-  static_assert(B % 16 == 0, "whole 16-byte loads");
+  constexpr int B = 2 * E;                          // bytes of the tile per thread (8, 16 or 32)
+  static_assert(B == 8 || B % 16 == 0, "8-byte or whole 16-byte loads");
   __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * 16];
   {
     uint4* z = reinterpret_cast<uint4*>(&hist[0][0]);
@@ -243,12 +243,18 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
     const u64 base = (u64)tile * (kRadixTPB * E) + (u64)t * B;
     const u32 copy = t & 15u;
     u32* h = hist[half];
-    if (base + B <= n) {
-      uint4 q[B / 16];
+    if (B == 8 && base + B <= n) {
+      const uint2 q = *reinterpret_cast<const uint2*>(plane + base);
+      const u32 w[2] = {q.x, q.y};
 #pragma unroll
-      for (int i = 0; i < B / 16; ++i) q[i] = *reinterpret_cast<const uint4*>(plane + base + 16 * i);
+      for (int b = 0; b < 8; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+    } else if (base + B <= n) {
+      constexpr int Q = B >= 16 ? B / 16 : 1;
+      uint4 q[Q];
 #pragma unroll
-      for (int i = 0; i < B / 16; ++i) {
+      for (int i = 0; i < Q; ++i) q[i] = *reinterpret_cast<const uint4*>(plane + base + 16 * i);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
         const u32 w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
 #pragma unroll
         for (int b = 0; b < 16; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
