@@ -162,7 +162,7 @@ def main():
     bound = ctx.compress_bound(size)
     d_comp = ctx.dmalloc(bound) if coder == "H" else None
     ring = [np.empty(bound, np.uint8) for _ in range(depth + 1)] if coder == "B" else []
-    h_rec = np.empty(bound, np.uint8) if coder == "H" else None
+    h_rec = ctx.host_alloc(bound) if coder == "H" else None      # page-locked: the record comes down in one DMA
 
     pending = []                 # tickets of blocks under way ('B')
     comp = [0]
