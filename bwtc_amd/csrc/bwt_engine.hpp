@@ -24,6 +24,7 @@
 #include <map>
 #include <memory>
 #include <utility>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -34,19 +35,27 @@ struct RrEmit;
 // ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
 // Page-locked host bytes: the packed streams are copied from the device straight into the
 // block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
+// Where the system will not lock that many pages (96 blocks under way hold 12 GB per context) the
+// bytes are ordinary memory: the copy is then staged by the runtime, slower but the same bytes.
 class PinnedBytes {
  public:
-  PinnedBytes() : p_(nullptr), n_(0) {}
-  ~PinnedBytes() { if (p_) (void)hipHostFree(p_); }
+  PinnedBytes() : p_(nullptr), n_(0), locked_(true) {}
+  ~PinnedBytes() { release(); }
   PinnedBytes(const PinnedBytes&) = delete;
   PinnedBytes& operator=(const PinnedBytes&) = delete;
-  void swap(PinnedBytes& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); }
+  void swap(PinnedBytes& o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(locked_, o.locked_); }
   bool reserve(size_t n) {
     if (n <= n_) return true;
-    if (p_) (void)hipHostFree(p_);
-    p_ = nullptr; n_ = 0;
+    release();
     void* q = nullptr;
-    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) != hipSuccess) return false;
+    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) == hipSuccess) {
+      locked_ = true;
+    } else {
+      (void)hipGetLastError();                     // not an error of the caller's stream
+      q = std::malloc(n + n / 8);
+      if (!q) return false;
+      locked_ = false;
+    }
     p_ = static_cast<uint8_t*>(q);
     n_ = n + n / 8;
     return true;
@@ -54,8 +63,13 @@ class PinnedBytes {
   uint8_t* data() { return p_; }
   size_t size() const { return n_; }
  private:
+  void release() {
+    if (p_) { if (locked_) (void)hipHostFree(p_); else std::free(p_); }
+    p_ = nullptr; n_ = 0;
+  }
   uint8_t* p_;
   size_t n_;
+  bool locked_;
 };
 
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
