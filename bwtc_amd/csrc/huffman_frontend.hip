@@ -32,21 +32,42 @@ constexpr int kRunE = 16;
 constexpr int kRunTile = kRunTPB * kRunE;      // bytes per workgroup
 
 // head bits of the 16 bytes starting at p0 (bit e = byte p0+e starts a run)
+// a thread's sixteen bytes and the byte before them, loaded ahead of their use
+struct RunBytes { uint4 v; u32 prev; bool fast; };
+__device__ __forceinline__ RunBytes run_bytes_fetch(const u8* __restrict__ bwt, u32 size, u32 p0, bool aligned) {
+  RunBytes rb;
+  rb.v = make_uint4(0, 0, 0, 0); rb.prev = 0;
+  rb.fast = aligned && p0 < size && p0 + kRunE <= size;
+  if (rb.fast) { rb.v = *reinterpret_cast<const uint4*>(bwt + p0); rb.prev = p0 ? bwt[p0 - 1] : 0u; }
+  return rb;
+}
+
+// pre: the bytes if they were fetched ahead (and could be: whole aligned rows).  plain: the caller
+// knows that no section starts inside the tile, plain_first is then the first section after it.
 __device__ __forceinline__ u32 run_head_bits(const u8* __restrict__ bwt, u32 size, u32 p0,
                                              const u32* __restrict__ s_sec, u32 nsec,
-                                             u32* first_sec, u8 (&b)[kRunE], bool aligned) {
+                                             u32* first_sec, u8 (&b)[kRunE], bool aligned,
+                                             const RunBytes* pre = nullptr, bool plain = false, u32 plain_first = 0) {
   u32 heads = 0;
   *first_sec = nsec;
   if (p0 >= size) return 0;
-  u8 prev = p0 ? bwt[p0 - 1] : 0;
-  if (aligned && p0 + kRunE <= size) {
-    const uint4 v = *reinterpret_cast<const uint4*>(bwt + p0);
-    const u32 w[4] = {v.x, v.y, v.z, v.w};
+  u8 prev;
+  if (pre && pre->fast) {
+    prev = (u8)pre->prev;
+    const u32 w[4] = {pre->v.x, pre->v.y, pre->v.z, pre->v.w};
 #pragma unroll
     for (int e = 0; e < kRunE; ++e) b[e] = (u8)(w[e >> 2] >> (8 * (e & 3)));
   } else {
+    prev = p0 ? bwt[p0 - 1] : 0;
+    if (aligned && p0 + kRunE <= size) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bwt + p0);
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int e = 0; e < kRunE; ++e) b[e] = (p0 + e < size) ? bwt[p0 + e] : 0;
+      for (int e = 0; e < kRunE; ++e) b[e] = (u8)(w[e >> 2] >> (8 * (e & 3)));
+    } else {
+#pragma unroll
+      for (int e = 0; e < kRunE; ++e) b[e] = (p0 + e < size) ? bwt[p0 + e] : 0;
+    }
   }
 #pragma unroll
   for (int e = 0; e < kRunE; ++e) {
@@ -54,6 +75,7 @@ __device__ __forceinline__ u32 run_head_bits(const u8* __restrict__ bwt, u32 siz
     if (p < size && (p == 0 || b[e] != prev)) heads |= 1u << e;
     prev = b[e];
   }
+  if (plain) { *first_sec = plain_first; return heads; }
   // section starts inside [p0, p0 + 16): binary search for the first one >= p0
   u32 lo = 0, hi = nsec;
   while (lo < hi) { u32 mid = (lo + hi) >> 1; if (s_sec[mid] < p0) lo = mid + 1; else hi = mid; }
@@ -113,7 +135,7 @@ struct RunStatsOut {
 
 template <bool GAMMA, bool DIST>
 __device__ __forceinline__ void count_run(const RunStatsOut& o, u32 s, u32 sym, u32 len, bool in_s0,
-                                          u32* hist, u32* s_len, u32 copy, u32& gsum) {
+                                          u32* hist, u32* s_len, u32 copy, u32& gsum, u32& n_len1, u32& n_len2) {
   if (in_s0) atomicAdd(&hist[sym * 8u + copy], 1u);
   else atomicAdd(&o.run_freqs[s * 256u + sym], 1u);
   if (GAMMA) {
@@ -122,7 +144,11 @@ __device__ __forceinline__ void count_run(const RunStatsOut& o, u32 s, u32 sym, 
     else atomicAdd(&o.gbits[s], (unsigned long long)g);
   }
   if (DIST) {
-    if (in_s0 && len < kLenLds) atomicAdd(&s_len[len], 1u);
+    // lengths 1 and 2 (four runs of five in text) are counted in registers: every lane adding to
+    // the one LDS word of length 1 is a 64-way conflict per instruction
+    if (in_s0 && len == 1u) ++n_len1;
+    else if (in_s0 && len == 2u) ++n_len2;
+    else if (in_s0 && len < kLenLds) atomicAdd(&s_len[len], 1u);
     else if (len < kLenDense) atomicAdd(&o.dense[(u64)s * kLenDense + len], 1u);
     else {
       const u32 slot = atomicAdd(o.over_count, 1u);
@@ -143,6 +169,10 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
   __shared__ u32 hist[256 * 8];               // runs per symbol of the section being accumulated, 8 copies
   __shared__ u32 s_len[kLenLds];
   __shared__ u32 s_g0;
+  // the tile's runs, gathered here and written out by consecutive lanes (a thread storing its own
+  // runs put some thirty partial-line requests on the memory system per instruction)
+  __shared__ u32 s_rstart[kRunTile];
+  __shared__ u8 s_rsym[kRunTile];
   if (threadIdx.x < nsec) s_sec[threadIdx.x] = sec_start[threadIdx.x];
   for (u32 i = threadIdx.x; i < 256 * 8; i += kRunTPB) hist[i] = 0;
   if (DIST) for (u32 i = threadIdx.x; i < kLenLds; i += kRunTPB) s_len[i] = 0;
@@ -163,12 +193,25 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
   const u32 tile_end = min(tile_begin + tiles_per_wg, ntiles);
   u32 acc_s = 0xFFFFFFFFu;                    // section the LDS statistics belong to
   const u32 copy = threadIdx.x & 7u;
+  // The bytes of the next tile and its place in run_start[] are fetched before the current tile is
+  // worked on, and the tile's section is found with uniform (scalar) loads: per tile the walk had
+  // a memory latency, sixteen dependent LDS reads of two per-thread searches and two barriers in a row.
+  RunBytes ahead = run_bytes_fetch(bwt, size, tile_begin * kRunTile + threadIdx.x * kRunE, aligned != 0);
+  u32 off_ahead = tile_begin < tile_end ? tile_off[tile_begin] : 0u;
   for (u32 tile = tile_begin; tile < tile_end; ++tile) {
     const u32 t0 = tile * kRunTile;
     const u32 p0 = t0 + threadIdx.x * kRunE;
+    const RunBytes mine = ahead;
+    const u32 my_off = off_ahead;
+    if (tile + 1 < tile_end) {
+      ahead = run_bytes_fetch(bwt, size, p0 + kRunTile, aligned != 0);
+      off_ahead = tile_off[tile + 1];
+    }
     // section of the tile's first byte: its runs are counted in LDS
     u32 s0;
-    { u32 lo = 0, hi = nsec; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_sec[mid] <= t0) lo = mid; else hi = mid; } s0 = lo; }
+    { u32 lo = 0, hi = nsec; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (sec_start[mid] <= t0) lo = mid; else hi = mid; } s0 = lo; }
+    // no section starts inside the tile (nearly always): the threads need not look for one
+    const bool plain = sec_start[s0] < t0 && (s0 + 1 >= nsec || sec_start[s0 + 1] >= t0 + (u32)kRunTile);
     __syncthreads();                          // the previous tile's LDS traffic is done
     if (s0 != acc_s) {
       if (acc_s != 0xFFFFFFFFu) { flush(acc_s); __syncthreads(); }
@@ -176,14 +219,14 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
     }
     u8 b[kRunE];
     u32 sec;                                  // first section start >= p0
-    const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0);
+    const u32 heads = run_head_bits(bwt, size, p0, s_sec, nsec, &sec, b, aligned != 0, &mine, plain, s0 + 1u);
     s_fh[threadIdx.x] = heads ? p0 + (u32)__builtin_ctz(heads) : 0xFFFFFFFFu;
     u32 total;
-    u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + tile_off[tile];
+    u32 r = block_scan_excl_add<kRunTPB>(__popc(heads), scr, &total) + my_off;
     // (block_scan's barriers also publish s_fh)
     const u32 s0_end = s0 + 1 < nsec ? s_sec[s0 + 1] : 0xFFFFFFFFu;
     u32 cur = sec ? sec - 1u : 0u;            // section of the byte before the next section start
-    u32 gsum = 0;
+    u32 gsum = 0, n_len1 = 0, n_len2 = 0;
     u32 open_run = kNoRun;
     if (heads) {
       // end of the thread's last run: the first head of a later thread, if the tile has one
@@ -194,12 +237,12 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
       for (int e = 0; e < kRunE; ++e) {
         const u32 p = p0 + e;                 // (heads has no bits at or beyond size)
         if ((heads >> e) & 1u) {
-          run_start[r] = p;
-          run_sym[r] = b[e];
+          s_rstart[r - my_off] = p;
+          s_rsym[r - my_off] = b[e];
           if (sec < nsec && s_sec[sec] == p) { first_run[sec] = r; cur = sec; ++sec; }
           rest &= rest - 1u;                  // heads after this one
           const u32 nxt = rest ? p0 + (u32)__builtin_ctz(rest) : next_after;
-          if (nxt != 0xFFFFFFFFu) count_run<GAMMA, DIST>(o, cur, b[e], nxt - p, p < s0_end && cur == s0, hist, s_len, copy, gsum);
+          if (nxt != 0xFFFFFFFFu) count_run<GAMMA, DIST>(o, cur, b[e], nxt - p, p < s0_end && cur == s0, hist, s_len, copy, gsum, n_len1, n_len2);
           else open_run = r;
           ++r;
         }
@@ -209,9 +252,16 @@ __global__ __launch_bounds__(kRunTPB) void k_runs_emit_stats(
       *n_runs = r; run_start[r] = size; first_run[nsec] = r;     // the block's last byte is here, its run started earlier
     }
     if (open_run != kNoRun) o.tile_open[tile] = open_run;
+    __syncthreads();                          // the tile's runs are in LDS
+    for (u32 i = threadIdx.x; i < total; i += kRunTPB) { run_start[my_off + i] = s_rstart[i]; run_sym[my_off + i] = s_rsym[i]; }
     if (GAMMA) {
       gsum = wave_scan_add(gsum, lane_id());
       if (lane_id() == kWave - 1 && gsum) atomicAdd(&s_g0, gsum);
+    }
+    if (DIST) {
+      n_len1 = wave_scan_add(n_len1, lane_id());
+      n_len2 = wave_scan_add(n_len2, lane_id());
+      if (lane_id() == kWave - 1) { if (n_len1) atomicAdd(&s_len[1], n_len1); if (n_len2) atomicAdd(&s_len[2], n_len2); }
     }
   }
   __syncthreads();
