@@ -274,13 +274,16 @@ __global__ __launch_bounds__(256) void k_open_runs(const u32* __restrict__ run_s
                                                    const u8* __restrict__ run_sym,
                                                    const u32* __restrict__ first_run, u32 nsec,
                                                    u32 ntiles, RunStatsOut o) {
+  __shared__ u32 s_first[257];                  // the search below: eight dependent reads, from LDS instead of L2
+  for (u32 i = threadIdx.x; i <= nsec; i += 256u) s_first[i] = first_run[i];
+  __syncthreads();
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= ntiles) return;
   const u32 r = o.tile_open[t];
   if (r == kNoRun) return;
   const u32 len = run_start[r + 1] - run_start[r];
   u32 lo = 0, hi = nsec;
-  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (first_run[mid] <= r) lo = mid; else hi = mid; }
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_first[mid] <= r) lo = mid; else hi = mid; }
   const u32 s = lo, sym = run_sym[r];
   atomicAdd(&o.run_freqs[s * 256u + sym], 1u);
   if (GAMMA) atomicAdd(&o.gbits[s], (unsigned long long)gamma_bits(len));

@@ -312,20 +312,24 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_compact_pack(const u8* __restrict
   }
 }
 
-// coded elements before the first element of every group
+// coded elements before the first element of every group: the tile's offset plus the coded
+// elements of the tile before the group's first one, counted by a wave (one lane walking up to
+// 4096 bytes on its own was a quarter of a millisecond of latencies)
 __global__ __launch_bounds__(kWtTPB) void k_wt_group_pos(const u32* __restrict__ group_start,
                                                          u32 n_groups, u32 n,
                                                          const u8* __restrict__ code,
                                                          const u32* __restrict__ tile_off,
                                                          u32* __restrict__ coded_pos) {
-  const u32 g = blockIdx.x * kWtTPB + threadIdx.x;
+  const u32 g = blockIdx.x * (kWtTPB / kWave) + threadIdx.x / kWave;
+  const u32 lane = lane_id();
   if (g >= n_groups) return;
   const u32 j = group_start[g];
-  if (j >= n) { coded_pos[g] = 0xFFFFFFFFu; return; }     // empty group, the host fills it in
+  if (j >= n) { if (lane == 0) coded_pos[g] = 0xFFFFFFFFu; return; }     // empty group, the host fills it in
   const u32 tile = j / kWtTile;
-  u32 c = tile_off[tile];
-  for (u32 i = tile * kWtTile; i < j; ++i) c += code[i] != kWtSkip;
-  coded_pos[g] = c;
+  u32 c = 0;
+  for (u32 i = tile * kWtTile + lane; i < j; i += kWave) c += code[i] != kWtSkip;
+  c = wave_scan_add(c, lane);
+  if (lane == kWave - 1) coded_pos[g] = tile_off[tile] + c;
 }
 
 static inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
@@ -458,7 +462,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_code, d_tile, d_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_tile + tiles, 0, 4, st));
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
-  hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB)), dim3(kWtTPB), 0, st, d_gstart,
+  hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB / kWave)), dim3(kWtTPB), 0, st, d_gstart,
                      n_groups, n, d_code, d_tile, ptr32(o_gpos));
   BWTC_HIP_TRY(hipMemsetAsync(base + o_packed, 0, ((u64)ceil_div(n, 16) + 1) * 4ull, st));
   hipLaunchKernelGGL(k_wt_compact_pack, dim3(tiles), dim3(kWtTPB), 0, st, d_code, n, d_tile, ptr32(o_packed));
