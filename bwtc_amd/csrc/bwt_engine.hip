@@ -402,33 +402,41 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loads, was eight memory latencies in a row per wave); the neighbours across an iteration's ends
 // are the adjacent iterations' end lanes, and only the two slots next to the whole chunk are
 // loaded on their own.
-template <typename K, bool INIT>
+template <typename K, bool INIT, bool SPLIT>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
-                                         u32 m, u32 n, u32 short_len, K kmask, u32 split, u32 wbase, u32 lane,
+                                         u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
                                          RrMasks<K, INIT>& f) {
-  // split (initial ranking of 64-bit keys only): a suffix number's upper bits sit in bits 48.. of
+  // SPLIT (initial ranking of 64-bit keys only): a suffix number's upper bits sit in bits 48.. of
   // its key and idx[] holds 16-bit lower halves (the sort moved 10 bytes per item instead of 12)
-  const unsigned short* idx16 = reinterpret_cast<const unsigned short*>(idx);
-  auto suffix_of = [&](K kraw, u32 p) -> u32 {
-    if (sizeof(K) == 8 && split) return ((u32)((u64)kraw >> 48) << 16) | (u32)idx16[p];
-    return idx[p];
+  auto suffix_of = [&](K kraw, u32 word, u32 p) -> u32 {     // the 16-bit half out of its aligned word (two lanes per word)
+    if (sizeof(K) == 8 && SPLIT) return ((u32)((u64)kraw >> 48) << 16) | ((p & 1u) ? word >> 16 : word & 0xFFFFu);
+    return word;
   };
   K kc[kRrE];
+  {
+    K kraw[kRrE];
+    u32 word[kRrE];
 #pragma unroll
-  for (int e = 0; e < kRrE; ++e) {
-    const u32 p = wbase + e * kWave + lane;
-    const bool ok = p < m;
-    const K kraw = ok ? key[p] : (K)0;
-    f.sfx[e] = ok ? suffix_of(kraw, p) : 0u;
-    f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw >> 56) : 0u;
-    kc[e] = kraw & kmask;
+    for (int e = 0; e < kRrE; ++e) {               // nothing but loads: sixteen in flight
+      const u32 p = wbase + e * kWave + lane;
+      const bool ok = p < m;
+      kraw[e] = ok ? key[p] : (K)0;
+      word[e] = ok ? idx[(sizeof(K) == 8 && SPLIT) ? p >> 1 : p] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < kRrE; ++e) {
+      const u32 p = wbase + e * kWave + lane;
+      f.sfx[e] = p < m ? suffix_of(kraw[e], word[e], p) : 0u;
+      f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw[e] >> 56) : 0u;
+      kc[e] = kraw[e] & kmask;
+    }
   }
   K before = (K)0, after = (K)0;          // slots wbase - 1 and wbase + chunk (where they exist)
   u32 ibefore = 0u;
   if (lane == 0 && wbase > 0 && wbase < m) {
     const K braw = key[wbase - 1];
     before = braw & kmask;
-    if (INIT) ibefore = suffix_of(braw, wbase - 1);
+    if (INIT) ibefore = suffix_of(braw, idx[(sizeof(K) == 8 && SPLIT) ? (wbase - 1) >> 1 : wbase - 1], wbase - 1);
   }
   if (lane == kWave - 1 && wbase + (u32)kRrChunk < m) after = key[wbase + kRrChunk] & kmask;
 #pragma unroll
@@ -456,10 +464,10 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
 
 __device__ __forceinline__ u32 top_bit(u64 v) { return 63u - (u32)__clzll((unsigned long long)v); }
 
-template <typename K, bool INIT>
+template <typename K, bool INIT, bool SPLIT = false>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
                                                           const u32* __restrict__ idx, u32 m,
-                                                          u32 n, u32 short_len, K kmask, u32 split,
+                                                          u32 n, u32 short_len, K kmask,
                                                           u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
                                                           u32* __restrict__ aggC) {
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, split, wbase, lane, f);
+  rr_masks<K, INIT, SPLIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
   u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
@@ -574,10 +582,10 @@ struct RrEmit {
   u8* rec_plane; int rec_shift;      // MODE 2: digit (s >> rec_shift) & 255 of every record, for the window partition's first pass
 };
 
-template <typename K, bool INIT, int MODE, int EMIT>
+template <typename K, bool INIT, int MODE, int EMIT, bool SPLIT = false>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
-    u32 n, u32 short_len, K kmask, u32 split, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
+    u32 n, u32 short_len, K kmask, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
     u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out,
     u32* __restrict__ pair_s, u32* __restrict__ pair_r, RrEmit em) {
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT>(key, idx, m, n, short_len, kmask, split, wbase, lane, f);
+  rr_masks<K, INIT, SPLIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
   {
     u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
@@ -1171,8 +1179,10 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
-  hipLaunchKernelGGL((k_rerank_reduce<K, INIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
-                     short_len, kmask, split, d_aggA, d_aggB, d_aggC);
+  if (split) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, INIT && sizeof(K) == 8>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                                short_len, kmask, d_aggA, d_aggB, d_aggC);
+  else hipLaunchKernelGGL((k_rerank_reduce<K, INIT, false>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                          short_len, kmask, d_aggA, d_aggB, d_aggC);
   hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, counts);
   // how much stays active decides the route, so the counts are read before the apply kernel
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
@@ -1191,10 +1201,13 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   u64* recA = static_cast<u64*>(rb.rec_free);
   u64* recB = static_cast<u64*>(rb.rec_keys);
 
-#define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
-  hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,      \
-                     (const u32*)rb.aglob, m, n, short_len, kmask, split, d_aggA, d_aggB, d_aggC, d_rank, sa_out, \
+#define BWTC_APPLY_S(MODE, EMIT, SP, PS, PR, AIDX)                                                          \
+  hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT, SP>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,   \
+                     (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,  \
                      AIDX, rb.aglob_next, d_GRP, PS, PR, re)
+#define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
+  do { if (split) BWTC_APPLY_S(MODE, EMIT, (INIT && sizeof(K) == 8), PS, PR, AIDX);                       \
+       else BWTC_APPLY_S(MODE, EMIT, false, PS, PR, AIDX); } while (0)
   if (dense) {
     u32* tri_key = reinterpret_cast<u32*>(recA);
     // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
@@ -1233,6 +1246,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     else BWTC_APPLY(0, 0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
   }
 #undef BWTC_APPLY
+#undef BWTC_APPLY_S
   if (m_next == 0) return 0;
   hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m_next, 256 * kSimpleE)), dim3(256), 0, st,
                      (const u32*)rb.v_free, (const u32*)d_GRP, (const u32*)d_rank,
