@@ -128,16 +128,19 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 #define BWTC_EXISTS(e) (SKIP ? (bool)((okm >> (e)) & 1u) : (wslot + (e) * kWave) < tile_n)
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    u32 slot = wslot + e * kWave;
-    bool ok = slot < tile_n;
-    k[e] = ok ? kin[tile_base + slot] : (K)0;
-    if (SKIP && k[e] == ~(K)0) ok = false;
+    const u32 slot = wslot + e * kWave;
+    const bool in = slot < tile_n;
+    k[e] = in ? kin[tile_base + slot] : (K)0;
     // values_mode 1 / 3: first pass of a sort whose values are the items' own positions (3: counted
-    // down from n - 1, the suffix sorter's descending slots), nothing to
-    // read; 2: keys only
-    v[e] = (!ok || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot)
+    // down from n - 1, the suffix sorter's descending slots), nothing to read; 2: keys only.
+    // A hole's value is loaded like any other and never used: a load that waits for the key to
+    // say whether the item exists would put the pass's sixteen loads in a row.
+    v[e] = (!in || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot)
                                : values_mode == 3 ? (u32)(n - 1u - (tile_base + slot)) : vin[tile_base + slot];
-    if (SKIP) okm |= (ok ? 1u : 0u) << e;
+  }
+  if (SKIP) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) okm |= ((wslot + e * kWave < tile_n && k[e] != ~(K)0) ? 1u : 0u) << e;
   }
   __syncthreads();
 
