@@ -126,17 +126,32 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   u32 okm = 0;                                     // SKIP: bit e = this thread's item e exists
   // does item e of this thread exist?  (without holes that is a compare, no register)
 #define BWTC_EXISTS(e) (SKIP ? (bool)((okm >> (e)) & 1u) : (wslot + (e) * kWave) < tile_n)
+  // All loads of the tile back to back.  (With the values' mode switched on per item inside one
+  // loop the compiler put a full wait behind every item's loads: sixteen memory latencies in a
+  // row at the head of the kernel that runs twenty times per block.)  A hole's value is loaded
+  // like any other and never used.
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const u32 slot = wslot + e * kWave;
-    const bool in = slot < tile_n;
-    k[e] = in ? kin[tile_base + slot] : (K)0;
-    // values_mode 1 / 3: first pass of a sort whose values are the items' own positions (3: counted
-    // down from n - 1, the suffix sorter's descending slots), nothing to read; 2: keys only.
-    // A hole's value is loaded like any other and never used: a load that waits for the key to
-    // say whether the item exists would put the pass's sixteen loads in a row.
-    v[e] = (!in || KEYS) ? 0u : values_mode == 1 ? (u32)(tile_base + slot)
-                               : values_mode == 3 ? (u32)(n - 1u - (tile_base + slot)) : vin[tile_base + slot];
+    k[e] = slot < tile_n ? kin[tile_base + slot] : (K)0;
+  }
+  // values_mode 1 / 3: first pass of a sort whose values are the items' own positions (3: counted
+  // down from n - 1, the suffix sorter's descending slots), nothing to read; 2: keys only.
+  if (KEYS) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = 0u;
+  } else if (values_mode == 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const u32 slot = wslot + e * kWave;
+      v[e] = slot < tile_n ? (u32)vin[tile_base + slot] : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const u32 pos = (u32)tile_base + wslot + e * kWave;
+      v[e] = values_mode == 1 ? pos : (u32)n - 1u - pos;
+    }
   }
   if (SKIP) {
 #pragma unroll
