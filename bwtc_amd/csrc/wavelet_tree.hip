@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_count(const u32* __restrict__ run
   }
 }
 
-// Two phases per workgroup of 256 runs.  One thread per RUN looks the run up (symbol entry, gap
+// Two phases per workgroup of 512 runs (two per thread).  One thread per RUN looks the run up (symbol entry, gap
 // prefix, length entry), parks what its steps need in LDS and writes its number into the owner
 // byte of each of its steps; then one thread per STEP of the workgroup's consecutive stretch of
 // output (off[] is the prefix of the step counts) fetches its word from the pool, so the lookups
@@ -132,56 +132,84 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_count(const u32* __restrict__ run
 // wave, and stored a word per lane and cache line.)  Stretches longer than the owner window (very
 // long codes) find the run by a search over the 257 offsets instead.  `plane` receives the sort's
 // first digit of every step word (radix_sort.hpp, digit planes).
-constexpr u32 kWtOwnerWin = 8192;     // 32 steps per run on average
+constexpr u32 kWtOwnerWin = 8192;     // steps of a workgroup's runs that the owner table covers: 16 per run on average
+constexpr int kWtExpandR = 2;         // runs per thread (their lookups are in flight together)
+constexpr u32 kWtExpandRuns = kWtTPB * kWtExpandR;
 
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
                                                       u32* __restrict__ key, u8* __restrict__ plane) {
-  __shared__ u32 s_off[kWtTPB + 1];
-  __shared__ u32 s_sym[kWtTPB];        // pool offset of the run's symbol steps
-  __shared__ u32 s_len[kWtTPB];        // pool offset of its length steps
-  __shared__ u32 s_meta[kWtTPB];       // symbol steps | common prefix << 8 | leaf rank << 16
-  __shared__ u8 s_owner[kWtOwnerWin];
-  const u32 r0 = blockIdx.x * kWtTPB;
-  const u32 r = r0 + threadIdx.x;
-  const u32 cnt = min((u32)kWtTPB, n_runs - r0);
-  bool uniform; u32 sec_first;
-  u32 s = wt_section_uniform(t.first_run, t.nsec, r0, cnt, &uniform, &sec_first);
+  __shared__ u32 s_off[kWtExpandRuns + 1];
+  __shared__ u32 s_sym[kWtExpandRuns];        // pool offset of the run's symbol steps
+  __shared__ u32 s_len[kWtExpandRuns];        // pool offset of its length steps
+  __shared__ u32 s_meta[kWtExpandRuns];       // symbol steps | common prefix << 8 | leaf rank << 16
+  __shared__ unsigned short s_owner[kWtOwnerWin];
+  const u32 r0 = blockIdx.x * kWtExpandRuns;
+  const u32 cnt = min(kWtExpandRuns, n_runs - r0);
+  bool uniform; u32 sec_first0;
+  const u32 s_uniform = wt_section_uniform(t.first_run, t.nsec, r0, cnt, &uniform, &sec_first0);
   // Everything a run needs is looked up before the first barrier, in two rounds of independent
-  // loads (the run's own words and offsets, then the table entries they select).
-  const u32 rr = min(r, n_runs - 1u);
-  const u32 my_off = off[min(r, n_runs)];                   // off[n_runs] = total
-  const u32 end_off = threadIdx.x == 0 ? off[min(r0 + (u32)kWtTPB, n_runs)] : 0u;
-  const u32 c = run_sym[rr];
-  const u32 cp = run_sym[rr ? rr - 1u : 0u];
-  const u32 len = run_start[rr + 1] - run_start[rr];
+  // loads (the runs' own words and offsets, then the table entries they select).
+  u32 my_off[kWtExpandR], c[kWtExpandR], cp[kWtExpandR], len[kWtExpandR], sec[kWtExpandR], sec_first[kWtExpandR];
+#pragma unroll
+  for (int q = 0; q < kWtExpandR; ++q) {
+    const u32 r = r0 + (u32)q * kWtTPB + threadIdx.x;
+    const u32 rr = min(r, n_runs - 1u);
+    my_off[q] = off[min(r, n_runs)];                        // off[n_runs] = total
+    c[q] = run_sym[rr];
+    cp[q] = run_sym[rr ? rr - 1u : 0u];
+    len[q] = run_start[rr + 1] - run_start[rr];
+    sec[q] = s_uniform; sec_first[q] = sec_first0;
+  }
+  const u32 end_off = threadIdx.x == 0 ? off[min(r0 + kWtExpandRuns, n_runs)] : 0u;
   if (!uniform) {                                           // a section border inside the workgroup: the lanes search for themselves
-    u32 lo = 0, hi = t.nsec;
-    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (t.first_run[mid] <= rr) lo = mid; else hi = mid; }
-    s = lo;
-    sec_first = t.first_run[lo];
+#pragma unroll
+    for (int q = 0; q < kWtExpandR; ++q) {
+      const u32 rr = min(r0 + (u32)q * kWtTPB + threadIdx.x, n_runs - 1u);
+      u32 lo = 0, hi = t.nsec;
+      while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (t.first_run[mid] <= rr) lo = mid; else hi = mid; }
+      sec[q] = lo;
+      sec_first[q] = t.first_run[lo];
+    }
   }
-  const uint2 sy = t.symtab[s * 256u + c];
-  const u64 code_c = t.symcode[s * 256u + c], code_p = t.symcode[s * 256u + cp];
-  const uint2 led = t.lendense[(u64)s * kWtLenDense + min(len, kWtLenDense - 1u)];
-  s_off[threadIdx.x] = my_off;
-  if (threadIdx.x == 0) s_off[kWtTPB] = end_off;
-  if (r < n_runs) {
-    // steps at depth > (common prefix with the previous run's code) carry the gap flag
-    const u32 common = r > sec_first ? (u32)__clzll(code_c ^ code_p) : 0u;
-    u32 len_off = 0;
-    if (sy.y >> 16) len_off = len < kWtLenDense ? led.x : wt_length_entry(t, s, len).x;
-    s_sym[threadIdx.x] = sy.x;
-    s_len[threadIdx.x] = len_off;
-    s_meta[threadIdx.x] = (sy.y & 255u) | (min(common, 64u) << 8) | (((sy.y >> 8) & 255u) << 16);
+  uint2 sy[kWtExpandR], led[kWtExpandR];
+  u64 code_c[kWtExpandR], code_p[kWtExpandR];
+#pragma unroll
+  for (int q = 0; q < kWtExpandR; ++q) {
+    sy[q] = t.symtab[sec[q] * 256u + c[q]];
+    code_c[q] = t.symcode[sec[q] * 256u + c[q]];
+    code_p[q] = t.symcode[sec[q] * 256u + cp[q]];
+    led[q] = t.lendense[(u64)sec[q] * kWtLenDense + min(len[q], kWtLenDense - 1u)];
   }
+#pragma unroll
+  for (int q = 0; q < kWtExpandR; ++q) {
+    const u32 x = (u32)q * kWtTPB + threadIdx.x;            // the run's number in the workgroup
+    const u32 r = r0 + x;
+    s_off[x] = my_off[q];
+    if (r < n_runs) {
+      // steps at depth > (common prefix with the previous run's code) carry the gap flag
+      const u32 common = r > sec_first[q] ? (u32)__clzll(code_c[q] ^ code_p[q]) : 0u;
+      u32 len_off = 0;
+      if (sy[q].y >> 16) len_off = len[q] < kWtLenDense ? led[q].x : wt_length_entry(t, sec[q], len[q]).x;
+      s_sym[x] = sy[q].x;
+      s_len[x] = len_off;
+      s_meta[x] = (sy[q].y & 255u) | (min(common, 64u) << 8) | (((sy[q].y >> 8) & 255u) << 16);
+    }
+  }
+  if (threadIdx.x == 0) s_off[kWtExpandRuns] = end_off;
   __syncthreads();
   const u32 o0 = s_off[0], o1 = s_off[cnt];
   const bool owned = o1 - o0 <= kWtOwnerWin;
-  if (owned && r < n_runs) {
-    const u32 b = s_off[threadIdx.x] - o0, e = s_off[threadIdx.x + 1] - o0;
-    for (u32 i = b; i < e; ++i) s_owner[i] = (u8)threadIdx.x;
+  if (owned) {
+#pragma unroll
+    for (int q = 0; q < kWtExpandR; ++q) {
+      const u32 x = (u32)q * kWtTPB + threadIdx.x;
+      if (r0 + x < n_runs) {
+        const u32 b = s_off[x] - o0, e = s_off[x + 1] - o0;
+        for (u32 i = b; i < e; ++i) s_owner[i] = (unsigned short)x;
+      }
+    }
   }
   __syncthreads();
   // four steps per thread and round, every pool lookup of the round in flight before the first is used
@@ -446,7 +474,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   BWTC_HIP_TRY(e.wait());
   const u32 n = e.h_small[0];
   if (n == 0 || (u64)n > cap) return -3;
-  hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtTPB)), dim3(kWtTPB), 0, st, d_run_start,
+  hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtExpandRuns)), dim3(kWtTPB), 0, st, d_run_start,
                      d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), base + o_code);
   // sort by (group, leaf rank), keys only; the bit and the gap flag ride along in the word
   u32* ks = nullptr; u32* vs = nullptr;
