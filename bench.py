@@ -265,10 +265,15 @@ def main():
         traffic, traffic_src = None, None
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_text256.json")))
         if args.size_mib == 256 and pmcs:
+            # all scatter launches of the transform (the same mix the probe averages over)
+            tot_b, tot_n = 0.0, 0
             for name, v in json.load(open(pmcs[-1]))["kernels"].items():
-                if "k_radix_scatter<unsigned long" in name and traffic is None:
-                    traffic = int(v["hbm_bytes_per_launch_avg"])
-                    traffic_src = os.path.relpath(pmcs[-1], ROOT)
+                if "k_radix_scatter<" in name:
+                    tot_b += v["hbm_bytes_per_launch_avg"] * v["launches"]
+                    tot_n += v["launches"]
+            if tot_n:
+                traffic = int(tot_b / tot_n)
+                traffic_src = os.path.relpath(pmcs[-1], ROOT)
         if kt["scatter_launches"]:
             achieved = kt["scatter_bytes"] / (kt["scatter_ms"] * 1e-3) / 1e9
             bwt_ms = statistics.mean(dev_ms)

@@ -372,7 +372,8 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
       else { if (make_plane) BWTC_SCATTER(false, true, false); else BWTC_SCATTER(false, false, false); }
 #undef BWTC_SCATTER
       { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
-      if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(V))));
+      // algorithmic bytes of the pass: every item read once and written once, plus the digit plane it leaves
+      if (timed) probe->end(st, (n_in + n) * (sizeof(K) + (keys_only ? 0 : sizeof(V))) + (make_plane ? n : 0));
       K* tk = kin; kin = kout; kout = tk;
       V* tv = vin; vin = vout; vout = tv;
       first = false;
