@@ -319,6 +319,25 @@ def test_chained_sort_variant(oracle, monkeypatch):
         assert rc == 0 and (inv == d).all()
 
 
+@pytest.mark.parametrize("switch", ["BWTC_HIP_GRAMS=0", "BWTC_HIP_GRAMS=4", "BWTC_HIP_SPLIT_INDEX=0", "BWTC_HIP_PLANES=0",
+                                    "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12"])
+def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
+    """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
+    only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
+    from bwtc_amd import hip
+    name, value = switch.split("=")
+    monkeypatch.setenv(name, value)
+    size = 6 << 20
+    text = synth.gen_text(size, 21)
+    zeros = text.copy()
+    zeros[zeros == 101] = 0
+    with hip.Context(0, size) as ctx:
+        for d in (text, zeros):
+            a = ctx.bwt_block(d, 7)
+            b = oracle.oracle_bwt_block(d, 7)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), switch
+
+
 def test_two_contexts_in_two_threads(oracle):
     """One context per worker thread (the farm's unit): two threads transform different blocks
     on the same GPU at the same time."""
