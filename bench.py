@@ -146,7 +146,10 @@ def main():
 
     size = args.size_mib << 20
     world_hint = max(1, int(os.environ.get("WORLD_SIZE", "1")))
-    auto_depth = 96 if (has_avx512() and mem_available_gb() / world_hint >= 24) else 16
+    # the fused host engines keep a text block under way for about four seconds: 96 blocks cover
+    # that at 45 ms per block, 128 leave a margin where the memory is there (17 GB of streams per rank)
+    mem_per_rank = mem_available_gb() / world_hint
+    auto_depth = (128 if mem_per_rank >= 40 else 96 if mem_per_rank >= 24 else 16) if has_avx512() else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()

@@ -233,7 +233,10 @@ class HostPipeline {
   // (>= kLaneDepth blocks, 1.2 GB of host memory each).  Shallower pipelines keep the scalar
   // chains, two per task (codeSectionsPaired).  BWTC_HIP_CODER_LANES=1 / 0 overrides.
   HostPipeline(unsigned threads, uint64_t huge_group_elements, unsigned depth = 16);
-  static constexpr unsigned kLaneDepth = 48;
+  // (Measured again with the GPU side at 45 ms per block: the lane route then needs more than 64
+  // blocks under way to beat the scalar chains, and from 56 blocks on the fused engines beat both
+  // -- so by default the lanes are only used when asked for.)
+  static constexpr unsigned kLaneDepth = 1u << 30;
   ~HostPipeline();                                   // joins the workers; every queued block must be finished
   // job: record (header part), plan, coded_pos, codes, prob (room for the coded elements), rank and
   // user_out/user_cap set.  Builds the block's coder from the carried model state and queues its
@@ -256,7 +259,7 @@ class HostPipeline {
   // under way: a lone block, or the first blocks of a stream, would crawl through nearly empty
   // vectors.  The caller sets WaveletJob::fused from this before queue().
   bool fusedNow(char model) const { return max_fused_engines_ && model == 'B' && clock.unfinished.load() >= (int)kFusedBacklog; }
-  static constexpr unsigned kFusedDepth = 72;
+  static constexpr unsigned kFusedDepth = 56;        // 256 MiB text, 16 threads, 45 ms of GPU per block: 48 deep = the scalar route's rate, 64 deep 1.5x, 96 deep 2.3x
   static constexpr unsigned kFusedBacklog = 6;
   StageClock clock;
  private:
