@@ -376,16 +376,17 @@ class WaveletEncoder : public EntropyEncoder {
   bool overlapsBlocks() const { return true; }
   // never more than the context allows (BWTC_HIP_WAVELET_DEPTH), or _begin would refuse with -6
   size_t depth() const {
-    const size_t lim = m_ctx ? bwtc_hip_wavelet_depth(m_ctx) : (size_t)kDepth;
-    return std::max<size_t>(1, std::min<size_t>(kDepth, lim));
+    const size_t lim = m_ctx ? bwtc_hip_wavelet_depth(m_ctx) : (size_t)kDefaultDepth;
+    return std::max<size_t>(1, std::min<size_t>(kMaxDepth, lim));
   }
   size_t pending() const { return m_order.size(); }
   // device half: upload, transform on the device, run scanner + stream kernels; the models and
   // range coders of the block are queued on the context's worker threads.  The block's bytes
   // in host memory are left as they were.
   void begin(BWTBlock& block, BWTManager& bwtm) {
-    assert(!block.isTransformed() && m_order.size() < kDepth);
     start(bwtm);
+    const size_t slots = depth();                                   // fixed once the context exists
+    assert(!block.isTransformed() && m_order.size() < slots);
     const uint32 size = (uint32)block.size();
     if (m_devBytes < (uint64)size + 64) {
       if (m_dev) bwtc_hip_free(m_ctx, m_dev);
@@ -393,8 +394,8 @@ class WaveletEncoder : public EntropyEncoder {
       if (!m_dev) hipFatal(-2, "bwtc_hip_malloc");
       m_devBytes = (uint64)size + 64;
     }
-    if (m_slots.size() < kDepth) m_slots.resize(kDepth);
-    Slot& slot = m_slots[m_next % kDepth];
+    if (m_slots.size() < slots) m_slots.resize(slots);
+    Slot& slot = m_slots[m_next % slots];
     const uint64 cap = bwtc_hip_compress_bound(size);
     if (slot.cap < cap) {                                         // not zero-filled: only the record's bytes get touched
       std::free(slot.rec);
@@ -413,7 +414,7 @@ class WaveletEncoder : public EntropyEncoder {
                                                   &block.LFpowers()[0], (uint32)block.LFpowers().size(),
                                                   freqs, 0, slot.rec, slot.cap, &slot.ticket),
              "bwtc_hip_wavelet_encode_device_begin");
-    m_order.push_back(m_next % kDepth);
+    m_order.push_back(m_next % slots);
     ++m_next;
   }
   size_t finishOldest(OutStream* out) {
@@ -426,7 +427,9 @@ class WaveletEncoder : public EntropyEncoder {
     return (size_t)n;
   }
  private:
-  enum { kDepth = 12 };
+  // blocks under way: what the context allows (BWTC_HIP_WAVELET_DEPTH, 16 unless the caller asks
+  // for more: from 56 on the library's fused host engines are used, bwtc_hip.h)
+  enum { kDefaultDepth = 12, kMaxDepth = 256 };
   struct Slot { byte* rec; uint64 cap; uint64_t ticket; Slot() : rec(0), cap(0), ticket(0) {} };
   void start(BWTManager& bwtm) {
     m_ctx = bwtm.hipContext();
@@ -487,7 +490,7 @@ class Compressor {
   size_t writeGlobalHeader() { m_out->writeByte((byte)m_options.entropyCoder); return 1; }
   // The blocks of the stream farmed over several contexts, one per listed device (the same device
   // may be listed more than once): bwtc_hip_farm.hpp.  Same bytes as compress().
-  size_t compressFarmed(const std::vector<int>& devices, uint32 startingPoints);
+  size_t compressFarmed(const std::vector<int>& devices, uint32 startingPoints, unsigned depth = 0);   // depth: blocks under way per context (0 = 12)
 
   // Compressor.cpp:65-118 with no precompression: every read of bwtBlockSize bytes is one
   // precompressor block holding one BWT block (pbBlockSize == bwtBlockSize, :81).

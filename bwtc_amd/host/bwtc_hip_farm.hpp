@@ -265,10 +265,10 @@ class BlockFarm {
 };
 
 // Compressor.cpp:65-118 over a BlockFarm: the caller's thread reads and writes, in block order.
-inline size_t Compressor::compressFarmed(const std::vector<int>& devices, uint32 startingPoints) {
+inline size_t Compressor::compressFarmed(const std::vector<int>& devices, uint32 startingPoints, unsigned depth) {
   size_t compressedSize = writeGlobalHeader();
   const size_t bs = bwtBlockSize();
-  BlockFarm farm(devices, (uint32)bs, m_options.entropyCoder, startingPoints);
+  BlockFarm farm(devices, (uint32)bs, m_options.entropyCoder, startingPoints, depth ? depth : 12);
   std::vector<byte> record;
   uint32 blockSize = 0;
   for (;;) {

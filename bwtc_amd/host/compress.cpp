@@ -13,19 +13,42 @@
 //     -D, --devices LIST farm the blocks of the stream over these GPUs, e.g. 0,1,2,3 (one context,
 //                        one thread and one page-locked staging ring per entry; the same bytes as
 //                        with one device)
+//     -P, --pipeline N   blocks under way per context for the wavelet coders (default: 128 or 96
+//                        when the blocks are 64 MB and more, the input file has 256 blocks and
+//                        more per context and the host has 40 / 24 GB free, else 16;
+//                        BWTC_HIP_WAVELET_DEPTH overrides).  From 56 on the library codes
+//                        with its fused 16-lane engines: a block then takes seconds, the stream
+//                        two to three times less host time.
 //     -v, --verb N       verbosity
 // Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc m/M (models
 // whose reference implementation reads past its table) are rejected, --prepr is not offered.
 #include <getopt.h>
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
 #include "bwtc_hip.hpp"
 #include "bwtc_hip_farm.hpp"
 
+static double memAvailableGB() {
+  double gb = 0.0;
+  if (FILE* f = std::fopen("/proc/meminfo", "r")) {
+    char line[256];
+    while (std::fgets(line, sizeof line, f)) {
+      unsigned long long kb;
+      if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { gb = kb / 1048576.0; break; }
+    }
+    std::fclose(f);
+  }
+  return gb;
+}
+
 int main(int argc, char** argv) {
   size_t mem = 100;
+  unsigned pipeline = 0;
   unsigned starts = 8;
   char bwt = 'a', enc = 'B';                                     // compress.cpp:115-118 defaults
   bool from_stdin = false, to_stdout = false;
@@ -35,10 +58,10 @@ int main(int argc, char** argv) {
                               {"bwt", required_argument, 0, 'b'},   {"enc", required_argument, 0, 'e'},
                               {"stdin", no_argument, 0, 'i'},       {"stdout", no_argument, 0, 'c'},
                               {"device", required_argument, 0, 'd'}, {"verb", required_argument, 0, 'v'},
-                              {"devices", required_argument, 0, 'D'},
+                              {"devices", required_argument, 0, 'D'}, {"pipeline", required_argument, 0, 'P'},
                               {"help", no_argument, 0, 'h'},        {0, 0, 0, 0}};
   int o;
-  while ((o = getopt_long(argc, argv, "m:s:e:icd:D:v:h", longopts, 0)) != -1) {
+  while ((o = getopt_long(argc, argv, "m:s:e:icd:D:P:v:h", longopts, 0)) != -1) {
     switch (o) {
       case 'm': mem = std::strtoul(optarg, 0, 10); break;
       case 's': starts = (unsigned)std::strtoul(optarg, 0, 10); break;
@@ -50,6 +73,7 @@ int main(int argc, char** argv) {
       case 'D':
         for (const char* p = optarg; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
         break;
+      case 'P': pipeline = (unsigned)std::strtoul(optarg, 0, 10); break;
       case 'v': verbosity = std::atoi(optarg); break;
       default:
         std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|b|u|H] [-i] [-c] [input] [output]\n");
@@ -69,12 +93,39 @@ int main(int argc, char** argv) {
   }
   if (!from_stdin && in_name.empty()) { std::fprintf(stderr, "no input\n"); return 1; }
 
+  // how many blocks a context keeps under way (the library reads it when the context is created)
+  if (enc != 'H' && !std::getenv("BWTC_HIP_WAVELET_DEPTH")) {
+    const size_t n_ctx = devices.empty() ? 1 : devices.size();
+    if (pipeline == 0) {
+      // Deep pipelines only for long streams: the fused engines keep every block under way for
+      // seconds, which a stream of a few dozen blocks never earns back (24 blocks of 256 MiB:
+      // 10.4 s instead of 7.6 s).
+      const double gb = memAvailableGB() / n_ctx;
+      const double block_bytes = mem * 0.185 * 1e6;
+      double stream_bytes = 0.0;
+      if (!from_stdin) {
+        if (FILE* f = std::fopen(in_name.c_str(), "rb")) {
+          if (fseeko(f, 0, SEEK_END) == 0) stream_bytes = (double)ftello(f);
+          std::fclose(f);
+        }
+      }
+      const bool deep = block_bytes >= 64e6 && stream_bytes / block_bytes >= 256.0 * n_ctx;
+      pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : 16;
+    }
+    if (pipeline > 256) pipeline = 256;
+    char buf[16];
+    std::snprintf(buf, sizeof buf, "%u", pipeline);
+    setenv("BWTC_HIP_WAVELET_DEPTH", buf, 1);
+  } else if (enc != 'H') {                                       // the caller's environment sets the contexts' limit
+    const unsigned lim = (unsigned)std::max(1, std::atoi(std::getenv("BWTC_HIP_WAVELET_DEPTH")));
+    if (pipeline == 0 || pipeline > lim) pipeline = lim;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name),
                               mem * 1000000, enc);                // compress.cpp:192-193
   size_t compressed;
   if (!devices.empty()) {
-    compressed = compressor.compressFarmed(devices, starts < 1 ? 1 : starts > 256 ? 256 : starts);
+    compressed = compressor.compressFarmed(devices, starts < 1 ? 1 : starts > 256 ? 256 : starts, pipeline);
   } else {
     compressor.initializeBwtAlgorithm(bwt, starts, device);
     compressed = compressor.compress(1);
