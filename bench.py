@@ -108,25 +108,25 @@ def cpu_baseline(size_mib, seed, coder, runs):
                   "(median beside it): BWT by %s, 1 thread%s"
                   % (size_mib, seed, len(tot),
                      "the reference's divbwtf (oracle/_ref)" if use_ref else "oracle/bwtc_oracle.c",
-                     "; '%s' encode by the oracle's restatement of the reference coder" % coder if coder in "HB" else ""),
+                     "; '%s' encode by the oracle's restatement of the reference coder" % coder if coder in ("H", "B") else ""),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--coder", choices=["B", "H"], default="B",
                     help="entropy coder of the step: B = wavelet (BASELINE config), H = Huffman")
     ap.add_argument("--bwt-only", action="store_true", help="the transform alone (config 5 with --size-mib 1024)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="'B': blocks under way at once.  0 = 96 when the host CPU has AVX-512 (the fused model + "
-                         "range-coder lane engines: a block under way then holds 0.2 GB of host memory) and 24 GB "
-                         "of free memory per rank, else 16 (scalar coders, 1.2 GB per block)")
+                    help="'B': blocks under way at once.  0 = what the product picks for a stream as long as the one "
+                         "this run codes (compress.cpp: 128 / 96 blocks -- the fused lane engines -- only for streams "
+                         "of 256 blocks and more, when the host has AVX-512 and 40 / 24 GB per rank; else 16)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
-    ap.add_argument("--cpu-runs", type=int, default=1, help="runs of the one-thread CPU baseline (median and best reported)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -146,10 +146,13 @@ def main():
 
     size = args.size_mib << 20
     world_hint = max(1, int(os.environ.get("WORLD_SIZE", "1")))
-    # the fused host engines keep a text block under way for about four seconds: 96 blocks cover
-    # that at 45 ms per block, 128 leave a margin where the memory is there (17 GB of streams per rank)
+    # The depth the product would pick for this stream (bwtc_amd/host/compress.cpp): the fused host
+    # engines keep a text block under way for seconds, so the deep pipelines (128 / 96 blocks) are
+    # only for streams of 256 blocks and more; everything shorter runs 16 deep.
     mem_per_rank = mem_available_gb() / world_hint
-    auto_depth = (128 if mem_per_rank >= 40 else 96 if mem_per_rank >= 24 else 16) if has_avx512() else 16
+    stream_blocks = max(args.warmup, 16) + args.steps
+    deep = stream_blocks >= 256 and has_avx512()
+    auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
@@ -194,7 +197,9 @@ def main():
         lf, freqs = ctx.bwt_block_device(d_in[i % 2], d_out, size, 8)
         if coder == "H":
             comp[0] = ctx.huffman_encode_device(d_out, size, lf, freqs, d_comp)
-            ctx.lib.bwtc_hip_memcpy_to_host(ctx.handle, h_rec.ctypes.data, d_comp, comp[0])
+            rc = ctx.lib.bwtc_hip_memcpy_to_host(ctx.handle, h_rec.ctypes.data, d_comp, comp[0])
+            if rc:
+                raise hip.BwtcHipError("bwtc_hip_memcpy_to_host failed with code %d" % rc)
         elif coder == "B":
             pending.append(ctx.wavelet_encode_device_begin(d_out, size, lf, freqs, ring[i % (depth + 1)], threads))
         clock["gpu_s"] += time.perf_counter() - t
@@ -215,12 +220,14 @@ def main():
     issued[0] = 0
     upload(0)
     t0 = time.perf_counter()
-    for _ in range(max(args.warmup, depth if coder == "B" else 0)):
+    fill_blocks = max(args.warmup, depth if coder == "B" else 0)
+    for _ in range(fill_blocks):
         step()                                           # nothing is collected here: the pipeline fills
     fill_ms = 1e3 * (time.perf_counter() - t0)
     ctx.reset_kernel_timers()
     clock["gpu_s"] = clock["collect_s"] = 0.0
     m0, c0, b0 = ctx.wavelet_host_clock()
+    f0 = ctx.wavelet_host_progress()[1]
     dev_ms = []
 
     def timed_step():
@@ -230,11 +237,16 @@ def main():
     # ---- timed: K steps, each begins one block and (B) collects one ------------------------------
     elapsed = farm.timed(timed_step, args.steps, 0, None)
     m1, c1, b1 = ctx.wavelet_host_clock()
+    f1 = ctx.wavelet_host_progress()[1]
     gpu_s, collect_s = clock["gpu_s"], clock["collect_s"]            # of the timed region only
     t0 = time.perf_counter()
     drain()
     drain_ms = 1e3 * (time.perf_counter() - t0)
     comp_bytes = comp[0]
+    # records the host workers finished inside the timed region: the rate the host half really
+    # sustained (the records COLLECTED there may all have been finished during the fill)
+    finished = (f1 - f0) if coder == "B" else args.steps
+    finished = int(-farm.max(-finished))                 # the slowest rank's count
 
     # the spec peak beside what a plain device copy reaches on this box
     copy_gbs = None
@@ -299,12 +311,23 @@ def main():
         step_ms = 1e3 * elapsed / args.steps
         gpu_ms = 1e3 * gpu_s / args.steps
         wait_ms = 1e3 * collect_s / args.steps
-        blocks_done = max(1, b1 - b0)
+        blocks_done = max(1, max(b1 - b0, f1 - f0))
         what = ("BWT only" if coder is None else "BWT+encode")
+        # What the region PROVES: `steps` blocks were begun in it, `finished` records were finished by
+        # the host half in it.  The value is the smaller of the two rates; the closed loop (every
+        # block of the stream, fill and drain included) is reported beside it.
+        counted = min(args.steps, finished)
+        value = world * counted * size / 1e6 / elapsed
+        all_blocks = fill_blocks + args.steps
+        wall_s = (fill_ms + drain_ms) * 1e-3 + elapsed
+        closed = world * all_blocks * size / 1e6 / wall_s
+        # blocks a stream needs before its closed-loop rate is within 10 % of `value`
+        overhead_s = max(0.0, wall_s - all_blocks * elapsed / args.steps)
+        stream_for_rate = int(9.0 * overhead_s / (elapsed / args.steps)) + 1
         out = {
             "metric": "MB/s compressed (%s) on %d MiB block" % (what, args.size_mib)
                       if coder else "MB/s transformed (BWT only) on %d MiB block" % args.size_mib,
-            "value": round(total_mb / elapsed, 2), "unit": "MB/s", "n_gpus": world,
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
@@ -315,8 +338,9 @@ def main():
                        "timed_region": "block in page-locked host memory -> " +
                                        ("transformed block in HBM" if coder is None else "record in host memory") +
                                        "; upload of block i+1 overlaps the kernels of block i" +
-                                       ("; steady state of a %d-deep block pipeline (K blocks begun and K records "
-                                        "collected inside the region, fill and drain outside)" % depth if coder == "B" else ""),
+                                       ("; %d-deep block pipeline: K blocks begun and K records collected inside the "
+                                        "region, value counts min(K, records the host finished inside it); fill and "
+                                        "drain outside, closed loop reported beside" % depth if coder == "B" else ""),
                        "stages": "BWT (suffix sort + BWT + LFpowers + freqs) on the GPU" +
                                  (" + 'B' wavelet coder: run scanner, tree bit vectors, traversal order and gap "
                                   "flags on the GPU; adaptive models and the range coder (one serial chain per "
@@ -327,7 +351,13 @@ def main():
             "single_block_ms": round(single_ms, 1), "h2d_ms": round(h2d_ms, 2),
             "fill_ms": round(fill_ms, 1), "drain_ms": round(drain_ms, 1),
             "gpu_ms_per_step": round(gpu_ms, 2), "collect_wait_ms_per_step": round(wait_ms, 2),
-            "host_bound": bool(coder == "B" and wait_ms > 0.1 * step_ms),
+            "issue_rate_MBps": round(total_mb / elapsed, 2),
+            "host_blocks_finished_in_region": finished,
+            "closed_loop": {"blocks": all_blocks, "wall_s": round(wall_s, 3), "MBps": round(closed, 2),
+                            "what": "every block of the stream / (fill + timed region + drain)"},
+            "stream_blocks_for_rate": stream_for_rate,
+            "host_mem_per_rank_gb": round(mem_per_rank, 1),
+            "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,
             "host_model_s_per_block": round((m1 - m0) / blocks_done, 3) if coder == "B" else 0.0,

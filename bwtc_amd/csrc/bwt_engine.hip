@@ -1022,12 +1022,22 @@ hipError_t BwtEngine::codes_wait() {
 }
 
 int BwtEngine::reserve_run_arrays() {
-  if (d_run_start[0]) return 0;
+  if (d_run_start[0] && d_run_start[1] && d_run_sym[0] && d_run_sym[1]) return 0;
+  // all four or none: a half-allocated set left behind by a failed call would let the next
+  // block's scanner write through a null pointer
+  bool ok = true;
   for (int b = 0; b < 2; ++b) {
-    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_run_start[b]), (cap + 2) * 4));
-    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_run_sym[b]), cap + 64));
+    if (!d_run_start[b]) ok = ok && hipMalloc(reinterpret_cast<void**>(&d_run_start[b]), (cap + 2) * 4) == hipSuccess;
+    if (!d_run_sym[b]) ok = ok && hipMalloc(reinterpret_cast<void**>(&d_run_sym[b]), cap + 64) == hipSuccess;
   }
-  return 0;
+  if (ok) return 0;
+  (void)hipGetLastError();
+  for (int b = 0; b < 2; ++b) {
+    if (d_run_start[b]) (void)hipFree(d_run_start[b]);
+    if (d_run_sym[b]) (void)hipFree(d_run_sym[b]);
+    d_run_start[b] = nullptr; d_run_sym[b] = nullptr;
+  }
+  return -2;
 }
 
 hipError_t BwtEngine::wait() {
@@ -1431,6 +1441,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     m = res.m;
   }
   BWTC_HIP_TRY(hipGetLastError());
+  BWTC_HIP_TRY(take_sticky_error());
   return 0;
 }
 
@@ -1494,6 +1505,7 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   BWTC_HIP_TRY(hipEventRecord(ev_end, st));
   BWTC_HIP_TRY(wait());
   BWTC_HIP_TRY(hipGetLastError());
+  BWTC_HIP_TRY(take_sticky_error());
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
   probe.harvest();
   stats.n = n;

@@ -268,6 +268,10 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
                            const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket,
                            const std::function<void()>* while_scanning = nullptr);
 int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out);
+// Blocks begun with _begin join their stream one or two calls later; this makes every such block
+// join NOW, in ticket order, with the stream's current state and model -- what must happen before
+// the context starts another stream (bwtc_hip_wavelet_start / _reset).
+int wavelet_join_begun(BwtEngine& e);
 void wavelet_pipeline_release(BwtEngine& e);
 
 // Inverse transform of a device-resident transformed block (d_bwt and d_out may alias).

@@ -336,6 +336,10 @@ static unsigned pick_threads(uint32_t threads) {
 
 int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
   if (!ctx || !bwtc::wavelet::isWaveletModel(coder)) return -1;
+  // blocks begun with _begin that have not joined their stream yet belong to the OLD stream:
+  // they join it now, with its state and its model, before either changes
+  const int rc = wavelet_join_begun(ctx->eng);
+  if (rc) return rc;
   ctx->eng.wavelet_state = 4;
   ctx->eng.wavelet_model = coder;
   return 0;
@@ -348,6 +352,14 @@ int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double
   if (model_seconds) *model_seconds = p ? p->clock.model_ns.load() * 1e-9 : 0.0;
   if (coder_seconds) *coder_seconds = p ? p->clock.coder_ns.load() * 1e-9 : 0.0;
   if (blocks) *blocks = p ? p->clock.blocks.load() : 0;
+  return 0;
+}
+
+int bwtc_hip_wavelet_host_progress(bwtc_hip_ctx* ctx, uint64_t* queued, uint64_t* finished) {
+  if (!ctx) return -1;
+  const HostPipeline* p = ctx->eng.pipeline;
+  if (queued) *queued = p ? p->clock.blocks.load() : 0;
+  if (finished) *finished = p ? p->clock.finished.load() : 0;
   return 0;
 }
 

@@ -22,6 +22,13 @@ constexpr int kWave = 64;
     }                                                                                 \
   } while (0)
 
+// Calls whose failure cannot be returned on the spot (inside void helpers, between launches)
+// leave their first error here; every transform / coder entry point checks it at its read-back,
+// next to hipGetLastError().  Per thread: a context is driven by one thread at a time.
+inline hipError_t& sticky_error() { static thread_local hipError_t e = hipSuccess; return e; }
+inline void note_error(hipError_t rc) { if (rc != hipSuccess && sticky_error() == hipSuccess) sticky_error() = rc; }
+inline hipError_t take_sticky_error() { const hipError_t e = sticky_error(); sticky_error() = hipSuccess; return e; }
+
 static inline u32 ceil_div(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 static inline int bit_width_u64(u64 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 

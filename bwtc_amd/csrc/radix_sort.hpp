@@ -314,11 +314,11 @@ struct ScatterProbe {
   double total_ms = 0.0;
   bool begin(hipStream_t st) {
     if (!enabled || used >= kMax) return false;
-    if (!created) { for (int i = 0; i < 2 * kMax; ++i) (void)hipEventCreate(&ev[i]); created = true; }
-    (void)hipEventRecord(ev[2 * used], st);
+    if (!created) { for (int i = 0; i < 2 * kMax; ++i) note_error(hipEventCreate(&ev[i])); created = true; }
+    note_error(hipEventRecord(ev[2 * used], st));
     return true;
   }
-  void end(hipStream_t st, u64 nbytes) { (void)hipEventRecord(ev[2 * used + 1], st); bytes[used++] = nbytes; }
+  void end(hipStream_t st, u64 nbytes) { note_error(hipEventRecord(ev[2 * used + 1], st)); bytes[used++] = nbytes; }
   // call after the stream has been synchronised
   void harvest() {
     for (int i = 0; i < used; ++i) {
@@ -628,14 +628,14 @@ static inline void radix_sort_pairs_sweep(K* k0, K* k1, u32* v0, u32* v1, u64 n,
   if (n > 1 && npasses > 0) {
     const u32 ntiles = ceil_div(n, radix_tile<K>());
     const u32 per_chain = (ntiles + kChains - 1) / kChains;
-    (void)hipMemsetAsync(ws.hist_all, 0, (size_t)npasses * kChains * kRadixBins * 4, st);
-    (void)hipMemsetAsync(ws.tickets, 0, (size_t)kSweepMaxPasses * kChains * 4, st);
+    note_error(hipMemsetAsync(ws.hist_all, 0, (size_t)npasses * kChains * kRadixBins * 4, st));
+    note_error(hipMemsetAsync(ws.tickets, 0, (size_t)kSweepMaxPasses * kChains * 4, st));
     const u32 hist_blocks = kChains * (per_chain < 768u ? per_chain : 768u);
     hipLaunchKernelGGL(k_radix_hist_all<K>, dim3(hist_blocks), dim3(kRadixTPB), 0, st, kin, n, bit_lo,
                        npasses, per_chain, ntiles, ws.hist_all);
     hipLaunchKernelGGL(k_radix_bases, dim3(npasses), dim3(kRadixBins), 0, st, ws.hist_all, ws.bases);
     for (int p = 0; p < npasses; ++p) {
-      (void)hipMemsetAsync(ws.status, 0, (size_t)ntiles * kRadixBins * 4, st);
+      note_error(hipMemsetAsync(ws.status, 0, (size_t)ntiles * kRadixBins * 4, st));
       const bool timed = probe && probe->begin(st);
       hipLaunchKernelGGL(k_radix_sweep<K>, dim3(((ntiles + 7u) / 8u) * 8u), dim3(kRadixTPB), 0, st,
                          kin, vin, kout, vout, n, bit_lo + p * kRadixBits, ntiles, per_chain,

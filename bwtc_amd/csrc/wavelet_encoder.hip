@@ -175,6 +175,12 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
     return 0;
   }
   if (!job.streams_ready) { *state_out = state_in; HostPipeline::finishNow(job); return 0; }
+  if (job.fused && e.wavelet_model != 'B') {
+    // prepared for the fused engines (no probability array) while the stream's model was 'B', queued
+    // after a switch to 'b' / 'u': those go the two-stage way and need the array
+    job.fused = false;
+    if (!job.prob.reserve(static_cast<size_t>(job.coded_pos.empty() ? 0 : job.coded_pos.back()) + 8)) return -2;
+  }
   *state_out = e.pipeline->queue(jobp, state_in, e.wavelet_model);
   return 0;
 }
@@ -289,11 +295,19 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
   return rc;
 }
 
+int wavelet_join_begun(BwtEngine& e) {
+  if (!e.deferred_queue) return 0;                    // _prepare / _queue callers place their blocks themselves
+  for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it) {
+    if (it->second->queued) continue;
+    const int rc = wavelet_encode_queue(e, it->first, e.wavelet_state, &e.wavelet_state);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 void wavelet_pipeline_release(BwtEngine& e) {
   // a block begun with _begin joins the stream one call later: the last one still has to
-  if (e.deferred_queue)
-    for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)
-      if (!it->second->queued) (void)wavelet_encode_queue(e, it->first, e.wavelet_state, &e.wavelet_state);
+  (void)wavelet_join_begun(e);
   e.half_job.reset();
   e.copy_job.reset();
   for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.begin(); it != e.jobs.end(); ++it)

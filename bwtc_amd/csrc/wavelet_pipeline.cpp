@@ -81,6 +81,7 @@ void HostPipeline::finishNow(WaveletJob& job) {
 void HostPipeline::finish(WaveletJob& job) {
   --clock.unfinished;
   finishNow(job);
+  ++clock.finished;
 }
 
 // Every group of the block is modelled: its sections' range coders.
@@ -129,7 +130,7 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
   job.models_left = job.coder->modelTasks();
   job.sections_left = job.coder->sectionTasks();
   ++clock.blocks;
-  if (job.models_left == 0 || job.sections_left == 0) { finishNow(job); return next_state; }
+  if (job.models_left == 0 || job.sections_left == 0) { finishNow(job); ++clock.finished; return next_state; }
   ++clock.unfinished;
   if (model == 'B' && max_fused_engines_ && job.fused) {
     job.models_left = 0;

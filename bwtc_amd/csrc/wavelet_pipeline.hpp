@@ -30,7 +30,7 @@ namespace bwtc_hip {
 
 // host time spent in the two stages (summed over threads), for BWTC_HIP_DEBUG
 struct StageClock {
-  std::atomic<uint64_t> model_ns{0}, coder_ns{0}, blocks{0};
+  std::atomic<uint64_t> model_ns{0}, coder_ns{0}, blocks{0}, finished{0};
   std::atomic<int> unfinished{0};      // blocks begun and not yet finished by the workers
 };
 

@@ -35,7 +35,7 @@ EXPORTS = [
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
     "bwtc_hip_memcpy_to_host", "bwtc_hip_host_alloc", "bwtc_hip_host_free",
-    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
@@ -85,6 +85,7 @@ def load():
     L.bwtc_hip_memcpy_to_device_async.argtypes = [_vp, _vp, _vp, _u64]
     L.bwtc_hip_copy_wait.argtypes = [_vp]
     L.bwtc_hip_wavelet_host_clock.argtypes = [_vp, _vp, _vp, _vp]
+    L.bwtc_hip_wavelet_host_progress.argtypes = [_vp, _vp, _vp]
     L.bwtc_hip_synth.argtypes = [ctypes.c_char, _u64, _u64, _vp]
     L.bwtc_hip_n_lf.restype = _u32
     L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
@@ -238,6 +239,13 @@ class Context:
         _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
                "bwtc_hip_wavelet_host_clock")
         return m.value, c.value, b.value
+
+    def wavelet_host_progress(self):
+        """(blocks that joined the host half, blocks whose record the workers have finished)."""
+        q, f = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self.lib.bwtc_hip_wavelet_host_progress(self.handle, ctypes.byref(q), ctypes.byref(f)),
+               "bwtc_hip_wavelet_host_progress")
+        return q.value, f.value
 
     def to_host(self, d_ptr, nbytes):
         out = np.empty(nbytes, np.uint8)

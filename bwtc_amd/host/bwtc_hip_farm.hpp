@@ -69,6 +69,8 @@ class BlockFarm {
     for (size_t d = 0; d < m_workers.size(); ++d) {
       Worker& w = *m_workers[d];
       for (int b = 0; b < 2; ++b) { bwtc_hip_free(w.ctx, w.d_in[b]); bwtc_hip_host_free(w.ctx, w.h_in[b]); }
+      for (size_t i = 0; i < w.outFree.size(); ++i) std::free(w.outFree[i]);
+      for (size_t i = 0; i < w.pending.size(); ++i) std::free(w.pending[i].out);
       if (w.d_comp) bwtc_hip_free(w.ctx, w.d_comp);
       bwtc_hip_destroy(w.ctx);
     }
@@ -127,7 +129,9 @@ class BlockFarm {
  private:
   struct Job { size_t index; uint32 size; int buf; int dev; };   // buf: host staging buffer, dev: device buffer
   struct Done { std::vector<byte> record; uint32 size; };
-  struct Pending { size_t index; uint32 size; uint64_t ticket; std::unique_ptr<std::vector<byte> > out; };
+  // out: where the context's workers leave the record -- compress_bound(maxBlock) bytes, NOT
+  // zero-filled (only the record's bytes are ever touched) and recycled through Worker::outFree
+  struct Pending { size_t index; uint32 size; uint64_t ticket; byte* out; };
   struct Worker {
     int device = 0;
     bwtc_hip_ctx* ctx = nullptr;
@@ -137,6 +141,7 @@ class BlockFarm {
     void* d_comp = nullptr;
     std::deque<Job> jobs;                 // assigned, not yet taken (guarded by the farm's mutex)
     std::deque<Pending> pending;          // 'B': queued on the context, record not collected yet (worker's own)
+    std::vector<byte*> outFree;           // 'B': record buffers not in use (at most depth + 1 exist per worker)
     size_t taken = 0;                     // jobs taken so far: job number t uses device buffer t & 1
     std::thread thread;
   };
@@ -156,13 +161,14 @@ class BlockFarm {
     m_cv.notify_all();
   }
   bool collectOldest(Worker& w) {
-    Pending p = std::move(w.pending.front());
+    Pending p = w.pending.front();
     w.pending.pop_front();
     uint64_t n = 0;
     const int rc = bwtc_hip_wavelet_encode_end(w.ctx, p.ticket, &n);
-    if (rc) { fail(rc, "bwtc_hip_wavelet_encode_end"); return false; }
-    p.out->resize((size_t)n);
-    deliver(p.index, p.size, *p.out);
+    if (rc) { std::free(p.out); fail(rc, "bwtc_hip_wavelet_encode_end"); return false; }
+    std::vector<byte> record(p.out, p.out + (size_t)n);              // the record's bytes only
+    w.outFree.push_back(p.out);
+    deliver(p.index, p.size, record);
     return true;
   }
 
@@ -211,23 +217,27 @@ class BlockFarm {
       const uint32 n_lf = bwtc_hip_n_lf(cur.size, m_sp);
       rc = bwtc_hip_bwt_block_device(w.ctx, d_blk, d_blk, cur.size, lf, n_lf, freqs);
       if (rc) return fail(rc, "bwtc_hip_bwt_block_device");
-      std::unique_ptr<std::vector<byte> > out(new std::vector<byte>(bwtc_hip_compress_bound(cur.size)));
       if (m_coder == 'H') {
         uint64_t n = 0;
         rc = bwtc_hip_huffman_encode_device(w.ctx, d_blk, cur.size, lf, n_lf, freqs, static_cast<uint8_t*>(w.d_comp),
                                             bwtc_hip_compress_bound(m_maxBlock), &n);
         if (rc) return fail(rc, "bwtc_hip_huffman_encode_device");
-        out->resize((size_t)n);
-        rc = bwtc_hip_memcpy_to_host(w.ctx, out->data(), w.d_comp, n);
+        std::vector<byte> out((size_t)n);                              // sized once the record's length is known
+        rc = bwtc_hip_memcpy_to_host(w.ctx, out.data(), w.d_comp, n);
         if (rc) return fail(rc, "bwtc_hip_memcpy_to_host");
-        deliver(cur.index, cur.size, *out);
+        deliver(cur.index, cur.size, out);
       } else {
         while (w.pending.size() >= m_depth) if (!collectOldest(w)) return;
         Pending p;
         p.index = cur.index; p.size = cur.size;
+        const uint64_t cap = bwtc_hip_compress_bound(m_maxBlock);
+        if (w.outFree.empty()) {
+          p.out = static_cast<byte*>(std::malloc((size_t)cap));
+          if (!p.out) return fail(-2, "farm record buffer");
+        } else { p.out = w.outFree.back(); w.outFree.pop_back(); }
         rc = bwtc_hip_wavelet_encode_device_prepare(w.ctx, d_blk, cur.size, lf, n_lf, freqs, m_threadsPerContext,
-                                                    out->data(), out->size(), &p.ticket);
-        if (rc) return fail(rc, "bwtc_hip_wavelet_encode_device_prepare");
+                                                    p.out, cap, &p.ticket);
+        if (rc) { std::free(p.out); return fail(rc, "bwtc_hip_wavelet_encode_device_prepare"); }
         {
           // the block's place in the stream: after block index - 1, whichever context holds that one
           std::unique_lock<std::mutex> g(m_mu);
@@ -238,9 +248,8 @@ class BlockFarm {
           if (rc == 0) { m_state = after; ++m_nextQueue; }
         }
         m_cv.notify_all();
-        if (rc) return fail(rc, "bwtc_hip_wavelet_encode_queue");
-        p.out = std::move(out);
-        w.pending.push_back(std::move(p));
+        if (rc) { std::free(p.out); return fail(rc, "bwtc_hip_wavelet_encode_queue"); }
+        w.pending.push_back(p);
       }
       if (haveNext) { cur = next; have = true; uploaded = true; } else have = false;
     }

@@ -219,6 +219,10 @@ uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
  * coder (adaptive models, range coders; seconds summed over threads) and the blocks queued. */
 int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds,
                                 uint64_t* blocks);
+/* Blocks that have joined the host half so far (*queued) and blocks whose record the worker
+ * threads have finished (*finished): what a caller needs to tell the rate the host half sustains
+ * from the rate at which blocks are begun. */
+int bwtc_hip_wavelet_host_progress(bwtc_hip_ctx* ctx, uint64_t* queued, uint64_t* finished);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 /* A new wavelet stream with the main probability model of coder letter `coder`
  * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,

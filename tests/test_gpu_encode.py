@@ -290,6 +290,43 @@ def test_wavelet_other_model_letters_on_the_device_route(hip_ctx, oracle):
         hip_ctx.wavelet_reset()
 
 
+def test_wavelet_start_with_begun_blocks_not_yet_in_their_stream(hip_ctx, oracle):
+    """_begin lets a block join its stream one or two calls later.  A new stream started in
+    between (bwtc_hip_wavelet_start) must not reach back: the begun blocks are coded with the old
+    stream's state and model, the next block starts the new one."""
+    d = synth.gen_text(3 * 400000, 23)
+    bs = 400000
+    blocks = [d[o:o + bs] for o in range(0, d.size, bs)]
+
+    def begin(blk):
+        d_in = hip_ctx.dmalloc(blk.size + 16)
+        try:
+            hip_ctx.to_device(d_in, blk)
+            lf, freqs = hip_ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+            out = np.zeros(hip_ctx.compress_bound(blk.size), np.uint8)
+            return hip_ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=4), out
+        finally:
+            hip_ctx.dfree(d_in)
+
+    try:
+        hip_ctx.wavelet_reset()
+        a = [begin(blocks[0]), begin(blocks[1])]          # stream 1 ('B'): two blocks begun, none collected
+        hip_ctx.wavelet_start("b")                        # stream 2 starts here
+        b = [begin(blocks[2])]
+        first = b"B"
+        for (t, out), blk in zip(a, blocks[:2]):
+            first += _packed(blk.size) + _packed(1) + b"\x00" + out[:hip_ctx.wavelet_encode_end(t)].tobytes()
+        first += b"\x00"
+        second = b"b"
+        for (t, out), blk in zip(b, blocks[2:]):
+            second += _packed(blk.size) + _packed(1) + b"\x00" + out[:hip_ctx.wavelet_encode_end(t)].tobytes()
+        second += b"\x00"
+        assert first == oracle.oracle_compress_wavelet("B", d[:2 * bs], bs, 8).tobytes()
+        assert second == oracle.oracle_compress_wavelet("b", d[2 * bs:], bs, 8).tobytes()
+    finally:
+        hip_ctx.wavelet_reset()
+
+
 def test_wavelet_B_context_closed_with_blocks_under_way():
     """bwtc_hip_destroy with uncollected blocks: they are finished (their records land in the
     buffers given to _begin), nothing hangs or crashes."""
