@@ -4,7 +4,9 @@
 #include "bwtc_hip.h"
 #include "entropy_host.hpp"
 #include "wavelet_host.hpp"
+#include "wavelet_gpu_models.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -493,6 +495,53 @@ int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run
   codes.push_back(0);
   std::vector<bwtc::wavelet::SectionOutput> outs;
   bwtc::wavelet::codeStreams(plan, coded_pos.data(), codes.data(), pick_threads(threads), state, &outs, nullptr, coder);
+  uint64_t n = 0;
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    if (n + outs[s].bytes.size() > out_cap) return -1;
+    std::memcpy(out + n, outs[s].bytes.data(), outs[s].bytes.size());
+    n += outs[s].bytes.size();
+  }
+  *out_bytes = n;
+  return 0;
+}
+
+int bwtc_hip_host_wavelet_streams_lanes(uint32_t n_sections, const uint32_t* first_run,
+                                        const uint8_t* run_sym, const uint32_t* run_start,
+                                        const uint32_t* run_freqs, const uint32_t* dist_offset,
+                                        const uint32_t* dist_len, const uint32_t* dist_cnt,
+                                        uint32_t threads, char coder, uint32_t* state, uint8_t* out,
+                                        uint64_t out_cap, uint64_t* out_bytes) {
+  if (!first_run || !run_sym || !run_start || !run_freqs || !dist_offset || !dist_len || !dist_cnt ||
+      !state || !out || !out_bytes || n_sections > 256 || coder != 'B') return -1;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t> > > dist(n_sections);
+  std::vector<bwtc::wavelet::SectionRuns> secs(n_sections);
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    for (uint32_t i = dist_offset[s]; i < dist_offset[s + 1]; ++i) dist[s].push_back(std::make_pair(dist_len[i], dist_cnt[i]));
+    secs[s].symbols = run_sym + first_run[s];
+    secs[s].starts = run_start + first_run[s];
+    secs[s].n_runs = first_run[s + 1] - first_run[s];
+    secs[s].run_freqs = run_freqs + (size_t)s * 256;
+    secs[s].dist = dist[s].data();
+    secs[s].n_dist = dist[s].size();
+  }
+  bwtc::wavelet::StreamPlan plan;
+  if (!bwtc::wavelet::planStreams(secs, &plan)) return -5;
+  std::vector<uint32_t> coded_pos;
+  std::vector<uint8_t> codes;
+  if (!bwtc::wavelet::expandStreamsOnHost(plan, secs, &coded_pos, &codes)) return -3;
+  const uint32_t total = coded_pos.back();
+  std::vector<uint32_t> packed(total / 16 + 2, 0);
+  std::memcpy(packed.data(), codes.data(), codes.size());
+  std::vector<bwtc::wavelet::gm::Task> tasks;
+  std::vector<bwtc::wavelet::gm::Chunk> chunks;
+  bwtc::wavelet::gm::buildTasks(plan, coded_pos.data(), &tasks, &chunks);
+  std::vector<uint16_t> w((size_t)total + 8);
+  if (!bwtc::wavelet::gm::modelsOnHostLanes(packed.data(), total, tasks, chunks, state, w.data())) return -7;
+  std::vector<bwtc::wavelet::SectionOutput> outs(plan.sections.size());
+  bwtc::wavelet::StreamCoder sc(plan, coded_pos.data(), *state, bwtc::wavelet::StreamCoder::Modelled());
+  std::atomic<size_t> cursor(0);
+  (void)threads;
+  sc.codeSectionsW(&cursor, w.data(), &outs);
   uint64_t n = 0;
   for (uint32_t s = 0; s < n_sections; ++s) {
     if (n + outs[s].bytes.size() > out_cap) return -1;

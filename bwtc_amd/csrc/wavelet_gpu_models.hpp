@@ -1,0 +1,326 @@
+// The adaptive models of the 'B' coder as data-parallel passes (device: wavelet_gpu_models.hip;
+// the same lane functions run on the host for the CPU tests, modelsOnHostLanes below).
+//
+// What the reference does (WaveletTree.hpp:637-809 with the models of
+// probmodels/ProbabilityModel.cpp:38-75): every coded element is coded with the probability of
+// ONE of fifteen small predictors -- the eight UnbiasedPredictors of FSM8 (main model), the four
+// of FSM<4> (gaps), the three of FSM<3> (integer codes) -- picked by three tiny state machines
+// that only look at the coded bits, and that predictor then moves 1/2^delay of the way towards
+// the coded bit (BitPredictors.hpp:37-65).  A model task (a symbol-tree node, or one integer
+// level) starts with fresh predictors; the main machine's state runs on from task to task, section
+// to section and block to block (FSM8::resetModel keeps it, FSM.hpp:196-205).
+//
+// Serial as written, but the structure is: (1) state machines = finite automata over the bits:
+// a composition scan gives every chunk its exact start states; (2) given the states, every
+// element names its predictor ("slot"), and the fifteen predictors of a task are INDEPENDENT
+// one-dimensional chains  x <- x +- ((bound - x) >> d)  over the subsequence of bits that name
+// them.  Those subsequences are gathered, stably, into one bit array ("slot space": slot-major,
+// then task, then order), where every chain is contiguous.  (3) A chain is cut into slot-chunks.
+// Both update maps are monotone and non-expanding on integers, so the images of the two extreme
+// start values bracket every start value; after kWarm updates the bracket is narrower than 2^d
+// (checked, not assumed).  Inside a bracket that narrow a step merges AT MOST ONE pair of
+// neighbouring candidates -- the pair (v, v+1) with (bound - v) = 0 mod 2^d -- so the whole map
+// "value at the chunk's start -> value at its end" is carried as (image of the lowest candidate,
+// bit mask of the surviving increments): O(1) per step.  A short serial walk over a chain's
+// chunks (one table look-up each) then gives every slot-chunk its TRUE start value, a second
+// pass over slot space leaves the true value at every 32nd position, and the last pass walks
+// the elements in coding order with exact predictors and writes, per element,
+//     w = bit << 15 | probability of the coded bit (12 bits),
+// which is all the range coder needs (wavelet_rc.hpp, runChainW).  Nothing is approximated: the
+// bytes are those of the sequential encoder, and an input the scheme cannot bracket raises an
+// error flag instead of a wrong byte.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BWTC_GM_HD __host__ __device__ __forceinline__
+#else
+#define BWTC_GM_HD inline
+#endif
+
+namespace bwtc {
+namespace wavelet {
+struct StreamPlan;
+namespace gm {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr u32 kChunk = 2048;       // elements per chunk: tasks cut along an aligned grid of the packed stream
+constexpr u32 kSlotChunk = 2048;   // slot-space positions per slot-chunk
+constexpr u32 kWarm = 256;         // updates from the extreme values before a slot-chunk (bracket < 2^d after ~175)
+constexpr u32 kSample = 32;        // true values are kept at every kSample-th slot-space position
+constexpr u32 kSlots = 15;
+constexpr u32 kSlotStride = 16;    // rows of the per-lane slot tables
+enum TaskType { kTRoot = 0, kTGaps = 1, kTInner = 2, kTInts = 3 };
+
+struct Task { u32 begin, end, type, first_chunk; };      // elements [begin, end) of the packed stream
+struct Chunk { u32 begin, end, task_first; };            // task | (first chunk of its task) << 31
+
+// error bits (a set bit means: this block is not coded from these probabilities)
+constexpr u32 kErrBracket = 1, kErrChain = 2, kErrTotal = 4;
+
+// ---- the fifteen predictors -------------------------------------------------------------------
+// slot 0..7 main (kept as the probability of a ONE: the upper four are InversePredictors,
+// 4096 - p), 8..11 gaps, 12..14 integer codes
+BWTC_GM_HD u32 slotFloor(u32 k) { return k >= 12 ? 100u : 2u; }
+BWTC_GM_HD u32 slotDelay(u32 k) { return (k == 0 || k == 7) ? 4u : 5u; }
+BWTC_GM_HD u32 slotInit(u32 k) { return k < 4 ? 2400u - 100u * k : k < 8 ? 1996u - 100u * (k - 4u) : 2048u; }
+BWTC_GM_HD u32 moved(u32 x, u32 bit, u32 floor, u32 d) {
+  return bit ? x + (((4096u - floor) - x) >> d) : x - ((x - floor) >> d);
+}
+
+// ---- the three state machines (FSM.hpp:42-67) ---------------------------------------------------
+BWTC_GM_HD u32 next8(u32 s, u32 bit) { return bit ? (s >= 4 ? (s < 7 ? s + 1 : 7u) : 4u) : (s < 4 ? (s ? s - 1 : 0u) : 3u); }
+BWTC_GM_HD u32 next4(u32 s, u32 bit) { return (bit << 1) | (s >> 1); }
+BWTC_GM_HD u32 next3(u32 s, u32 bit) { return bit ? (s < 2 ? s + 1 : 2u) : (s ? s - 1 : 0u); }
+
+// packed states of a chunk's start: mc | gc << 3 | ic << 5
+BWTC_GM_HD u32 packState(u32 mc, u32 gc, u32 ic) { return mc | (gc << 3) | (ic << 5); }
+
+// A chunk's effect on the three machines as maps: bits 0..23 the images of main states 0..7
+// (3 bits each), 24..31 of gap states 0..3 (2 bits each), 32..37 of integer states 0..2.
+constexpr u64 kMapIdentity = 0xFAC688ull | (0xE4ull << 24) | (0x24ull << 32);
+BWTC_GM_HD u64 mapConstGapsInts(u64 m, u32 gc, u32 ic) {           // the machines a task start resets
+  const u64 g = gc * 0x55u, i = ic * 0x15u;
+  return (m & 0xFFFFFFull) | (g << 24) | (i << 32);
+}
+// g after f
+BWTC_GM_HD u64 mapCompose(u64 f, u64 g) {
+  u64 h = 0;
+  for (u32 i = 0; i < 8; ++i) { const u32 fi = (u32)(f >> (3 * i)) & 7u; h |= (u64)((u32)(g >> (3 * fi)) & 7u) << (3 * i); }
+  for (u32 i = 0; i < 4; ++i) { const u32 fi = (u32)(f >> (24 + 2 * i)) & 3u; h |= (u64)((u32)(g >> (24 + 2 * fi)) & 3u) << (24 + 2 * i); }
+  for (u32 i = 0; i < 3; ++i) { const u32 fi = (u32)(f >> (32 + 2 * i)) & 3u; h |= (u64)((u32)(g >> (32 + 2 * fi)) & 3u) << (32 + 2 * i); }
+  return h;
+}
+BWTC_GM_HD u32 mapApply(u64 m, u32 st) {
+  const u32 mc = st & 7u, gc = (st >> 3) & 3u, ic = (st >> 5) & 3u;
+  return packState((u32)(m >> (3 * mc)) & 7u, (u32)(m >> (24 + 2 * gc)) & 3u, (u32)(m >> (32 + 2 * ic)) & 3u);
+}
+
+BWTC_GM_HD u32 codeAt(const u32* packed, u32 i) { return (packed[i >> 4] >> ((i & 15u) * 2u)) & 3u; }
+BWTC_GM_HD u32 bitAt(const u32* bits, u32 p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
+BWTC_GM_HD u32 popc(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (u32)__popc(v);
+#else
+  return (u32)__builtin_popcount(v);
+#endif
+}
+
+// One element's slot and the machines' next states.
+struct Machines { u32 mc, gc, ic; };
+BWTC_GM_HD u32 stepMachines(u32 type, u32 v, Machines& m) {
+  const u32 bit = v & 1u, flag = v >> 1;
+  u32 slot;
+  if (type == kTRoot) { slot = m.mc; m.mc = next8(m.mc, bit); }
+  else if (type == kTGaps) { slot = 8u + m.gc; m.gc = next4(m.gc, bit); }
+  else if (type == kTInts) { slot = 12u + m.ic; m.ic = next3(m.ic, bit); }
+  else {
+    slot = flag ? 8u + m.gc : m.mc;
+    m.mc = next8(m.mc, bit);                     // pm.updateState also under a gap (WaveletTree.hpp:724,751)
+    if (flag) m.gc = next4(m.gc, bit);
+  }
+  return slot;
+}
+
+// ---- pass 1: a chunk's state maps ------------------------------------------------------------------
+BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
+  const bool adv = type == kTRoot || type == kTInner;
+  bool changed = false;
+  u32 first = 0, run = 0, s = 0;                  // main: leading run of equal bits, then one state
+  u32 gk = 0, gb1 = 0, gb2 = 0;                   // gaps: number of updates (capped at 2), last and last-but-one bit
+  u32 i0 = 0, i1 = 1, i2 = 2;                     // integers: the images themselves
+  for (u32 i = begin; i < end; ++i) {
+    const u32 v = codeAt(packed, i), bit = v & 1u, flag = v >> 1;
+    if (adv) {
+      if (changed) s = next8(s, bit);
+      else if (run == 0) { first = bit; run = 1; }
+      else if (bit == first) run = run < 4 ? run + 1 : 4;
+      else { changed = true; s = bit ? 4u : 3u; }  // a change of bit value fixes the state (FSM.hpp:42-67)
+    }
+    if (type == kTGaps || (type == kTInner && flag)) { gb2 = gb1; gb1 = bit; gk = gk < 2 ? gk + 1 : 2; }
+    if (type == kTInts) { i0 = next3(i0, bit); i1 = next3(i1, bit); i2 = next3(i2, bit); }
+  }
+  u64 m = 0;
+  for (u32 st = 0; st < 8; ++st) {
+    u32 x = st;
+    if (changed) x = s; else for (u32 r = 0; r < run; ++r) x = next8(x, first);
+    m |= (u64)x << (3 * st);
+  }
+  for (u32 st = 0; st < 4; ++st) {
+    const u32 x = gk == 0 ? st : gk == 1 ? ((gb1 << 1) | (st >> 1)) : ((gb1 << 1) | gb2);
+    m |= (u64)x << (24 + 2 * st);
+  }
+  m |= (u64)i0 << 32; m |= (u64)i1 << 34; m |= (u64)i2 << 36;
+  return m;
+}
+
+// ---- pass 2: updates per slot ------------------------------------------------------------------------
+// tab: kSlotStride rows, this lane's column (row k at tab[k * stride]); zeroed here
+BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* tab, u32 stride) {
+  for (u32 k = 0; k < kSlots; ++k) tab[k * stride] = 0;
+  Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
+  for (u32 i = begin; i < end; ++i) {
+    const u32 slot = stepMachines(type, codeAt(packed, i), m);
+    tab[slot * stride] += 1;
+  }
+}
+
+// ---- pass 3: the bits, gathered by slot --------------------------------------------------------------
+// pos/acc: two tables as above.  pos[k] starts at base[k] (the chunk's first position of slot k in
+// slot space).  The words of `sbits` are shared with neighbouring chunks: OR-ed in.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BWTC_GM_OR(ptr, val) atomicOr((ptr), (val))
+#else
+#define BWTC_GM_OR(ptr, val) (*(ptr) |= (val))
+#endif
+BWTC_GM_HD void lanePartition(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* pos, u32* acc,
+                              u32 stride, u32* sbits) {
+  Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
+  for (u32 i = begin; i < end; ++i) {
+    const u32 v = codeAt(packed, i);
+    const u32 slot = stepMachines(type, v, m);
+    const u32 p = pos[slot * stride];
+    u32 a = acc[slot * stride] | ((v & 1u) << (p & 31u));
+    if ((p & 31u) == 31u) { if (a) BWTC_GM_OR(&sbits[p >> 5], a); a = 0; }
+    acc[slot * stride] = a;
+    pos[slot * stride] = p + 1;
+  }
+  for (u32 k = 0; k < kSlots; ++k) {
+    const u32 a = acc[k * stride];
+    if (a) BWTC_GM_OR(&sbits[(pos[k * stride] - 1u) >> 5], a);       // a != 0: at least one bit since the last flush
+  }
+}
+
+// ---- slot space ----------------------------------------------------------------------------------------
+// sb[0..ns]: start of every stream (slot-major, then task), sb[ns] = total; the last stream that
+// starts at or before p
+BWTC_GM_HD u32 streamAt(const u32* sb, u32 ns, u32 p) {
+  u32 lo = 0, hi = ns;                             // sb[lo] <= p < sb[hi] (sb[0] = 0; p < total = sb[ns])
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (sb[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// One step of a bracket: x0 = image of the lowest candidate, mask bit j = candidates j and j+1
+// still differ (by exactly one).  Fewer than 2^d candidates' values: at most one pair merges.
+BWTC_GM_HD void bracketStep(u32& x0, u32& mask, u32 bit, u32 floor, u32 d) {
+  if (mask) {
+    const u32 mod = (1u << d) - 1u;
+    const u32 t = (bit ? (4096u - floor) - x0 : floor - 1u - x0) & mod;   // the merging pair: values x0 + t, x0 + t + 1
+    if (t < popc(mask)) {
+      u32 m = mask;
+      for (u32 i = 0; i < t; ++i) m &= m - 1u;
+      mask &= ~(m & (0u - m));
+    }
+  }
+  x0 = moved(x0, bit, floor, d);
+}
+
+struct SlotMap { u32 lo_x0; u32 mask; };           // lo_x0 = bracket base L | x0 at the chunk's end << 16
+
+// pass 4: slot-chunk j = positions [j * kSlotChunk, ...): its map from start value to end value
+BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j, u32* err) {
+  const u32 p0 = j * kSlotChunk, p1 = p0 + kSlotChunk < total ? p0 + kSlotChunk : total;
+  u32 sg = streamAt(sb, ns, p0);
+  u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
+  const u32 s0 = sb[sg];
+  u32 x0, mask, L;
+  if (p0 - s0 <= kWarm) {                          // the chain starts close by: exact
+    x0 = slotInit(k);
+    for (u32 p = s0; p < p0; ++p) x0 = moved(x0, bitAt(sbits, p), floor, d);
+    L = x0; mask = 0;
+  } else {
+    u32 lo = floor, hi = 4096u - floor;
+    for (u32 p = p0 - kWarm; p < p0; ++p) { const u32 b = bitAt(sbits, p); lo = moved(lo, b, floor, d); hi = moved(hi, b, floor, d); }
+    const u32 w = hi - lo;
+    if (w >= (1u << d)) { *err |= kErrBracket; return SlotMap{0, 0}; }
+    L = lo; x0 = lo; mask = (1u << w) - 1u;
+  }
+  u32 next = sb[sg + 1];
+  for (u32 p = p0; p < p1; ++p) {
+    while (p >= next) {                            // another chain starts here: fresh predictor, known exactly
+      ++sg; next = sb[sg + 1];
+      k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
+      x0 = slotInit(k); mask = 0;
+    }
+    bracketStep(x0, mask, bitAt(sbits, p), floor, d);
+  }
+  return SlotMap{L | (x0 << 16), mask};
+}
+
+// pass 5: stream sg -- the true value at every slot-chunk border inside it
+BWTC_GM_HD void laneChain(const SlotMap* smap, const u32* sb, u32 sg, unsigned short* sstart, u32* err) {
+  const u32 s0 = sb[sg], s1 = sb[sg + 1];
+  if (s1 <= s0) return;
+  u32 j = s0 / kSlotChunk;
+  u32 t = 0;
+  bool first = true;
+  for (; (u64)(j + 1) * kSlotChunk < s1; ++j) {
+    const SlotMap m = smap[j];
+    if (first) { t = m.lo_x0 >> 16; first = false; }          // the chunk the chain starts in ends exactly
+    else {
+      const u32 off = t - (m.lo_x0 & 0xFFFFu);
+      if (off > 31u) { *err |= kErrChain; return; }
+      t = (m.lo_x0 >> 16) + popc(m.mask & ((1u << off) - 1u));
+    }
+    sstart[j + 1] = (unsigned short)t;
+  }
+}
+
+// pass 6: slot-chunk j again, from its true start value: the value at every kSample-th position
+BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j,
+                            const unsigned short* sstart, unsigned short* samples) {
+  const u32 p0 = j * kSlotChunk, p1 = p0 + kSlotChunk < total ? p0 + kSlotChunk : total;
+  u32 sg = streamAt(sb, ns, p0);
+  u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
+  u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
+  u32 next = sb[sg + 1];
+  for (u32 p = p0; p < p1; ++p) {
+    while (p >= next) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
+    if ((p & (kSample - 1u)) == 0) samples[p / kSample] = (unsigned short)x;
+    x = moved(x, bitAt(sbits, p), floor, d);
+  }
+}
+
+// pass 7: the elements of a chunk in coding order with exact predictors.  q: table row k = slot k.
+// out[i] = bit << 15 | probability of the coded bit
+BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32 task, u32 chunk, u32 nc, u32 nt,
+                         const u32* base, const u32* sb, const u32* sbits, const unsigned short* samples,
+                         u32* q, u32 stride, unsigned short* out) {
+  const u32 k_lo = type == kTGaps ? 8u : type == kTInts ? 12u : 0u;
+  const u32 k_hi = type == kTRoot ? 8u : type == kTInts ? 15u : 12u;
+  for (u32 k = k_lo; k < k_hi; ++k) {
+    const u32 P = base[k * nc + chunk], s0 = sb[k * nt + task];
+    const u32 floor = slotFloor(k), d = slotDelay(k);
+    const u32 a0 = P & ~(kSample - 1u);
+    u32 a, x;
+    if (a0 > s0) { a = a0; x = samples[a0 / kSample]; } else { a = s0; x = slotInit(k); }
+    for (u32 p = a; p < P; ++p) x = moved(x, bitAt(sbits, p), floor, d);
+    q[k * stride] = x;
+  }
+  Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
+  for (u32 i = begin; i < end; ++i) {
+    const u32 v = codeAt(packed, i), bit = v & 1u;
+    const u32 slot = stepMachines(type, v, m);
+    const u32 pr = q[slot * stride];
+    q[slot * stride] = moved(pr, bit, slotFloor(slot), slotDelay(slot));
+    out[i] = (unsigned short)((bit << 15) | (bit ? pr : 4096u - pr));
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+// Tasks (in coding order) and chunks of a block from its plan and the groups' coded positions.
+void buildTasks(const ::bwtc::wavelet::StreamPlan& plan, const u32* coded_pos, std::vector<Task>* tasks,
+                std::vector<Chunk>* chunks);
+
+// The passes above run lane by lane on the host (tests; the product runs them on the GPU).
+// state: the main machine's carried state, updated.  false: an error flag was raised.
+bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& tasks, const std::vector<Chunk>& chunks,
+                       u32* state, unsigned short* out);
+
+}  // namespace gm
+}  // namespace wavelet
+}  // namespace bwtc

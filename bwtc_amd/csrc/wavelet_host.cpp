@@ -977,6 +977,19 @@ StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, cons
   std::stable_sort(sections_.begin(), sections_.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
 }
 
+StreamCoder::StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, uint32_t end_state, Modelled)
+    : plan_(plan), pos_(coded_pos), codes_(nullptr), end_state_(end_state), model_('B') {
+  const size_t nsec = plan.sections.size();
+  std::vector<uint64_t> weight(nsec, 0);
+  for (size_t s = 0; s < nsec; ++s) {
+    const StreamPlan::Section& sec = plan.sections[s];
+    if (sec.level_first.size() < 2) continue;
+    weight[s] = coded_pos[sec.group_base + sec.level_first.back()] - coded_pos[sec.group_base];
+    sections_.push_back(static_cast<uint32_t>(s));
+  }
+  std::stable_sort(sections_.begin(), sections_.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+}
+
 // state of the main model before group `group` of section s (group = n_nodes: after the section)
 uint32_t StreamCoder::stateBefore(size_t s, uint32_t group) const {
   // 'b' and 'u' reset their state machine with the model: every group starts from the same state
@@ -1124,6 +1137,19 @@ size_t StreamCoder::codeSectionsPaired(std::atomic<size_t>* cursor, const uint16
     for (int l = 0; l < 2; ++l) {
       if (busy[l] && lane[l].i >= lane[l].e) { lane[l].finish(); busy[l] = false; ++finished; }
     }
+  }
+}
+
+size_t StreamCoder::codeSectionsW(std::atomic<size_t>* cursor, const uint16_t* w, std::vector<SectionOutput>* out) const {
+  size_t finished = 0;
+  for (;;) {
+    const size_t k = cursor->fetch_add(1);
+    if (k >= sections_.size()) return finished;
+    CoderChain c;
+    startSection(k, out, &c);
+    runChainW(c, w, c.e);
+    c.finish();
+    ++finished;
   }
 }
 

@@ -102,6 +102,10 @@ class StreamCoder {
  public:
   StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, const uint8_t* codes, uint32_t fsm8_state,
               char model = 'B');
+  // For a block whose models ran elsewhere (wavelet_gpu_models.hpp): no model tasks, no packed
+  // streams; only the sections' chains over  w = bit << 15 | probability of the coded bit.
+  struct Modelled {};
+  StreamCoder(const StreamPlan& plan, const uint32_t* coded_pos, uint32_t end_state, Modelled);
   uint32_t endState() const { return end_state_; }        // the carried state after the block
   uint64_t elements() const;                              // size of the probability buffer
   size_t modelTasks() const { return tasks_.size(); }
@@ -119,6 +123,9 @@ class StreamCoder {
   // the same for sections taken from a shared cursor, two chains at a time in one thread;
   // returns how many sections this call finished
   size_t codeSectionsPaired(std::atomic<size_t>* cursor, const uint16_t* prob, std::vector<SectionOutput>* out) const;
+  // sections from the cursor, one chain at a time (a chain alone runs at its full speed: the
+  // block's longest one sets its latency), over w-elements (runChainW)
+  size_t codeSectionsW(std::atomic<size_t>* cursor, const uint16_t* w, std::vector<SectionOutput>* out) const;
   // section task k as a chain for the 16-lane coder engine (wavelet_rc.hpp): puts the section's
   // prefix into out[section] and describes the elements to code
   void describeChain(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out, ChainDesc* d) const;

@@ -49,6 +49,26 @@ void runChain(CoderChain& c, const uint8_t* codes, const uint16_t* prob, uint64_
   c.lo = lo; c.size = size; c.i = std::max(c.i, until);
 }
 
+void runChainW(CoderChain& c, const uint16_t* w, uint64_t until) {
+  const uint64_t kChunk = 16384;
+  uint32_t lo = c.lo, size = c.size;
+  uint64_t b = c.i;
+  for (; b < until; b += kChunk) {
+    const uint64_t ce = std::min(until, b + kChunk);
+    uint8_t* o = c.room(kChunk);
+    for (uint64_t i = b; i < ce; ++i) {
+      const uint32_t x = w[i];
+      const uint32_t bit = x >> 15, m = x & 0x7FFFu;
+      const uint32_t ns = static_cast<uint32_t>((static_cast<int64_t>(static_cast<uint64_t>(size) * m) + (static_cast<int64_t>(bit) - 2049)) >> 12);
+      lo += (bit - 1u) & (size - ns);                                     // a zero moves the low end up by t + 1 = size - ns
+      size = ns;
+      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; }
+    }
+    c.used = static_cast<size_t>(o - c.out->data());
+  }
+  c.lo = lo; c.size = size; c.i = std::max(c.i, until);
+}
+
 // Two chains stepped alternately.  A chain alone is bound by its multiply latency and by the
 // mispredicted byte-output branch; with the first output byte written branch-free (a second
 // byte in the same step is rare and stays a branch) two independent chains overlap and the

@@ -36,6 +36,12 @@ struct CoderChain {
 };
 
 void runChain(CoderChain& c, const uint8_t* codes, const uint16_t* prob, uint64_t until);
+// The same chain over elements that arrive as  w = bit << 15 | probability of the CODED bit
+// (wavelet_gpu_models.hpp): with m = w & 0x7FFF the next size is  (size * m + bit - 2049) >> 12
+// (arithmetic shift) for either bit value -- t - 1 = floor((size p - 2048) / 4096) for a one,
+// size - t - 1 = floor((size (4096 - p) - 2049) / 4096) for a zero -- so the loop-carried chain is
+// a multiply, an add and a shift.  Same bytes as runChain.
+void runChainW(CoderChain& c, const uint16_t* w, uint64_t until);
 // both chains read the same block's codes/prob; runs until the shorter chain ends
 void runChainPair(CoderChain& a, CoderChain& b, const uint8_t* codes, const uint16_t* prob);
 // the same for chains of different blocks, at most `limit` elements of each

@@ -42,7 +42,7 @@ EXPORTS = [
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
     "bwtc_hip_wavelet_encode_device_prepare", "bwtc_hip_wavelet_encode_queue",
-    "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -117,6 +117,7 @@ def load():
     L.bwtc_hip_host_wavelet_sections.argtypes = [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, ctypes.c_char, _vp, _vp, _u64,
                                                  ctypes.POINTER(_u64)]
     L.bwtc_hip_host_wavelet_streams.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
+    L.bwtc_hip_host_wavelet_streams_lanes.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
     L.bwtc_hip_host_huffman_lengths.restype = None
     L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
     L.bwtc_hip_host_huffman_codes.restype = None

@@ -257,6 +257,15 @@ int bwtc_hip_host_wavelet_streams(uint32_t n_sections, const uint32_t* first_run
                                   const uint32_t* dist_len, const uint32_t* dist_cnt,
                                   uint32_t threads, char coder, uint32_t* state, uint8_t* out,
                                   uint64_t out_cap, uint64_t* out_bytes);
+/* The same, with the adaptive models run the way the GPU runs them (wavelet_gpu_models.hpp: state
+ * scan, slot space, bracketed chains, w-elements) -- lane by lane on the host, for tests without a
+ * GPU.  Coder 'B' only.  -7: the passes raised their error flag. */
+int bwtc_hip_host_wavelet_streams_lanes(uint32_t n_sections, const uint32_t* first_run,
+                                  const uint8_t* run_sym, const uint32_t* run_start,
+                                  const uint32_t* run_freqs, const uint32_t* dist_offset,
+                                  const uint32_t* dist_len, const uint32_t* dist_cnt,
+                                  uint32_t threads, char coder, uint32_t* state, uint8_t* out,
+                                  uint64_t out_cap, uint64_t* out_bytes);
 
 /* Host-only pieces of the 'H' coder (no device work; usable without a GPU).  They are the
  * small-table steps the encoder runs between its device passes, exported so the host logic

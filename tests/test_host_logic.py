@@ -167,6 +167,32 @@ def test_wavelet_host_half_matches_oracle(oracle):
             assert end_state2 == end_state
 
 
+def test_wavelet_models_as_data_parallel_passes_on_host_lanes(oracle):
+    """wavelet_gpu_models.hpp -- the adaptive models as the GPU runs them (state scan, slot space,
+    bracketed chains, w-elements, runChainW) -- lane by lane on the host: the same payload and the
+    same carried state as the sequential models, from every starting state, on inputs whose chains
+    span many slot-chunks."""
+    from bwtc_amd import synth
+    H = _host()
+    rng = np.random.default_rng(77)
+    cases = [np.frombuffer(b"abracadabra", np.uint8), np.frombuffer(b"a", np.uint8),
+             np.full(30000, 65, np.uint8), synth.gen_text(200000, 3), synth.gen_dna(150000, 2),
+             synth.gen_random_bytes(120000, 1),
+             np.repeat(rng.integers(0, 5, 2000).astype(np.uint8), rng.integers(1, 300, 2000)),
+             (rng.geometric(0.2, 90000) % 256).astype(np.uint8),
+             np.tile(np.array([0, 1], np.uint8), 100000),                       # alternating bits everywhere
+             np.repeat(rng.integers(0, 2, 40000).astype(np.uint8), rng.integers(1, 4, 40000)),
+             synth.gen_text(3 << 20, 11)]
+    for i, d in enumerate(cases):
+        bwt, lf, freqs = oracle.oracle_bwt_block(d, 4)
+        sections = oracle.oracle_sections(freqs)
+        for state in ((4, 0, 7) if d.size < 1 << 20 else (4,)):
+            want, end_want = _host_wavelet_payload(H, bwt, sections, state, 2, "bwtc_hip_host_wavelet_streams")
+            got, end_got = _host_wavelet_payload(H, bwt, sections, state, 2, "bwtc_hip_host_wavelet_streams_lanes")
+            assert got == want, (i, d.size, state)
+            assert end_got == end_want, (i, d.size, state)
+
+
 def test_wavelet_other_model_letters(oracle):
     """Coder letters 'b' (FSM<6, EvenIntervalPredictor<4>>) and 'u' (EvenIntervalPredictor<4>):
     both host routes of the product against the oracle's restatement.  No reference-produced
