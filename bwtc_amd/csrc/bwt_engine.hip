@@ -978,6 +978,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     use_sweep = e && std::strcmp(e, "sweep") == 0;
     const char* w = std::getenv("BWTC_HIP_WAVELET");
     wavelet_on_host = w && std::strcmp(w, "host") == 0;
+    const char* gmv = std::getenv("BWTC_HIP_MODELS");
+    device_models = !(gmv && std::strcmp(gmv, "host") == 0);
     const char* d = std::getenv("BWTC_HIP_WAVELET_DEPTH");
     if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
     dense_route = !(std::getenv("BWTC_HIP_DENSE") && std::getenv("BWTC_HIP_DENSE")[0] == '0');
@@ -1011,6 +1013,8 @@ hipError_t BwtEngine::ensure_d2h_stream() {
   hipError_t rc = hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking);
   if (rc != hipSuccess) return rc;
   rc = hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming);
+  if (rc != hipSuccess) return rc;
+  rc = hipEventCreateWithFlags(&ev_models, hipEventDisableTiming);
   if (rc != hipSuccess) return rc;
   return hipEventCreateWithFlags(&ev_codes, hipEventBlockingSync | hipEventDisableTiming);
 }
@@ -1055,6 +1059,10 @@ void BwtEngine::release() {
   if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
   if (d2h_stream) { (void)hipStreamSynchronize(d2h_stream); (void)hipStreamDestroy(d2h_stream); d2h_stream = nullptr; }
   if (ev_packed) { (void)hipEventDestroy(ev_packed); ev_packed = nullptr; }
+  if (ev_models) { (void)hipEventDestroy(ev_models); ev_models = nullptr; }
+  if (d_gm) { (void)hipFree(d_gm); d_gm = nullptr; gm_bytes = 0; }
+  if (d_gm_w) { (void)hipFree(d_gm_w); d_gm_w = nullptr; gm_w_bytes = 0; }
+  if (h_gm) { (void)hipHostFree(h_gm); h_gm = nullptr; h_gm_bytes = 0; }
   if (ev_codes) { (void)hipEventDestroy(ev_codes); ev_codes = nullptr; }
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);

@@ -77,6 +77,9 @@ struct WaveletSectionStats;
 struct DeviceWaveletJob : WaveletJob {
   ~DeviceWaveletJob() { if (plan_future.valid()) plan_future.wait(); }   // the planner reads this object
   PinnedBytes codes_owner;
+  PinnedBytes w_owner;                 // device-modelled blocks: the w-elements (2 bytes per coded element)
+  u32* h_tail = nullptr;               //   {state after the block, error flags, elements counted} (in w_owner, behind the elements)
+  u32 gm_state_in = 0;                 //   the carried state the device passes were given
   // between wavelet_encode_prepare and wavelet_encode_queue
   bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
   bool host_route = false;             // coded by encodeSections at queue time instead
@@ -100,7 +103,7 @@ struct BwtEngine {
   hipStream_t copy_stream = nullptr;   // uploads that overlap the kernels (bwtc_hip_memcpy_to_device_async)
   hipEvent_t ev_copy = nullptr;
   hipStream_t d2h_stream = nullptr;    // packed wavelet streams to the host, under the next block's transform
-  hipEvent_t ev_packed = nullptr, ev_codes = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_codes = nullptr, ev_models = nullptr;
   bool codes_in_flight = false;
   hipError_t ensure_d2h_stream();
   hipError_t codes_wait();             // the copy issued by wavelet_streams_device(async_copy) has landed
@@ -146,6 +149,13 @@ struct BwtEngine {
   u8* h_stats = nullptr;   // pinned: the run scanner's statistics come down in two copies and one wait
   u64 h_stats_bytes = 0;
   int reserve_stats(u64 bytes);
+  // the adaptive models on the device (wavelet_gpu_models.hip): tables and slot space, the
+  // w-elements of the block whose copy to the host is under way, pinned staging for the tables
+  void* d_gm = nullptr;  u64 gm_bytes = 0;
+  void* d_gm_w = nullptr; u64 gm_w_bytes = 0;
+  u8* h_gm = nullptr;    u64 h_gm_bytes = 0;
+  int reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes);
+  bool device_models = true;           // BWTC_HIP_MODELS=host: the models stay on the worker threads (all routes of round 2)
   std::vector<u32> long_count;   // host scratch of the run statistics: counts of long run lengths, all zero between calls
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)
   // run arrays of the 'B' coder's scanner, two buffers: block i is scanned while block i-1's runs still
@@ -164,6 +174,7 @@ struct BwtEngine {
   unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH
   u64 huge_group_elements = 32u << 20; // BWTC_HIP_HUGE_MI: groups this large are modelled by scalar tasks, not lanes
   std::vector<std::unique_ptr<PinnedBytes> > codes_free;              // recycled: no fresh pages per block
+  std::vector<std::unique_ptr<PinnedBytes> > w_free;
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
@@ -250,7 +261,11 @@ int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const 
 // streams copied into `codes` (wavelet_tree.hip); plan comes from bwtc::wavelet::planStreams.
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           PinnedBytes* codes, bool async_copy = false);
+                           PinnedBytes* codes, bool async_copy = false, const u32** d_packed = nullptr);
+// The adaptive models of a block whose packed streams are in HBM (wavelet_gpu_models.hip): queues
+// the passes and the copy of the w-elements to h_w, of {state after, error flags, count} to h_tail.
+int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
+                          const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
 // 112-157, 159-163) for a device-resident transformed block, in two halves so that blocks

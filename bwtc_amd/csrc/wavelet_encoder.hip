@@ -55,14 +55,39 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
   const u8* d_run_sym = e.d_run_sym[job.run_buf];
   if (on_device) {
     if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
-    int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner, async_copy);
+    // The adaptive models on the device (wavelet_gpu_models.hip) need the carried state BEFORE this
+    // block: known when every block begun before it has joined the stream -- the _begin flow, where
+    // the block before the previous one joined while the scanner ran.  (_prepare / _queue callers
+    // learn the state at _queue time: their models stay on the worker threads.)
+    const bool on_gpu = e.device_models && e.wavelet_model == 'B' && e.deferred_queue;
+    if (on_gpu)
+      for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator o = e.jobs.begin(); o != e.jobs.end() && o->first < job.rank; ++o)
+        if (!o->second->queued) { const int rq = wavelet_encode_queue(e, o->first, e.wavelet_state, &e.wavelet_state); if (rq) return rq; }
+    const u32* d_packed = nullptr;
+    int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner, async_copy, &d_packed);
     if (rc) return rc;
     job.copying = async_copy;
     job.codes = job.codes_owner.data();
     const auto t2 = std::chrono::steady_clock::now();
     if (!e.pipeline) e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
-    job.fused = e.pipeline->fusedNow(e.wavelet_model);
-    if (!job.fused) {
+    if (on_gpu && e.wt_coded) {
+      if (!e.w_free.empty()) { job.w_owner.swap(*e.w_free.back()); e.w_free.pop_back(); }
+      const u64 w_bytes = ((u64)e.wt_coded * 2 + 63) / 64 * 64;
+      if (!job.w_owner.reserve(w_bytes + 64)) return -2;
+      job.h_tail = reinterpret_cast<u32*>(job.w_owner.data() + w_bytes);
+      job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = 0xFFFFFFFFu;
+      job.gm_state_in = e.wavelet_state;
+      rc = wavelet_models_device(e, d_packed, (u32)e.wt_coded, job.plan, job.coded_pos, e.wavelet_state,
+                                 reinterpret_cast<uint16_t*>(job.w_owner.data()), job.h_tail);
+      if (rc) return rc;
+      job.w = reinterpret_cast<const uint16_t*>(job.w_owner.data());
+      job.copying = true;                             // the w-elements are on their way (d2h stream) whatever async_copy says
+      if (debug)
+        std::fprintf(stderr, "wavelet: models of %llu coded elements queued on the device %.2f ms after the streams\n",
+                     (unsigned long long)e.wt_coded, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+    }
+    job.fused = !job.w && e.pipeline->fusedNow(e.wavelet_model);
+    if (!job.fused && !job.w) {
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(e.wt_coded + 8)) return -2;
     }
@@ -175,6 +200,22 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
     return 0;
   }
   if (!job.streams_ready) { *state_out = state_in; HostPipeline::finishNow(job); return 0; }
+  if (job.w) {
+    // modelled on the device: the copy has landed (above); the passes report themselves
+    const u32 n_coded = job.coded_pos.empty() ? 0u : job.coded_pos.back();
+    const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[0] < 8 && job.gm_state_in == state_in &&
+                    e.wavelet_model == 'B';
+    if (ok) {
+      job.w_end_state = job.h_tail[0];
+    } else {
+      // never seen; kept so that a surprise costs time, not bytes: the block's models run on the
+      // worker threads from its packed streams (which came down as well)
+      std::fprintf(stderr, "bwtc_hip: the device models of a block were not used (flags %u, counted %u of %u, state %u/%u); "
+                   "its models run on the host instead\n", job.h_tail[1], job.h_tail[2], n_coded, job.gm_state_in, state_in);
+      job.w = nullptr;
+      if (!job.prob.reserve(static_cast<size_t>(n_coded) + 8)) return -2;
+    }
+  }
   if (job.fused && e.wavelet_model != 'B') {
     // prepared for the fused engines (no probability array) while the stream's model was 'B', queued
     // after a switch to 'b' / 'u': those go the two-stage way and need the array
@@ -282,6 +323,10 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
     e.codes_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
     e.codes_free.back()->swap(job.codes_owner);
   }
+  if (job.w_owner.size() && e.w_free.size() < e.max_inflight) {
+    e.w_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
+    e.w_free.back()->swap(job.w_owner);
+  }
   if (job.prob.size() && e.prob_free.size() < e.max_inflight) {
     e.prob_free.push_back(std::unique_ptr<RawBuffer<uint16_t> >(new RawBuffer<uint16_t>()));
     e.prob_free.back()->swap(job.prob);
@@ -320,6 +365,7 @@ void wavelet_pipeline_release(BwtEngine& e) {
   delete e.pipeline;                              // joins the workers (engines retire when nothing is queued)
   e.pipeline = nullptr;
   e.codes_free.clear();
+  e.w_free.clear();
   e.prob_free.clear();
 }
 

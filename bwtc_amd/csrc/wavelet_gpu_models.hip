@@ -1,0 +1,264 @@
+// The adaptive models of the 'B' coder on the GPU: the lane functions of wavelet_gpu_models.hpp as
+// kernels, one lane per chunk (element passes) or per slot-chunk (slot-space passes).  Input: the
+// block's packed streams as wavelet_tree.hip left them in HBM; output: one 16-bit word per coded
+// element (bit, probability of the coded bit), copied to the host for the range coders.
+// A block of 526 M coded elements is 260 K chunks: every pass has the whole chip's lanes busy
+// with short serial walks; the passes are bound by instruction issue and LDS latency, not by HBM
+// (they read 0.13 GB of streams a few times and write 1 GB once).
+#include "bwt_engine.hpp"
+#include "scan.hpp"
+#include "wavelet_gpu_models.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace bwtc_hip {
+
+namespace gm = bwtc::wavelet::gm;
+
+constexpr int kGmTPB = 256;
+constexpr int kGmStateTPB = 1024;
+constexpr int kGmStateE = 8;
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_map(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
+                                                   const gm::Task* __restrict__ tasks, u32 nc, u64* __restrict__ cmap) {
+  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
+  if (c >= nc) return;
+  const gm::Chunk ch = chunks[c];
+  cmap[c] = gm::laneMap(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type);
+}
+
+// One workgroup: composition scan of the chunks' maps in coding order -> every chunk's start
+// states; *state_out = the main machine's state after the block.
+__global__ __launch_bounds__(kGmStateTPB) void k_gm_state(const gm::Chunk* __restrict__ chunks, const u64* __restrict__ cmap,
+                                                          u32 nc, u32 state_in, u32* __restrict__ cstate,
+                                                          u32* __restrict__ state_out) {
+  __shared__ u64 s_agg[kGmStateTPB];
+  __shared__ u32 s_carry;
+  const u32 tid = threadIdx.x;
+  if (tid == 0) s_carry = gm::packState(state_in & 7u, 2, 1);
+  __syncthreads();
+  for (u32 tile0 = 0; tile0 < nc; tile0 += kGmStateTPB * kGmStateE) {
+    const u32 c0 = tile0 + tid * kGmStateE;
+    u64 m[kGmStateE];
+    bool first[kGmStateE];
+#pragma unroll
+    for (int i = 0; i < kGmStateE; ++i) {
+      const bool in = c0 + i < nc;
+      m[i] = in ? cmap[c0 + i] : gm::kMapIdentity;
+      first[i] = in && (chunks[c0 + i].task_first >> 31);
+    }
+    u64 agg = gm::kMapIdentity;
+#pragma unroll
+    for (int i = 0; i < kGmStateE; ++i) {
+      if (first[i]) agg = gm::mapConstGapsInts(agg, 2, 1);
+      agg = gm::mapCompose(agg, m[i]);
+    }
+    s_agg[tid] = agg;
+    __syncthreads();
+    for (u32 off = 1; off < kGmStateTPB; off <<= 1) {
+      const u64 v = tid >= off ? gm::mapCompose(s_agg[tid - off], agg) : agg;
+      __syncthreads();
+      s_agg[tid] = agg = v;
+      __syncthreads();
+    }
+    u32 st = gm::mapApply(tid ? s_agg[tid - 1] : gm::kMapIdentity, s_carry);
+#pragma unroll
+    for (int i = 0; i < kGmStateE; ++i) {
+      if (c0 + i < nc) {
+        if (first[i]) st = gm::packState(st & 7u, 2, 1);
+        cstate[c0 + i] = st;
+        st = gm::mapApply(m[i], st);
+      }
+    }
+    __syncthreads();
+    if (tid == kGmStateTPB - 1) s_carry = st;
+    __syncthreads();
+  }
+  if (tid == 0) *state_out = s_carry & 7u;
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_count(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
+                                                     const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
+                                                     u32 nc, u32* __restrict__ cnt) {
+  __shared__ u32 tab[gm::kSlotStride][kGmTPB];
+  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
+  if (c >= nc) return;
+  const gm::Chunk ch = chunks[c];
+  gm::laneCount(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type, cstate[c], &tab[0][threadIdx.x], kGmTPB);
+  for (u32 k = 0; k < gm::kSlots; ++k) cnt[(u64)k * nc + c] = tab[k][threadIdx.x];
+}
+
+// sb[k * nt + t] = where stream (slot k, task t) starts in slot space; sb[15 nt] = total
+__global__ __launch_bounds__(kGmTPB) void k_gm_streams(const u32* __restrict__ base, const gm::Task* __restrict__ tasks,
+                                                       u32 nc, u32 nt, u32* __restrict__ sb) {
+  const u32 i = blockIdx.x * kGmTPB + threadIdx.x;
+  if (i > gm::kSlots * nt) return;
+  if (i == gm::kSlots * nt) { sb[i] = base[(u64)gm::kSlots * nc]; return; }
+  const u32 k = i / nt, t = i - k * nt;
+  sb[i] = base[(u64)k * nc + tasks[t].first_chunk];
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_partition(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
+                                                         const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
+                                                         const u32* __restrict__ base, u32 nc, u32* __restrict__ sbits) {
+  __shared__ u32 pos[gm::kSlotStride][kGmTPB];
+  __shared__ u32 acc[gm::kSlotStride][kGmTPB];
+  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
+  if (c >= nc) return;
+  const gm::Chunk ch = chunks[c];
+  for (u32 k = 0; k < gm::kSlots; ++k) { pos[k][threadIdx.x] = base[(u64)k * nc + c]; acc[k][threadIdx.x] = 0; }
+  gm::lanePartition(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type, cstate[c], &pos[0][threadIdx.x],
+                    &acc[0][threadIdx.x], kGmTPB, sbits);
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_bracket(const u32* __restrict__ sbits, const u32* __restrict__ sb, u32 ns, u32 nt,
+                                                       u32 total, u32 nsc, gm::SlotMap* __restrict__ smap, u32* __restrict__ err) {
+  const u32 j = blockIdx.x * kGmTPB + threadIdx.x;
+  if (j >= nsc) return;
+  u32 e = 0;
+  smap[j] = gm::laneBracket(sbits, sb, ns, nt, total, j, &e);
+  if (e) atomicOr(err, e);
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_chain(const gm::SlotMap* __restrict__ smap, const u32* __restrict__ sb, u32 ns,
+                                                     unsigned short* __restrict__ sstart, u32* __restrict__ err) {
+  const u32 sg = blockIdx.x * kGmTPB + threadIdx.x;
+  if (sg >= ns) return;
+  u32 e = 0;
+  gm::laneChain(smap, sb, sg, sstart, &e);
+  if (e) atomicOr(err, e);
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_samples(const u32* __restrict__ sbits, const u32* __restrict__ sb, u32 ns, u32 nt,
+                                                       u32 total, u32 nsc, const unsigned short* __restrict__ sstart,
+                                                       unsigned short* __restrict__ samples) {
+  const u32 j = blockIdx.x * kGmTPB + threadIdx.x;
+  if (j >= nsc) return;
+  gm::laneSamples(sbits, sb, ns, nt, total, j, sstart, samples);
+}
+
+__global__ __launch_bounds__(kGmTPB) void k_gm_emit(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
+                                                    const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
+                                                    const u32* __restrict__ base, const u32* __restrict__ sb,
+                                                    const u32* __restrict__ sbits, const unsigned short* __restrict__ samples,
+                                                    u32 nc, u32 nt, unsigned short* __restrict__ out) {
+  __shared__ u32 q[gm::kSlotStride][kGmTPB];
+  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
+  if (c >= nc) return;
+  const gm::Chunk ch = chunks[c];
+  const u32 t = ch.task_first & 0x7FFFFFFFu;
+  gm::laneEmit(packed, ch.begin, ch.end, tasks[t].type, cstate[c], t, c, nc, nt, base, sb, sbits, samples,
+               &q[0][threadIdx.x], kGmTPB, out);
+}
+
+static inline u64 gm_align(u64 v) { return (v + 255) / 256 * 256; }
+
+int BwtEngine::reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes) {
+  if (device_bytes > gm_bytes) {
+    if (d_gm) (void)hipFree(d_gm);
+    d_gm = nullptr; gm_bytes = 0;
+    const u64 want = gm_align(device_bytes + device_bytes / 8);
+    BWTC_HIP_TRY(hipMalloc(&d_gm, want));
+    gm_bytes = want;
+  }
+  if (host_bytes > h_gm_bytes) {
+    if (h_gm) (void)hipHostFree(h_gm);
+    h_gm = nullptr; h_gm_bytes = 0;
+    const u64 want = gm_align(host_bytes + host_bytes / 8);
+    BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_gm), want, hipHostMallocDefault));
+    h_gm_bytes = want;
+  }
+  if (w_bytes > gm_w_bytes) {
+    if (d_gm_w) (void)hipFree(d_gm_w);
+    d_gm_w = nullptr; gm_w_bytes = 0;
+    const u64 want = gm_align(w_bytes + w_bytes / 8);
+    BWTC_HIP_TRY(hipMalloc(&d_gm_w, want));
+    gm_w_bytes = want;
+  }
+  return 0;
+}
+
+// d_packed: the block's packed streams (n_coded elements) in HBM.  Queues the passes on the
+// engine's stream and the copy of the w-elements (and of {state after the block, error flags}) to
+// h_w / h_tail on the d2h stream; nothing is waited for.  state_in = the main machine's state
+// before the block.
+int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
+                          const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail) {
+  hipStream_t st = e.stream;
+  std::vector<gm::Task> tasks;
+  std::vector<gm::Chunk> chunks;
+  gm::buildTasks(plan, coded_pos.data(), &tasks, &chunks);
+  const u32 nt = (u32)tasks.size(), nc = (u32)chunks.size();
+  if (nt == 0 || nc == 0 || n_coded == 0) return -1;
+  const u32 ns = gm::kSlots * nt;
+  const u32 nsc = ceil_div(n_coded, gm::kSlotChunk);
+  const u64 n_base = (u64)gm::kSlots * nc + 1;
+
+  u64 at = 0;
+  auto take = [&](u64 bytes) { const u64 o = at; at = gm_align(at + bytes); return o; };
+  const u64 o_tasks = take((u64)nt * sizeof(gm::Task));
+  const u64 o_chunks = take((u64)nc * sizeof(gm::Chunk));
+  const u64 tables_end = at;
+  const u64 o_cmap = take((u64)nc * 8);
+  const u64 o_cstate = take((u64)nc * 4);
+  const u64 o_base = take(n_base * 4);
+  const u64 o_partial = take(((u64)ceil_div(n_base, kScanTile) + 1) * 4);
+  const u64 o_sb = take(((u64)ns + 1) * 4);
+  const u64 o_sbits = take(((u64)n_coded / 32 + 2) * 4);
+  const u64 o_smap = take((u64)nsc * sizeof(gm::SlotMap));
+  const u64 o_sstart = take(((u64)nsc + 1) * 2);
+  const u64 o_samples = take(((u64)n_coded / gm::kSample + 2) * 2);
+  const u64 o_tail = take(16);
+  int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
+  if (rc) return rc;
+  u8* base = static_cast<u8*>(e.d_gm);
+  std::memcpy(e.h_gm + o_tasks, tasks.data(), (size_t)nt * sizeof(gm::Task));
+  std::memcpy(e.h_gm + o_chunks, chunks.data(), (size_t)nc * sizeof(gm::Chunk));
+  BWTC_HIP_TRY(hipMemcpyAsync(base, e.h_gm, tables_end, hipMemcpyHostToDevice, st));
+  const gm::Task* d_tasks = reinterpret_cast<const gm::Task*>(base + o_tasks);
+  const gm::Chunk* d_chunks = reinterpret_cast<const gm::Chunk*>(base + o_chunks);
+  u64* d_cmap = reinterpret_cast<u64*>(base + o_cmap);
+  u32* d_cstate = reinterpret_cast<u32*>(base + o_cstate);
+  u32* d_base = reinterpret_cast<u32*>(base + o_base);
+  u32* d_sb = reinterpret_cast<u32*>(base + o_sb);
+  u32* d_sbits = reinterpret_cast<u32*>(base + o_sbits);
+  gm::SlotMap* d_smap = reinterpret_cast<gm::SlotMap*>(base + o_smap);
+  unsigned short* d_sstart = reinterpret_cast<unsigned short*>(base + o_sstart);
+  unsigned short* d_samples = reinterpret_cast<unsigned short*>(base + o_samples);
+  u32* d_tail = reinterpret_cast<u32*>(base + o_tail);              // [0] state after the block, [1] error flags
+  unsigned short* d_w = static_cast<unsigned short*>(e.d_gm_w);
+
+  BWTC_HIP_TRY(hipMemsetAsync(d_tail, 0, 16, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_sbits, 0, ((u64)n_coded / 32 + 2) * 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_base + n_base - 1, 0, 4, st));
+  const dim3 gc(ceil_div(nc, kGmTPB)), gs(ceil_div(nsc, kGmTPB)), tpb(kGmTPB);
+  hipLaunchKernelGGL(k_gm_map, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, nc, d_cmap);
+  hipLaunchKernelGGL(k_gm_state, dim3(1), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, state_in, d_cstate, d_tail);
+  hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, nc, d_base);
+  exclusive_scan_u32(d_base, n_base, reinterpret_cast<u32*>(base + o_partial), st);
+  hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
+  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, nc, d_sbits);
+  hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_chain, dim3(ceil_div(ns, kGmTPB)), tpb, 0, st, d_smap, d_sb, ns, d_sstart, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_samples, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_sstart, d_samples);
+  hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_samples,
+                     nc, nt, d_w);
+  // total of the scan = every element counted once (else the tables do not describe the streams)
+  BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + n_base - 1, 4, hipMemcpyDeviceToDevice, st));
+  BWTC_HIP_TRY(e.ensure_d2h_stream());
+  BWTC_HIP_TRY(hipEventRecord(e.ev_models, st));
+  BWTC_HIP_TRY(hipStreamWaitEvent(e.d2h_stream, e.ev_models, 0));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_w, d_w, (u64)n_coded * 2, hipMemcpyDeviceToHost, e.d2h_stream));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_tail, d_tail, 16, hipMemcpyDeviceToHost, e.d2h_stream));
+  BWTC_HIP_TRY(hipEventRecord(e.ev_codes, e.d2h_stream));
+  e.codes_in_flight = true;
+  if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "models on the device: %u coded elements, %u tasks, %u chunks, %u slot-chunks, state in %u\n",
+                 n_coded, nt, nc, nsc, state_in);
+  return 0;
+}
+
+}  // namespace bwtc_hip

@@ -110,6 +110,27 @@ BWTC_GM_HD u32 popc(u32 v) {
 #endif
 }
 
+// f(i, v) for the elements [begin, end) of the packed stream, one load per sixteen elements
+template <class F>
+BWTC_GM_HD void forElements(const u32* packed, u32 begin, u32 end, F f) {
+  if (begin >= end) return;
+  for (u32 wi = begin >> 4; wi <= (end - 1u) >> 4; ++wi) {
+    const u32 lo = wi << 4 > begin ? wi << 4 : begin, hi = (wi + 1u) << 4 < end ? (wi + 1u) << 4 : end;
+    u32 word = packed[wi] >> ((lo & 15u) * 2u);
+    for (u32 i = lo; i < hi; ++i, word >>= 2) f(i, word & 3u);
+  }
+}
+// f(p, bit) for the positions [p0, p1) of a bit array, one load per thirty-two
+template <class F>
+BWTC_GM_HD void forBits(const u32* bits, u32 p0, u32 p1, F f) {
+  if (p0 >= p1) return;
+  for (u32 wi = p0 >> 5; wi <= (p1 - 1u) >> 5; ++wi) {
+    const u32 lo = wi << 5 > p0 ? wi << 5 : p0, hi = (wi + 1u) << 5 < p1 ? (wi + 1u) << 5 : p1;
+    u32 word = bits[wi] >> (lo & 31u);
+    for (u32 p = lo; p < hi; ++p, word >>= 1) f(p, word & 1u);
+  }
+}
+
 // One element's slot and the machines' next states.
 struct Machines { u32 mc, gc, ic; };
 BWTC_GM_HD u32 stepMachines(u32 type, u32 v, Machines& m) {
@@ -133,8 +154,8 @@ BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
   u32 first = 0, run = 0, s = 0;                  // main: leading run of equal bits, then one state
   u32 gk = 0, gb1 = 0, gb2 = 0;                   // gaps: number of updates (capped at 2), last and last-but-one bit
   u32 i0 = 0, i1 = 1, i2 = 2;                     // integers: the images themselves
-  for (u32 i = begin; i < end; ++i) {
-    const u32 v = codeAt(packed, i), bit = v & 1u, flag = v >> 1;
+  forElements(packed, begin, end, [&](u32, u32 v) {
+    const u32 bit = v & 1u, flag = v >> 1;
     if (adv) {
       if (changed) s = next8(s, bit);
       else if (run == 0) { first = bit; run = 1; }
@@ -143,7 +164,7 @@ BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
     }
     if (type == kTGaps || (type == kTInner && flag)) { gb2 = gb1; gb1 = bit; gk = gk < 2 ? gk + 1 : 2; }
     if (type == kTInts) { i0 = next3(i0, bit); i1 = next3(i1, bit); i2 = next3(i2, bit); }
-  }
+  });
   u64 m = 0;
   for (u32 st = 0; st < 8; ++st) {
     u32 x = st;
@@ -163,10 +184,10 @@ BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
 BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* tab, u32 stride) {
   for (u32 k = 0; k < kSlots; ++k) tab[k * stride] = 0;
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
-  for (u32 i = begin; i < end; ++i) {
-    const u32 slot = stepMachines(type, codeAt(packed, i), m);
+  forElements(packed, begin, end, [&](u32, u32 v) {
+    const u32 slot = stepMachines(type, v, m);
     tab[slot * stride] += 1;
-  }
+  });
 }
 
 // ---- pass 3: the bits, gathered by slot --------------------------------------------------------------
@@ -180,15 +201,14 @@ BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 s
 BWTC_GM_HD void lanePartition(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* pos, u32* acc,
                               u32 stride, u32* sbits) {
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
-  for (u32 i = begin; i < end; ++i) {
-    const u32 v = codeAt(packed, i);
+  forElements(packed, begin, end, [&](u32, u32 v) {
     const u32 slot = stepMachines(type, v, m);
     const u32 p = pos[slot * stride];
     u32 a = acc[slot * stride] | ((v & 1u) << (p & 31u));
     if ((p & 31u) == 31u) { if (a) BWTC_GM_OR(&sbits[p >> 5], a); a = 0; }
     acc[slot * stride] = a;
     pos[slot * stride] = p + 1;
-  }
+  });
   for (u32 k = 0; k < kSlots; ++k) {
     const u32 a = acc[k * stride];
     if (a) BWTC_GM_OR(&sbits[(pos[k * stride] - 1u) >> 5], a);       // a != 0: at least one bit since the last flush
@@ -230,24 +250,24 @@ BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, 
   u32 x0, mask, L;
   if (p0 - s0 <= kWarm) {                          // the chain starts close by: exact
     x0 = slotInit(k);
-    for (u32 p = s0; p < p0; ++p) x0 = moved(x0, bitAt(sbits, p), floor, d);
+    forBits(sbits, s0, p0, [&](u32, u32 b) { x0 = moved(x0, b, floor, d); });
     L = x0; mask = 0;
   } else {
     u32 lo = floor, hi = 4096u - floor;
-    for (u32 p = p0 - kWarm; p < p0; ++p) { const u32 b = bitAt(sbits, p); lo = moved(lo, b, floor, d); hi = moved(hi, b, floor, d); }
+    forBits(sbits, p0 - kWarm, p0, [&](u32, u32 b) { lo = moved(lo, b, floor, d); hi = moved(hi, b, floor, d); });
     const u32 w = hi - lo;
     if (w >= (1u << d)) { *err |= kErrBracket; return SlotMap{0, 0}; }
     L = lo; x0 = lo; mask = (1u << w) - 1u;
   }
   u32 next = sb[sg + 1];
-  for (u32 p = p0; p < p1; ++p) {
-    while (p >= next) {                            // another chain starts here: fresh predictor, known exactly
+  forBits(sbits, p0, p1, [&](u32 p, u32 b) {
+    while (p >= next && sg + 1u < ns) {            // another chain starts here: fresh predictor, known exactly
       ++sg; next = sb[sg + 1];
       k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
       x0 = slotInit(k); mask = 0;
     }
-    bracketStep(x0, mask, bitAt(sbits, p), floor, d);
-  }
+    bracketStep(x0, mask, b, floor, d);
+  });
   return SlotMap{L | (x0 << 16), mask};
 }
 
@@ -278,11 +298,11 @@ BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32
   u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
   u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
   u32 next = sb[sg + 1];
-  for (u32 p = p0; p < p1; ++p) {
-    while (p >= next) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
+  forBits(sbits, p0, p1, [&](u32 p, u32 b) {
+    while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
     if ((p & (kSample - 1u)) == 0) samples[p / kSample] = (unsigned short)x;
-    x = moved(x, bitAt(sbits, p), floor, d);
-  }
+    x = moved(x, b, floor, d);
+  });
 }
 
 // pass 7: the elements of a chunk in coding order with exact predictors.  q: table row k = slot k.
@@ -298,17 +318,21 @@ BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 st
     const u32 a0 = P & ~(kSample - 1u);
     u32 a, x;
     if (a0 > s0) { a = a0; x = samples[a0 / kSample]; } else { a = s0; x = slotInit(k); }
-    for (u32 p = a; p < P; ++p) x = moved(x, bitAt(sbits, p), floor, d);
+    forBits(sbits, a, P, [&](u32, u32 b) { x = moved(x, b, floor, d); });
     q[k * stride] = x;
   }
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
-  for (u32 i = begin; i < end; ++i) {
-    const u32 v = codeAt(packed, i), bit = v & 1u;
+  u32 held = 0;                                    // the element at an even index waits for its neighbour: 4-byte stores
+  forElements(packed, begin, end, [&](u32 i, u32 v) {
+    const u32 bit = v & 1u;
     const u32 slot = stepMachines(type, v, m);
     const u32 pr = q[slot * stride];
     q[slot * stride] = moved(pr, bit, slotFloor(slot), slotDelay(slot));
-    out[i] = (unsigned short)((bit << 15) | (bit ? pr : 4096u - pr));
-  }
+    const u32 w = (bit << 15) | (bit ? pr : 4096u - pr);
+    if ((i & 1u) == 0 && i + 1u < end) held = w;
+    else if ((i & 1u) && i > begin) *reinterpret_cast<u32*>(out + i - 1u) = held | (w << 16);
+    else out[i] = (unsigned short)w;
+  });
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------

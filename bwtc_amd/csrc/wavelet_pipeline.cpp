@@ -123,6 +123,36 @@ void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
 
 uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t fsm8_state, char model) {
   WaveletJob& job = *jobp;
+  if (job.w) {
+    // The models ran on the device: what is left are the sections' range-coder chains, each on its
+    // own (a chain alone advances at its full speed, and the block's longest one is its latency),
+    // as many tasks as the block's elements are multiples of its longest chain, at least two.
+    job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.w_end_state, bwtc::wavelet::StreamCoder::Modelled()));
+    job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());
+    job.t_queued = job.t_modelled = std::chrono::steady_clock::now();
+    job.models_left = 0;
+    job.sections_left = job.coder->sectionTasks();
+    ++clock.blocks;
+    if (job.sections_left == 0) { finishNow(job); ++clock.finished; return job.w_end_state; }
+    ++clock.unfinished;
+    const uint64_t longest = std::max<uint64_t>(1, job.coder->largestSectionElements());
+    const size_t balanced = static_cast<size_t>(std::min<uint64_t>(pool_.size(), (job.coder->elements() + longest - 1) / longest));
+    const size_t engines = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(2, balanced), job.coder->sectionTasks()));
+    std::vector<std::function<void()> > next;
+    for (size_t q = 0; q < engines; ++q) {
+      next.push_back([this, jobp] {
+        WaveletJob& j = *jobp;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t did = j.coder->codeSectionsW(&j.section_cursor, j.w, &j.outs);
+        clock.coder_ns += since(t0);
+        bool fin;
+        { std::lock_guard<std::mutex> g(j.mu); j.sections_left -= did; fin = did > 0 && j.sections_left == 0; }
+        if (fin) finish(j);
+      });
+    }
+    pool_.submit(job.rank, next);
+    return job.w_end_state;
+  }
   job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes, fsm8_state, model));
   const uint32_t next_state = job.coder->endState();
   job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());

@@ -204,6 +204,9 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   std::vector<bwtc::wavelet::SectionOutput> outs;
   std::vector<std::vector<bwtc::wavelet::FusedGroup> > fused_groups;   // fused engines: the sections' group lists
   bool fused = false;                                // coded by the fused engines (no `prob`); set before queue()
+  const uint16_t* w = nullptr;                       // modelled on the device: bit << 15 | probability of the coded bit,
+                                                     //   per coded element (wavelet_gpu_models.hpp); no model tasks then
+  uint32_t w_end_state = 4;                          //   and the carried state after the block
   std::mutex mu;
   std::condition_variable cv;
   size_t models_left = 0, sections_left = 0;

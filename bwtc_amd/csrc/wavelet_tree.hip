@@ -394,7 +394,7 @@ int BwtEngine::reserve_stats(u64 bytes) {
 // packed elements.
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
-                           PinnedBytes* codes, bool async_copy) {
+                           PinnedBytes* codes, bool async_copy, const u32** d_packed) {
   hipStream_t st = e.stream;
   const auto t_entry = std::chrono::steady_clock::now();
   const u32 nsec = (u32)plan.sections.size();
@@ -525,6 +525,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
     if ((*coded_pos)[g] == 0xFFFFFFFFu) (*coded_pos)[g] = (*coded_pos)[g + 1];
   e.wt_elements = n;
   e.wt_coded = n_coded;
+  if (d_packed) *d_packed = ptr32(o_packed);
   return 0;
 }
 
