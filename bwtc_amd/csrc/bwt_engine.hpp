@@ -52,6 +52,7 @@ class PinnedBytes {
       locked_ = true;
     } else {
       (void)hipGetLastError();                     // not an error of the caller's stream
+      if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "PinnedBytes: %zu bytes could not be page-locked, using ordinary memory\n", n + n / 8);
       q = std::malloc(n + n / 8);
       if (!q) return false;
       locked_ = false;

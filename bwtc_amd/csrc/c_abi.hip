@@ -530,7 +530,7 @@ int bwtc_hip_host_wavelet_streams_lanes(uint32_t n_sections, const uint32_t* fir
   std::vector<uint8_t> codes;
   if (!bwtc::wavelet::expandStreamsOnHost(plan, secs, &coded_pos, &codes)) return -3;
   const uint32_t total = coded_pos.back();
-  std::vector<uint32_t> packed(total / 16 + 2, 0);
+  std::vector<uint32_t> packed(total / 16 + 8, 0);
   std::memcpy(packed.data(), codes.data(), codes.size());
   std::vector<bwtc::wavelet::gm::Task> tasks;
   std::vector<bwtc::wavelet::gm::Chunk> chunks;

@@ -123,12 +123,34 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_bracket(const u32* __restrict__ s
   if (e) atomicOr(err, e);
 }
 
-__global__ __launch_bounds__(kGmTPB) void k_gm_chain(const gm::SlotMap* __restrict__ smap, const u32* __restrict__ sb, u32 ns,
-                                                     unsigned short* __restrict__ sstart, u32* __restrict__ err) {
-  const u32 sg = blockIdx.x * kGmTPB + threadIdx.x;
-  if (sg >= ns) return;
+// level (a): one wave per group, lane = candidate of the group's first bracket
+__global__ __launch_bounds__(64) void k_gm_chain_group(const gm::SlotMap* __restrict__ smap, u32 nsc, u32 gsize,
+                                                       unsigned short* __restrict__ gmap, unsigned short* __restrict__ gL) {
+  const u32 g = blockIdx.x, cand = threadIdx.x;
+  if (cand >= 32) return;
+  gmap[g * 32u + cand] = (unsigned short)gm::laneChainGroup(smap, nsc, gsize, g, cand);
+  if (cand == 0) gL[g] = (unsigned short)(smap[g * gsize].lo_x0 & 0xFFFFu);
+}
+// level (b): the groups' maps into LDS, one thread walks them
+__global__ __launch_bounds__(1024) void k_gm_chain_top(const unsigned short* __restrict__ gmap, const unsigned short* __restrict__ gL,
+                                                       u32 ng, unsigned short* __restrict__ tg, u32* __restrict__ err) {
+  __shared__ unsigned short s_map[gm::kChainGroups * 32];
+  __shared__ unsigned short s_L[gm::kChainGroups], s_t[gm::kChainGroups];
+  for (u32 i = threadIdx.x; i < ng * 32u; i += 1024) s_map[i] = gmap[i];
+  for (u32 i = threadIdx.x; i < ng; i += 1024) s_L[i] = gL[i];
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 e = 0; gm::laneChainTop(s_map, s_L, ng, s_t, &e); if (e) atomicOr(err, e); }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < ng; i += 1024) tg[i] = s_t[i];
+}
+// level (c): lane per group
+__global__ __launch_bounds__(64) void k_gm_chain_fill(const gm::SlotMap* __restrict__ smap, u32 nsc, u32 gsize, u32 ng,
+                                                      const unsigned short* __restrict__ tg, unsigned short* __restrict__ sstart,
+                                                      u32* __restrict__ err) {
+  const u32 g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= ng) return;
   u32 e = 0;
-  gm::laneChain(smap, sb, sg, sstart, &e);
+  gm::laneChainFill(smap, nsc, gsize, g, tg, sstart, &e);
   if (e) atomicOr(err, e);
 }
 
@@ -210,6 +232,8 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   const u64 o_sbits = take(((u64)n_coded / 32 + 2) * 4);
   const u64 o_smap = take((u64)nsc * sizeof(gm::SlotMap));
   const u64 o_sstart = take(((u64)nsc + 1) * 2);
+  const u32 gsize = gm::chainGroupSize(nsc), ng = ceil_div(nsc, gsize);
+  const u64 o_gmap = take((u64)ng * 64), o_gL = take((u64)ng * 2), o_tg = take((u64)ng * 2);
   const u64 o_samples = take(((u64)n_coded / gm::kSample + 2) * 2);
   const u64 o_tail = take(16);
   int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
@@ -242,7 +266,12 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
   hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, nc, d_sbits);
   hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_tail + 1);
-  hipLaunchKernelGGL(k_gm_chain, dim3(ceil_div(ns, kGmTPB)), tpb, 0, st, d_smap, d_sb, ns, d_sstart, d_tail + 1);
+  unsigned short* d_gmap = reinterpret_cast<unsigned short*>(base + o_gmap);
+  unsigned short* d_gL = reinterpret_cast<unsigned short*>(base + o_gL);
+  unsigned short* d_tg = reinterpret_cast<unsigned short*>(base + o_tg);
+  hipLaunchKernelGGL(k_gm_chain_group, dim3(ng), dim3(64), 0, st, d_smap, nsc, gsize, d_gmap, d_gL);
+  hipLaunchKernelGGL(k_gm_chain_top, dim3(1), dim3(1024), 0, st, d_gmap, d_gL, ng, d_tg, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(ng, 64)), dim3(64), 0, st, d_smap, nsc, gsize, ng, d_tg, d_sstart, d_tail + 1);
   hipLaunchKernelGGL(k_gm_samples, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_sstart, d_samples);
   hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_samples,
                      nc, nt, d_w);

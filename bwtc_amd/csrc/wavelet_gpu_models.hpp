@@ -110,14 +110,53 @@ BWTC_GM_HD u32 popc(u32 v) {
 #endif
 }
 
-// f(i, v) for the elements [begin, end) of the packed stream, one load per sixteen elements
+// f(i, v) for the elements [begin, end) of the packed stream: 64 elements (16 bytes) per load, the
+// next load issued before the current piece is walked (a lane's loads are a serial chain of HBM /
+// L2 latencies otherwise); the packed array is padded to whole 16-byte pieces.
+struct Piece { u32 w[4]; };
+BWTC_GM_HD Piece loadPiece(const u32* packed, u32 q) {
+  Piece p;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4 v = reinterpret_cast<const uint4*>(packed)[q];
+  p.w[0] = v.x; p.w[1] = v.y; p.w[2] = v.z; p.w[3] = v.w;
+#else
+  for (u32 k = 0; k < 4; ++k) p.w[k] = packed[q * 4u + k];
+#endif
+  return p;
+}
+BWTC_GM_HD u32 pieceWord(const Piece& p, u32 k) {           // selects, not an indexed (scratch) access
+  const u32 a = k & 1u ? p.w[1] : p.w[0], b = k & 1u ? p.w[3] : p.w[2];
+  return k & 2u ? b : a;
+}
 template <class F>
 BWTC_GM_HD void forElements(const u32* packed, u32 begin, u32 end, F f) {
   if (begin >= end) return;
-  for (u32 wi = begin >> 4; wi <= (end - 1u) >> 4; ++wi) {
-    const u32 lo = wi << 4 > begin ? wi << 4 : begin, hi = (wi + 1u) << 4 < end ? (wi + 1u) << 4 : end;
-    u32 word = packed[wi] >> ((lo & 15u) * 2u);
-    for (u32 i = lo; i < hi; ++i, word >>= 2) f(i, word & 3u);
+  const u32 q0 = begin >> 6, q1 = (end - 1u) >> 6;
+  Piece cur = loadPiece(packed, q0);
+  for (u32 q = q0; q <= q1; ++q) {
+    const Piece nxt = loadPiece(packed, q < q1 ? q + 1u : q);
+    const u32 base = q << 6;
+    if (base >= begin && base + 64u <= end) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+      for (u32 k = 0; k < 4; ++k) {
+        u32 word = pieceWord(cur, k);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4
+#endif
+        for (u32 e = 0; e < 16; ++e, word >>= 2) f(base + k * 16u + e, word & 3u);
+      }
+    } else {
+      for (u32 k = 0; k < 4; ++k) {
+        const u32 wb = base + k * 16u;
+        const u32 lo = wb > begin ? wb : begin, hi = wb + 16u < end ? wb + 16u : end;
+        if (lo >= hi) continue;
+        u32 word = pieceWord(cur, k) >> ((lo & 15u) * 2u);
+        for (u32 i = lo; i < hi; ++i, word >>= 2) f(i, word & 3u);
+      }
+    }
+    cur = nxt;
   }
 }
 // f(p, bit) for the positions [p0, p1) of a bit array, one load per thirty-two
@@ -147,8 +186,22 @@ BWTC_GM_HD u32 stepMachines(u32 type, u32 v, Machines& m) {
   return slot;
 }
 
+template <u32 TYPE>
+BWTC_GM_HD u32 stepMachinesT(u32 v, Machines& m) { return stepMachines(TYPE, v, m); }   // TYPE is a constant: one branch survives
+
+// The walks are compiled once per task type (the inner loops then carry no type tests); a wave's
+// lanes nearly always share their type (a task's chunks are consecutive).
+#define BWTC_GM_BY_TYPE(type, CALL)                                                        \
+  do {                                                                                     \
+    if ((type) == kTRoot) { constexpr u32 TYPE = kTRoot; CALL; }                           \
+    else if ((type) == kTGaps) { constexpr u32 TYPE = kTGaps; CALL; }                      \
+    else if ((type) == kTInts) { constexpr u32 TYPE = kTInts; CALL; }                      \
+    else { constexpr u32 TYPE = kTInner; CALL; }                                           \
+  } while (0)
+
 // ---- pass 1: a chunk's state maps ------------------------------------------------------------------
-BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
+template <u32 type>
+BWTC_GM_HD u64 laneMapT(const u32* packed, u32 begin, u32 end) {
   const bool adv = type == kTRoot || type == kTInner;
   bool changed = false;
   u32 first = 0, run = 0, s = 0;                  // main: leading run of equal bits, then one state
@@ -178,16 +231,81 @@ BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
   m |= (u64)i0 << 32; m |= (u64)i1 << 34; m |= (u64)i2 << 36;
   return m;
 }
+// The same map from the chunk's TAIL alone, where that is enough (nearly always):
+//   main      four advancing elements fix the state whatever it was -- a change of bit value among
+//             them does, and so do four equal bits (FSM.hpp:42-67 saturates after four steps);
+//   gaps      the state is (last bit, bit before it) of the gap-coded elements;
+//   integers  two equal bits in a row fix the saturating counter; what follows is replayed.
+// Falls back to the full walk when the tail does not decide (short chunks, an INNER chunk with
+// fewer than two gap-coded elements in its last 64, integer bits that alternate over 64 elements).
+BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
+  const u32 n = end - begin;
+  bool quick = n >= 4;
+  u64 m = 0;
+  if (quick) {
+    const u32 tail = n < 64u ? n : 64u;            // elements end - tail .. end - 1
+    u32 bits = 0, flags = 0;                       // bit e = element end - 1 - e (the LAST element is bit 0), e < 32
+    u64 bits64 = 0;                                // the same for all 64 (integers)
+    for (u32 e = 0; e < tail; ++e) {
+      const u32 v = codeAt(packed, end - 1u - e);
+      if (e < 32u) { bits |= (v & 1u) << e; flags |= (v >> 1) << e; }
+      bits64 |= (u64)(v & 1u) << e;
+    }
+    if (type == kTRoot || type == kTInner) {
+      const u32 b4 = bits & 1u;
+      const u32 x = (bits ^ (0u - b4)) & 15u;      // set where one of the last four bits differs from the last one
+      const u32 r = x & 2u ? 1u : x & 4u ? 2u : x & 8u ? 3u : 4u;
+      const u32 st = r == 4u ? (b4 ? 7u : 0u) : (b4 ? 3u + r : 4u - r);
+      m |= (u64)(st * 0x249249u);                  // the same three bits eight times
+    } else {
+      m |= kMapIdentity & 0xFFFFFFull;
+    }
+    if (type == kTGaps) {
+      m |= (u64)((((bits & 1u) << 1) | ((bits >> 1) & 1u)) * 0x55u) << 24;
+    } else if (type == kTInner) {
+      const u32 f = flags & ((tail >= 32u) ? 0xFFFFFFFFu : ((1u << tail) - 1u));
+      if (popc(f) >= 2u) {
+        const u32 e1 = (u32)__builtin_ctz(f), e2 = (u32)__builtin_ctz(f & (f - 1u));
+        m |= (u64)(((((bits >> e1) & 1u) << 1) | ((bits >> e2) & 1u)) * 0x55u) << 24;
+      } else quick = false;
+    } else {
+      m |= kMapIdentity & (0xFFull << 24);
+    }
+    if (type == kTInts) {
+      const u64 eq = ~(bits64 ^ (bits64 >> 1)) & (tail >= 64u ? ~0ull >> 1 : ((1ull << (tail - 1u)) - 1ull));   // bit e: elements e and e+1 (from the end) are equal
+      if (eq) {
+        const u32 e = (u32)__builtin_ctzll(eq);    // the latest such pair: element end - 1 - e is its second bit
+        u32 st = (bits64 >> e) & 1u ? 2u : 0u;
+        for (u32 k = e; k-- > 0;) st = next3(st, (u32)(bits64 >> k) & 1u);
+        m |= (u64)(st * 0x15u) << 32;
+      } else quick = false;
+    } else {
+      m |= kMapIdentity & (0x3Full << 32);
+    }
+  }
+  if (quick) return m;
+  BWTC_GM_BY_TYPE(type, m = laneMapT<TYPE>(packed, begin, end));
+  return m;
+}
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BWTC_GM_LOCAL_ADD(ptr, val) __hip_atomic_fetch_add((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)   /* ds_add_u32, no round trip */
+#else
+#define BWTC_GM_LOCAL_ADD(ptr, val) (*(ptr) += (val))
+#endif
 // ---- pass 2: updates per slot ------------------------------------------------------------------------
 // tab: kSlotStride rows, this lane's column (row k at tab[k * stride]); zeroed here
-BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* tab, u32 stride) {
-  for (u32 k = 0; k < kSlots; ++k) tab[k * stride] = 0;
+template <u32 TYPE>
+BWTC_GM_HD void laneCountT(const u32* packed, u32 begin, u32 end, u32 state, u32* tab, u32 stride) {
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
   forElements(packed, begin, end, [&](u32, u32 v) {
-    const u32 slot = stepMachines(type, v, m);
-    tab[slot * stride] += 1;
+    const u32 slot = stepMachinesT<TYPE>(v, m);
+    BWTC_GM_LOCAL_ADD(&tab[slot * stride], 1u);
   });
+}
+BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* tab, u32 stride) {
+  for (u32 k = 0; k < kSlots; ++k) tab[k * stride] = 0;
+  BWTC_GM_BY_TYPE(type, laneCountT<TYPE>(packed, begin, end, state, tab, stride));
 }
 
 // ---- pass 3: the bits, gathered by slot --------------------------------------------------------------
@@ -198,17 +316,21 @@ BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 s
 #else
 #define BWTC_GM_OR(ptr, val) (*(ptr) |= (val))
 #endif
-BWTC_GM_HD void lanePartition(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* pos, u32* acc,
-                              u32 stride, u32* sbits) {
+template <u32 TYPE>
+BWTC_GM_HD void lanePartitionT(const u32* packed, u32 begin, u32 end, u32 state, u32* pos, u32* acc, u32 stride, u32* sbits) {
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
   forElements(packed, begin, end, [&](u32, u32 v) {
-    const u32 slot = stepMachines(type, v, m);
+    const u32 slot = stepMachinesT<TYPE>(v, m);
     const u32 p = pos[slot * stride];
     u32 a = acc[slot * stride] | ((v & 1u) << (p & 31u));
     if ((p & 31u) == 31u) { if (a) BWTC_GM_OR(&sbits[p >> 5], a); a = 0; }
     acc[slot * stride] = a;
     pos[slot * stride] = p + 1;
   });
+}
+BWTC_GM_HD void lanePartition(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* pos, u32* acc,
+                              u32 stride, u32* sbits) {
+  BWTC_GM_BY_TYPE(type, lanePartitionT<TYPE>(packed, begin, end, state, pos, acc, stride, sbits));
   for (u32 k = 0; k < kSlots; ++k) {
     const u32 a = acc[k * stride];
     if (a) BWTC_GM_OR(&sbits[(pos[k * stride] - 1u) >> 5], a);       // a != 0: at least one bit since the last flush
@@ -260,37 +382,69 @@ BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, 
     L = lo; x0 = lo; mask = (1u << w) - 1u;
   }
   u32 next = sb[sg + 1];
-  forBits(sbits, p0, p1, [&](u32 p, u32 b) {
-    while (p >= next && sg + 1u < ns) {            // another chain starts here: fresh predictor, known exactly
-      ++sg; next = sb[sg + 1];
-      k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
-      x0 = slotInit(k); mask = 0;
+  for (u32 wp = p0; wp < p1; wp += 32u) {          // p0 is a multiple of 32
+    const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
+    u32 word = sbits[wp >> 5];
+    if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
+      // equal bits that move no candidate any more: nothing to do for the whole word
+      if (hi - wp == 32u && ((word == 0u && ((x0 + popc(mask) - floor) >> d) == 0u) ||
+                             (word == 0xFFFFFFFFu && (((4096u - floor) - x0) >> d) == 0u))) continue;
+      for (u32 p = wp; p < hi; ++p, word >>= 1) bracketStep(x0, mask, word & 1u, floor, d);
+    } else {
+      for (u32 p = wp; p < hi; ++p, word >>= 1) {
+        while (p >= next && sg + 1u < ns) {        // another chain starts here: fresh predictor, known exactly
+          ++sg; next = sb[sg + 1];
+          k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
+          x0 = slotInit(k); mask = 0;
+        }
+        bracketStep(x0, mask, word & 1u, floor, d);
+      }
     }
-    bracketStep(x0, mask, b, floor, d);
-  });
+  }
   return SlotMap{L | (x0 << 16), mask};
 }
 
-// pass 5: stream sg -- the true value at every slot-chunk border inside it
-BWTC_GM_HD void laneChain(const SlotMap* smap, const u32* sb, u32 sg, unsigned short* sstart, u32* err) {
-  const u32 s0 = sb[sg], s1 = sb[sg + 1];
-  if (s1 <= s0) return;
-  u32 j = s0 / kSlotChunk;
-  u32 t = 0;
-  bool first = true;
-  for (; (u64)(j + 1) * kSlotChunk < s1; ++j) {
-    const SlotMap m = smap[j];
-    if (first) { t = m.lo_x0 >> 16; first = false; }          // the chunk the chain starts in ends exactly
-    else {
-      const u32 off = t - (m.lo_x0 & 0xFFFFu);
-      if (off > 31u) { *err |= kErrChain; return; }
-      t = (m.lo_x0 >> 16) + popc(m.mask & ((1u << off) - 1u));
-    }
-    sstart[j + 1] = (unsigned short)t;
+// pass 5: the true value at every slot-chunk border.  Slot space is ONE chain of maps for this
+// purpose: a chunk in which a predictor chain starts ends exactly (mask 0), so its map is a
+// constant and nothing runs across.  Three levels: (a) per group of `gsize` slot-chunks the
+// images of the group's first bracket (one lane per candidate, laneChainGroup), (b) a serial
+// walk over the groups (a table look-up each, laneChainTop), (c) per group the chunks' values
+// from the group's true start (laneChainFill).
+// slot-chunks per group: at most kChainGroups groups, so that level (b) stays a walk over one LDS table
+constexpr u32 kChainGroups = 1024;
+BWTC_GM_HD u32 chainGroupSize(u32 nsc) { const u32 g = (nsc + kChainGroups - 1u) / kChainGroups; return g < 16u ? 16u : g; }
+BWTC_GM_HD u32 slotMapApply(const SlotMap m, u32 t, u32* err) {
+  const u32 off = t - (m.lo_x0 & 0xFFFFu);
+  if (off > 31u) { if (m.mask && err) *err |= kErrChain; return m.lo_x0 >> 16; }   // a constant map takes any value
+  return (m.lo_x0 >> 16) + popc(m.mask & ((1u << off) - 1u));
+}
+// candidate `cand` (0..31) of group g's first bracket -> its value after the group; gL[g] = the bracket's base
+BWTC_GM_HD u32 laneChainGroup(const SlotMap* smap, u32 nsc, u32 gsize, u32 g, u32 cand) {
+  const u32 j0 = g * gsize, j1 = j0 + gsize < nsc ? j0 + gsize : nsc;
+  u32 t = (smap[j0].lo_x0 & 0xFFFFu) + cand;
+  for (u32 j = j0; j < j1; ++j) t = slotMapApply(smap[j], t, nullptr);
+  return t;
+}
+// gmap[g * 32 + cand], gL[g] -> tg[g] = the true value at group g's first border
+BWTC_GM_HD void laneChainTop(const unsigned short* gmap, const unsigned short* gL, u32 ng, unsigned short* tg, u32* err) {
+  u32 t = gL[0];                                   // slot space starts with a chain's start: exact
+  for (u32 g = 0; g < ng; ++g) {
+    tg[g] = (unsigned short)t;
+    u32 off = t - gL[g];
+    if (off > 31u) off = 0;                        // only a constant group map may be entered off its bracket (checked in Fill)
+    t = gmap[g * 32u + off];
   }
 }
+BWTC_GM_HD void laneChainFill(const SlotMap* smap, u32 nsc, u32 gsize, u32 g, const unsigned short* tg,
+                              unsigned short* sstart, u32* err) {
+  const u32 j0 = g * gsize, j1 = j0 + gsize < nsc ? j0 + gsize : nsc;
+  u32 t = tg[g];
+  for (u32 j = j0; j < j1; ++j) { sstart[j] = (unsigned short)t; t = slotMapApply(smap[j], t, err); }
+}
 
-// pass 6: slot-chunk j again, from its true start value: the value at every kSample-th position
+// pass 6: slot-chunk j again, from its true start value: the value at every kSample-th position.
+// A word of equal bits under a predictor that those bits no longer move (the common case once a
+// node's bits are predictable) is skipped whole.
 BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j,
                             const unsigned short* sstart, unsigned short* samples) {
   const u32 p0 = j * kSlotChunk, p1 = p0 + kSlotChunk < total ? p0 + kSlotChunk : total;
@@ -298,15 +452,75 @@ BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32
   u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
   u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
   u32 next = sb[sg + 1];
-  forBits(sbits, p0, p1, [&](u32 p, u32 b) {
-    while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
-    if ((p & (kSample - 1u)) == 0) samples[p / kSample] = (unsigned short)x;
-    x = moved(x, b, floor, d);
-  });
+  for (u32 wp = p0; wp < p1; wp += 32u) {          // p0 is a multiple of 32 = kSample
+    const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
+    u32 word = sbits[wp >> 5];
+    if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
+      samples[wp / kSample] = (unsigned short)x;
+      if (hi - wp == 32u && ((word == 0u && ((x - floor) >> d) == 0u) || (word == 0xFFFFFFFFu && (((4096u - floor) - x) >> d) == 0u))) continue;
+      for (u32 p = wp; p < hi; ++p, word >>= 1) x = moved(x, word & 1u, floor, d);
+    } else {
+      for (u32 p = wp; p < hi; ++p, word >>= 1) {
+        while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
+        if (p == wp) samples[wp / kSample] = (unsigned short)x;
+        x = moved(x, word & 1u, floor, d);
+      }
+    }
+  }
 }
 
 // pass 7: the elements of a chunk in coding order with exact predictors.  q: table row k = slot k.
 // out[i] = bit << 15 | probability of the coded bit
+template <u32 TYPE>
+BWTC_GM_HD u32 emitStep(u32 v, Machines& m, u32* q, u32 stride) {
+  const u32 bit = v & 1u;
+  const u32 slot = stepMachinesT<TYPE>(v, m);
+  const u32 pr = q[slot * stride];
+  q[slot * stride] = moved(pr, bit, TYPE == kTInts ? 100u : 2u, (TYPE == kTGaps || TYPE == kTInts) ? 5u : slotDelay(slot));
+  return (bit << 15) | (bit ? pr : 4096u - pr);
+}
+template <u32 TYPE>
+BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32* q, u32 stride, unsigned short* out) {
+  Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
+  if (begin >= end) return;
+  const u32 q0 = begin >> 6, q1 = (end - 1u) >> 6;
+  Piece cur = loadPiece(packed, q0);
+  for (u32 qi = q0; qi <= q1; ++qi) {
+    const Piece nxt = loadPiece(packed, qi < q1 ? qi + 1u : qi);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 wb = (qi << 6) + k * 16u;
+      u32 word = pieceWord(cur, k);
+      if (wb >= begin && wb + 16u <= end) {                      // sixteen elements: 32 bytes of output, two 16-byte stores
+        u32 o[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (u32 e = 0; e < 8; ++e) {
+          const u32 a = emitStep<TYPE>(word & 3u, m, q, stride);
+          const u32 b = emitStep<TYPE>((word >> 2) & 3u, m, q, stride);
+          word >>= 4;
+          o[e] = a | (b << 16);
+        }
+        u32* dst = reinterpret_cast<u32*>(out + wb);
+#if defined(__HIP_DEVICE_COMPILE__)
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4*>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+#else
+        for (u32 e = 0; e < 8; ++e) dst[e] = o[e];
+#endif
+      } else {
+        const u32 lo = wb > begin ? wb : begin, hi = wb + 16u < end ? wb + 16u : end;
+        if (lo >= hi) continue;
+        word >>= (lo & 15u) * 2u;
+        for (u32 i = lo; i < hi; ++i, word >>= 2) out[i] = (unsigned short)emitStep<TYPE>(word & 3u, m, q, stride);
+      }
+    }
+    cur = nxt;
+  }
+}
 BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32 task, u32 chunk, u32 nc, u32 nt,
                          const u32* base, const u32* sb, const u32* sbits, const unsigned short* samples,
                          u32* q, u32 stride, unsigned short* out) {
@@ -321,18 +535,7 @@ BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 st
     forBits(sbits, a, P, [&](u32, u32 b) { x = moved(x, b, floor, d); });
     q[k * stride] = x;
   }
-  Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
-  u32 held = 0;                                    // the element at an even index waits for its neighbour: 4-byte stores
-  forElements(packed, begin, end, [&](u32 i, u32 v) {
-    const u32 bit = v & 1u;
-    const u32 slot = stepMachines(type, v, m);
-    const u32 pr = q[slot * stride];
-    q[slot * stride] = moved(pr, bit, slotFloor(slot), slotDelay(slot));
-    const u32 w = (bit << 15) | (bit ? pr : 4096u - pr);
-    if ((i & 1u) == 0 && i + 1u < end) held = w;
-    else if ((i & 1u) && i > begin) *reinterpret_cast<u32*>(out + i - 1u) = held | (w << 16);
-    else out[i] = (unsigned short)w;
-  });
+  BWTC_GM_BY_TYPE(type, laneEmitT<TYPE>(packed, begin, end, state, q, stride, out));
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------

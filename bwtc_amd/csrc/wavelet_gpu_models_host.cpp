@@ -109,7 +109,16 @@ bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& ta
                  total, nt, nc, nsc, far, open_end);
   }
   std::vector<unsigned short> sstart(nsc + 1, 0);
-  for (u32 sg = 0; sg < ns; ++sg) laneChain(smap.data(), sb.data(), sg, sstart.data(), &err);
+  {
+    const u32 gsize = chainGroupSize(nsc), ng = (nsc + gsize - 1) / gsize;
+    std::vector<unsigned short> gmap(static_cast<size_t>(ng) * 32), gL(ng), tg(ng);
+    for (u32 g = 0; g < ng; ++g) {
+      gL[g] = static_cast<unsigned short>(smap[g * gsize].lo_x0 & 0xFFFFu);
+      for (u32 cand = 0; cand < 32; ++cand) gmap[g * 32 + cand] = static_cast<unsigned short>(laneChainGroup(smap.data(), nsc, gsize, g, cand));
+    }
+    laneChainTop(gmap.data(), gL.data(), ng, tg.data(), &err);
+    for (u32 g = 0; g < ng; ++g) laneChainFill(smap.data(), nsc, gsize, g, tg.data(), sstart.data(), &err);
+  }
   if (err) return false;
   std::vector<unsigned short> samples(total / kSample + 2, 0);
   for (u32 j = 0; j < nsc; ++j) laneSamples(sbits.data(), sb.data(), ns, nt, total, j, sstart.data(), samples.data());

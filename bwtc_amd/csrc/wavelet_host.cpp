@@ -1140,6 +1140,19 @@ size_t StreamCoder::codeSectionsPaired(std::atomic<size_t>* cursor, const uint16
   }
 }
 
+void StreamCoder::codeSectionW(size_t k, const uint16_t* w, std::vector<SectionOutput>* out) const {
+  CoderChain c;
+  startSection(k, out, &c);
+  runChainW(c, w, c.e);
+  c.finish();
+}
+
+void StreamCoder::describeChainW(size_t k, const uint16_t* w, std::vector<SectionOutput>* out, ChainDesc* d) const {
+  describeChain(k, nullptr, out, d);
+  d->codes = nullptr;
+  d->w = w;
+}
+
 size_t StreamCoder::codeSectionsW(std::atomic<size_t>* cursor, const uint16_t* w, std::vector<SectionOutput>* out) const {
   size_t finished = 0;
   for (;;) {

@@ -126,6 +126,8 @@ class StreamCoder {
   // sections from the cursor, one chain at a time (a chain alone runs at its full speed: the
   // block's longest one sets its latency), over w-elements (runChainW)
   size_t codeSectionsW(std::atomic<size_t>* cursor, const uint16_t* w, std::vector<SectionOutput>* out) const;
+  void codeSectionW(size_t k, const uint16_t* w, std::vector<SectionOutput>* out) const;     // section task k alone
+  void describeChainW(size_t k, const uint16_t* w, std::vector<SectionOutput>* out, ChainDesc* d) const;
   // section task k as a chain for the 16-lane coder engine (wavelet_rc.hpp): puts the section's
   // prefix into out[section] and describes the elements to code
   void describeChain(size_t k, const uint16_t* prob, std::vector<SectionOutput>* out, ChainDesc* d) const;

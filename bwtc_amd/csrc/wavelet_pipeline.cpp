@@ -54,6 +54,16 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   fused_sections_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   long_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
+  w_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
+  // Device-modelled blocks leave only the range coders to the host.  A lane of the 16-lane engine
+  // advances ITS chain five times slower than the scalar loop (9 ns against 1.7 per element), so
+  // the block's long sections -- from 32 Mi elements: a third of a second in a lane -- get a
+  // scalar task each (they set the block's latency), the others share the lanes with the sections
+  // of the blocks behind them (a third of the scalar loop's host time per element).
+  max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P + 3) / 4)) : 0u;
+  if (std::getenv("BWTC_HIP_W_ENGINES") && std::atoi(std::getenv("BWTC_HIP_W_ENGINES")) == 0) max_w_engines_ = 0;
+  w_long_chain_ = static_cast<uint64_t>(envNumber("BWTC_HIP_W_LONG_MI", 32)) << 20;
+  if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) w_long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests
 }
 
 HostPipeline::~HostPipeline() {}
@@ -135,6 +145,26 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
     ++clock.blocks;
     if (job.sections_left == 0) { finishNow(job); ++clock.finished; return job.w_end_state; }
     ++clock.unfinished;
+    if (max_w_engines_) {
+      size_t n_long = 0;                              // section tasks are sorted largest first
+      while (n_long < job.coder->sectionTasks() && job.coder->sectionElements(n_long) >= w_long_chain_) ++n_long;
+      std::vector<std::function<void()> > own;
+      for (size_t k = 0; k < n_long; ++k) {
+        own.push_back([this, jobp, k] {
+          WaveletJob& j = *jobp;
+          const auto t0 = std::chrono::steady_clock::now();
+          j.coder->codeSectionW(k, j.w, &j.outs);
+          clock.coder_ns += since(t0);
+          bool fin;
+          { std::lock_guard<std::mutex> g(j.mu); fin = --j.sections_left == 0; }
+          if (fin) finish(j);
+        });
+      }
+      if (!own.empty()) pool_.submit(job.rank, own);
+      if (w_chains_.add(jobp, n_long, job.coder->sectionTasks(), max_w_engines_))
+        pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(w_chains_, 16, &clock.coder_ns); });
+      return job.w_end_state;
+    }
     const uint64_t longest = std::max<uint64_t>(1, job.coder->largestSectionElements());
     const size_t balanced = static_cast<size_t>(std::min<uint64_t>(pool_.size(), (job.coder->elements() + longest - 1) / longest));
     const size_t engines = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(2, balanced), job.coder->sectionTasks()));

@@ -271,6 +271,9 @@ class HostPipeline {
   BlockGroupSource groups_;                          // before the pool: the workers are joined first
   BlockChainSource chains_;                          // sections for the 16-lane coder engines
   BlockChainSource long_chains_;                     // very long sections: scalar engines, two chains at a time
+  BlockChainSource w_chains_;                        // device-modelled blocks: their shorter sections, for the 16-lane engines
+  unsigned max_w_engines_;                           //   at most this many of them (0: no lanes, every chain scalar)
+  uint64_t w_long_chain_;                            //   sections this long keep a scalar task of their own
   BlockSectionSource fused_sections_;                // fused model + coder engines
   WorkerPool pool_;
   uint64_t huge_;
@@ -348,7 +351,8 @@ inline bool BlockChainSource::next(bwtc::wavelet::ChainDesc* d) {
     job = queue_.front().job;
     k = queue_.front().at++;
   }
-  job->coder->describeChain(k, job->prob.data(), &job->outs, d);
+  if (job->w) job->coder->describeChainW(k, job->w, &job->outs, d);
+  else job->coder->describeChain(k, job->prob.data(), &job->outs, d);
   d->cookie = job.get();
   return true;
 }

@@ -109,6 +109,36 @@ void runChainPair(CoderChain& a, const uint8_t* codes_a, const uint16_t* prob_a,
   }
 }
 
+void runChainPairW(CoderChain& a, const uint16_t* wa, CoderChain& b, const uint16_t* wb, uint64_t limit) {
+  const uint64_t kChunk = 8192;
+  uint64_t left = std::min(limit, std::min(a.e - a.i, b.e - b.i));
+  while (left > 0) {
+    const uint64_t n = std::min(left, kChunk);
+    uint8_t* oa = a.room(kChunk);
+    uint8_t* ob = b.room(kChunk);
+    uint32_t loa = a.lo, sa = a.size, lob = b.lo, sb = b.size;
+    uint64_t ia = a.i, ib = b.i;
+#define BWTC_RC_W(lo, size, o, i, w)                                                                      \
+    {                                                                                                      \
+      const uint32_t x = w[i];                                                                             \
+      const uint32_t bit = x >> 15, m = x & 0x7FFFu;                                                       \
+      const uint32_t ns = static_cast<uint32_t>((static_cast<int64_t>(static_cast<uint64_t>(size) * m) + (static_cast<int64_t>(bit) - 2049)) >> 12); \
+      lo += (bit - 1u) & (size - ns);                                                                      \
+      size = ns;                                                                                           \
+      while (((lo ^ (lo + size + 1)) & 0xFF000000u) == 0) { *o++ = static_cast<uint8_t>(lo >> 24); lo <<= 8; size = (size << 8) + 510u; } \
+      ++i;                                                                                                 \
+    }
+    for (uint64_t k = 0; k < n; ++k) {
+      BWTC_RC_W(loa, sa, oa, ia, wa)
+      BWTC_RC_W(lob, sb, ob, ib, wb)
+    }
+#undef BWTC_RC_W
+    a.lo = loa; a.size = sa; a.i = ia; a.used = static_cast<size_t>(oa - a.out->data());
+    b.lo = lob; b.size = sb; b.i = ib; b.used = static_cast<size_t>(ob - b.out->data());
+    left -= n;
+  }
+}
+
 void runChainPair(CoderChain& a, CoderChain& b, const uint8_t* codes, const uint16_t* prob) {
   runChainPair(a, codes, prob, b, codes, prob, ~static_cast<uint64_t>(0));
 }
@@ -162,28 +192,39 @@ BWTC_AVX512 inline void transpose16(__m512i r[16]) {
 // stays a branch) and handed to the lanes' outputs once per word, in event order -- so the
 // scalar byte stores and the unpredictable "does anybody emit" branch are off the loop that
 // carries the interval.
+// WMODE: the lanes' elements are w-words (bit << 15 | probability of the coded bit, wavelet_gpu_models.hpp)
+// read through L.prob; the probability of a one and the bit are taken from them.
+template <bool WMODE>
 BWTC_AVX512 void runWords(Lanes& L, uint64_t words, uint32_t busy_mask) {
   __m512i lo = _mm512_load_si512(L.lo), size = _mm512_load_si512(L.size);
   const __m512i one = _mm512_set1_epi32(1), c4095 = _mm512_set1_epi32(4095), c2048 = _mm512_set1_epi32(2048);
   const __m512i top = _mm512_set1_epi32(static_cast<int>(0xFF000000u)), c510 = _mm512_set1_epi32(510);
   const __m512i lane_id = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
   const __mmask16 kBusy = static_cast<__mmask16>(busy_mask);
-  alignas(64) uint32_t cw[kLanes];
+  const __m512i c32768 = _mm512_set1_epi32(32768), c32767 = _mm512_set1_epi32(32767), c4096 = _mm512_set1_epi32(4096);
+  alignas(64) uint32_t cw[kLanes] = {0};
   alignas(64) uint32_t ev[16 * kLanes * 4 + 64];       // at most four bytes per lane and step
   for (uint64_t w = 0; w < words; ++w) {
     __m512i P[16];
     for (int l = 0; l < kLanes; ++l) {
       P[l] = _mm512_cvtepu16_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(L.prob[l] + L.i[l])));
-      std::memcpy(&cw[l], L.codes[l] + (L.i[l] >> 2), 4);
+      if (!WMODE) std::memcpy(&cw[l], L.codes[l] + (L.i[l] >> 2), 4);
       L.i[l] += L.advance[l];
     }
     transpose16(P);
     __m512i W = _mm512_load_si512(cw);
     uint32_t n = 0;
     for (int t = 0; t < 16; ++t) {
-      const __m512i p = P[t];
-      const __mmask16 kBit = _mm512_test_epi32_mask(W, one);
-      W = _mm512_srli_epi32(W, 2);
+      __m512i p = P[t];
+      __mmask16 kBit;
+      if (WMODE) {
+        kBit = _mm512_test_epi32_mask(p, c32768);
+        const __m512i m = _mm512_and_si512(p, c32767);
+        p = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(c4096, m), m);       // probability of a one
+      } else {
+        kBit = _mm512_test_epi32_mask(W, one);
+        W = _mm512_srli_epi32(W, 2);
+      }
       const __m512i hi = _mm512_srli_epi32(size, 12), lw = _mm512_and_si512(size, c4095);
       const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, p),
                                           _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, p), c2048), 12));
@@ -240,9 +281,13 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
   bool busy[kLanes];
   for (int l = 0; l < kLanes; ++l) busy[l] = false;
   bool sourceDry = false;
+  bool wmode = false;                                  // this engine's chains come as w-words (a source hands out one kind)
+  auto scalar = [&](int l, uint64_t until) {
+    if (desc[l].w) runChainW(chain[l], desc[l].w, until); else runChain(chain[l], desc[l].codes, desc[l].prob, until);
+  };
   auto finishLane = [&](int l) {                       // the rest of the lane's chain, scalar, and its flush
     CoderChain& c = chain[l];
-    runChain(c, desc[l].codes, desc[l].prob, c.e);
+    scalar(l, c.e);
     c.finish();
     src.done(desc[l].cookie);
     busy[l] = false;
@@ -255,10 +300,11 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
         if (!src.next(&desc[l])) { sourceDry = true; break; }
         CoderChain& c = chain[l];
         c.start(desc[l].begin, desc[l].end, desc[l].out);
+        wmode = desc[l].w != nullptr;
         const uint64_t aligned = (c.i + 15) & ~static_cast<uint64_t>(15);
         busy[l] = true;
         if (c.e - c.i < kScalarOnly || aligned + 16 > c.e) { finishLane(l); continue; }
-        runChain(c, desc[l].codes, desc[l].prob, aligned);
+        scalar(l, aligned);
       }
       nbusy += busy[l];
     }
@@ -276,12 +322,14 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
       for (int l = 0; l < kLanes; ++l) if (busy[l]) ids[n++] = l;
       if (n >= 2) {
         const int a = ids[0], b = ids[1];
-        runChainPair(chain[a], desc[a].codes, desc[a].prob, chain[b], desc[b].codes, desc[b].prob, kSlice);
+        if (desc[a].w && desc[b].w) runChainPairW(chain[a], desc[a].w, chain[b], desc[b].w, kSlice);
+        else if (desc[a].w || desc[b].w) { scalar(a, std::min(chain[a].e, chain[a].i + kSlice)); scalar(b, std::min(chain[b].e, chain[b].i + kSlice)); }
+        else runChainPair(chain[a], desc[a].codes, desc[a].prob, chain[b], desc[b].codes, desc[b].prob, kSlice);
         if (chain[a].i >= chain[a].e) finishLane(a);
         if (chain[b].i >= chain[b].e) finishLane(b);
       } else {
         CoderChain& c = chain[ids[0]];
-        runChain(c, desc[ids[0]].codes, desc[ids[0]].prob, std::min(c.e, c.i + kSlice));
+        scalar(ids[0], std::min(c.e, c.i + kSlice));
         if (c.i >= c.e) finishLane(ids[0]);
       }
       sourceDry = false;                                 // ask again: other blocks may have arrived
@@ -294,14 +342,14 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
       for (int l = 0; l < kLanes; ++l) {
         if (busy[l]) {
           CoderChain& c = chain[l];
-          L.lo[l] = c.lo; L.size[l] = c.size; L.codes[l] = desc[l].codes; L.prob[l] = desc[l].prob; L.i[l] = c.i;
+          L.lo[l] = c.lo; L.size[l] = c.size; L.codes[l] = desc[l].codes; L.prob[l] = wmode ? desc[l].w : desc[l].prob; L.i[l] = c.i;
           L.out[l] = c.room(words * 16); L.advance[l] = 16;
         } else {
           L.lo[l] = 0; L.size[l] = 0xFFFFFFFEu; L.codes[l] = kZeroCodes; L.prob[l] = kZeroProb; L.i[l] = 0;
           L.out[l] = nullptr; L.advance[l] = 0;
         }
       }
-      runWords(L, words, mask);
+      if (wmode) runWords<true>(L, words, mask); else runWords<false>(L, words, mask);
       for (int l = 0; l < kLanes; ++l) {
         if (!busy[l]) continue;
         CoderChain& c = chain[l];

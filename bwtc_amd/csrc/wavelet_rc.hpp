@@ -42,6 +42,7 @@ void runChain(CoderChain& c, const uint8_t* codes, const uint16_t* prob, uint64_
 // size - t - 1 = floor((size (4096 - p) - 2049) / 4096) for a zero -- so the loop-carried chain is
 // a multiply, an add and a shift.  Same bytes as runChain.
 void runChainW(CoderChain& c, const uint16_t* w, uint64_t until);
+void runChainPairW(CoderChain& a, const uint16_t* wa, CoderChain& b, const uint16_t* wb, uint64_t limit);
 // both chains read the same block's codes/prob; runs until the shorter chain ends
 void runChainPair(CoderChain& a, CoderChain& b, const uint8_t* codes, const uint16_t* prob);
 // the same for chains of different blocks, at most `limit` elements of each
@@ -57,6 +58,8 @@ struct ChainDesc {
   uint64_t begin, end;
   std::vector<uint8_t>* out;
   void* cookie;              // handed back through done()
+  const uint16_t* w = nullptr;   // not null: the elements are w-words (wavelet_gpu_models.hpp), codes / prob unused;
+                                 //   one source hands out chains of one kind only
 };
 
 class ChainSource {

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../bwtc_amd/csrc/entropy_host.hpp"
+#include "../../bwtc_amd/csrc/wavelet_gpu_models.hpp"
 #include "../../bwtc_amd/csrc/wavelet_host.hpp"
 #include "../../bwtc_amd/csrc/wavelet_pipeline.hpp"
 #include "../../oracle/bwtc_oracle.h"
@@ -26,7 +27,9 @@ static int failures = 0;
 struct HostJob : WaveletJob {
   std::vector<uint8_t> codes_owner;
   std::vector<uint8_t> out;
+  std::vector<uint16_t> w_owner;
 };
+static bool g_device_models = false;     // blocks arrive modelled (w-words made by the lane functions the GPU runs)
 
 // what wavelet_section_stats_device delivers, computed with plain loops
 struct BlockRuns {
@@ -116,6 +119,20 @@ static void runStream(std::mt19937& rng, size_t blocks, size_t block_size, unsig
     job->user_out = job->out.data();
     job->user_cap = job->out.size();
     job->fused = std::getenv("BWTC_HIP_FUSED") != nullptr && (jobs.size() % 3) != 1;   // fused engines, with two-stage blocks in between
+    if (g_device_models && (jobs.size() % 4) != 2) {                   // every fourth block stays with the host models
+      const uint32_t total = job->coded_pos.back();
+      std::vector<uint32_t> packed(total / 16 + 8, 0);
+      std::memcpy(packed.data(), job->codes_owner.data(), std::min(job->codes_owner.size(), packed.size() * 4));
+      std::vector<bwtc::wavelet::gm::Task> tasks;
+      std::vector<bwtc::wavelet::gm::Chunk> chunks;
+      bwtc::wavelet::gm::buildTasks(job->plan, job->coded_pos.data(), &tasks, &chunks);
+      job->w_owner.assign((size_t)total + 64, 0);
+      uint32_t st = state;
+      CHECK(bwtc::wavelet::gm::modelsOnHostLanes(packed.data(), total, tasks, chunks, &st, job->w_owner.data()), "model lanes");
+      job->w = job->w_owner.data();
+      job->w_end_state = st;
+      job->fused = false;
+    }
     state = pipe.queue(job, state, 'B');                               // all blocks under way at once
     jobs.push_back(job);
     sizes.push_back(n);
@@ -229,6 +246,19 @@ int main() {
   runStream(rng, 14, 70000, 3, 32u << 20, 1);
   runFarmedStream(rng, 8, 120000, 2, 8);
   unsetenv("BWTC_HIP_FUSED");
+  // device-modelled blocks: only range coders on the host -- long sections as scalar tasks, the
+  // others in the 16-lane engines (where the CPU has them), mixed with host-modelled blocks
+  g_device_models = true;
+  setenv("BWTC_HIP_LONG_CHAIN_ELEMENTS", "30000", 1);
+  runStream(rng, 9, 250000, 6, 32u << 20, 8);
+  setenv("BWTC_HIP_LONG_CHAIN_ELEMENTS", "1", 1);                      // every section a scalar task
+  runStream(rng, 6, 200000, 4, 32u << 20, 8);
+  unsetenv("BWTC_HIP_LONG_CHAIN_ELEMENTS");
+  runStream(rng, 12, 120000, 5, 32u << 20, 1);                         // every section in the lanes
+  setenv("BWTC_HIP_W_ENGINES", "0", 1);
+  runStream(rng, 5, 200000, 3, 32u << 20, 8);                          // no lane engines: sections from a cursor
+  unsetenv("BWTC_HIP_W_ENGINES");
+  g_device_models = false;
   std::printf(failures ? "%d FAILURES\n" : "host pipeline: all tests passed\n", failures);
   return failures ? 1 : 0;
 }
