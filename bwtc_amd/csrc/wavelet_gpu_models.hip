@@ -23,69 +23,74 @@ constexpr int kGmStateTPB = 1024;
 constexpr int kGmStateE = 8;
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_map(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
-                                                   const gm::Task* __restrict__ tasks, u32 nc, u64* __restrict__ cmap) {
-  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
-  if (c >= nc) return;
+                                                   const gm::Task* __restrict__ tasks, const u32* __restrict__ order, u32 nc,
+                                                   u64* __restrict__ cmap) {
+  const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
+  if (gid >= nc) return;
+  const u32 c = order[gid];                          // lanes in type order: a wave walks one kind of loop
   const gm::Chunk ch = chunks[c];
   cmap[c] = gm::laneMap(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type);
 }
 
-// One workgroup: composition scan of the chunks' maps in coding order -> every chunk's start
-// states; *state_out = the main machine's state after the block.
-__global__ __launch_bounds__(kGmStateTPB) void k_gm_state(const gm::Chunk* __restrict__ chunks, const u64* __restrict__ cmap,
-                                                          u32 nc, u32 state_in, u32* __restrict__ cstate,
-                                                          u32* __restrict__ state_out) {
+// Composition scan of the chunks' maps in coding order -> every chunk's start states, in three
+// launches: per tile of 8192 chunks the threads' exclusive prefixes inside the tile and the tile's
+// map (many workgroups), a serial walk over the tiles (a map application each), and the walk of
+// every thread over its eight chunks from its true start state.
+__global__ __launch_bounds__(kGmStateTPB) void k_gm_state_tile(const gm::Chunk* __restrict__ chunks, const u64* __restrict__ cmap,
+                                                               u32 nc, u64* __restrict__ excl, u64* __restrict__ tagg) {
   __shared__ u64 s_agg[kGmStateTPB];
-  __shared__ u32 s_carry;
   const u32 tid = threadIdx.x;
-  if (tid == 0) s_carry = gm::packState(state_in & 7u, 2, 1);
+  const u32 c0 = blockIdx.x * (kGmStateTPB * kGmStateE) + tid * kGmStateE;
+  u64 agg = gm::kMapIdentity;
+#pragma unroll
+  for (int i = 0; i < kGmStateE; ++i) {
+    if (c0 + i < nc) {
+      if (chunks[c0 + i].task_first >> 31) agg = gm::mapConstGapsInts(agg, 2, 1);
+      agg = gm::mapCompose(agg, cmap[c0 + i]);
+    }
+  }
+  s_agg[tid] = agg;
   __syncthreads();
-  for (u32 tile0 = 0; tile0 < nc; tile0 += kGmStateTPB * kGmStateE) {
-    const u32 c0 = tile0 + tid * kGmStateE;
-    u64 m[kGmStateE];
-    bool first[kGmStateE];
-#pragma unroll
-    for (int i = 0; i < kGmStateE; ++i) {
-      const bool in = c0 + i < nc;
-      m[i] = in ? cmap[c0 + i] : gm::kMapIdentity;
-      first[i] = in && (chunks[c0 + i].task_first >> 31);
-    }
-    u64 agg = gm::kMapIdentity;
-#pragma unroll
-    for (int i = 0; i < kGmStateE; ++i) {
-      if (first[i]) agg = gm::mapConstGapsInts(agg, 2, 1);
-      agg = gm::mapCompose(agg, m[i]);
-    }
-    s_agg[tid] = agg;
+  for (u32 off = 1; off < kGmStateTPB; off <<= 1) {
+    const u64 v = tid >= off ? gm::mapCompose(s_agg[tid - off], agg) : agg;
     __syncthreads();
-    for (u32 off = 1; off < kGmStateTPB; off <<= 1) {
-      const u64 v = tid >= off ? gm::mapCompose(s_agg[tid - off], agg) : agg;
-      __syncthreads();
-      s_agg[tid] = agg = v;
-      __syncthreads();
-    }
-    u32 st = gm::mapApply(tid ? s_agg[tid - 1] : gm::kMapIdentity, s_carry);
-#pragma unroll
-    for (int i = 0; i < kGmStateE; ++i) {
-      if (c0 + i < nc) {
-        if (first[i]) st = gm::packState(st & 7u, 2, 1);
-        cstate[c0 + i] = st;
-        st = gm::mapApply(m[i], st);
-      }
-    }
-    __syncthreads();
-    if (tid == kGmStateTPB - 1) s_carry = st;
+    s_agg[tid] = agg = v;
     __syncthreads();
   }
-  if (tid == 0) *state_out = s_carry & 7u;
+  excl[blockIdx.x * kGmStateTPB + tid] = tid ? s_agg[tid - 1] : gm::kMapIdentity;
+  if (tid == kGmStateTPB - 1) tagg[blockIdx.x] = agg;
+}
+__global__ void k_gm_state_top(const u64* __restrict__ tagg, u32 ntiles, u32 state_in, u32* __restrict__ tstate,
+                               u32* __restrict__ state_out) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 st = gm::packState(state_in & 7u, 2, 1);
+  for (u32 t = 0; t < ntiles; ++t) { tstate[t] = st; st = gm::mapApply(tagg[t], st); }
+  *state_out = st & 7u;
+}
+__global__ __launch_bounds__(kGmStateTPB) void k_gm_state_apply(const gm::Chunk* __restrict__ chunks, const u64* __restrict__ cmap,
+                                                                u32 nc, const u64* __restrict__ excl, const u32* __restrict__ tstate,
+                                                                u32* __restrict__ cstate) {
+  const u32 tid = threadIdx.x;
+  const u32 c0 = blockIdx.x * (kGmStateTPB * kGmStateE) + tid * kGmStateE;
+  if (c0 >= nc) return;
+  u32 st = gm::mapApply(excl[blockIdx.x * kGmStateTPB + tid], tstate[blockIdx.x]);
+#pragma unroll
+  for (int i = 0; i < kGmStateE; ++i) {
+    if (c0 + i < nc) {
+      if (chunks[c0 + i].task_first >> 31) st = gm::packState(st & 7u, 2, 1);
+      cstate[c0 + i] = st;
+      st = gm::mapApply(cmap[c0 + i], st);
+    }
+  }
 }
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_count(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
                                                      const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
-                                                     u32 nc, u32* __restrict__ cnt) {
+                                                     const u32* __restrict__ order, u32 nc, u32* __restrict__ cnt) {
   __shared__ u32 tab[gm::kSlotStride][kGmTPB];
-  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
-  if (c >= nc) return;
+  const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
+  if (gid >= nc) return;
+  const u32 c = order[gid];
   const gm::Chunk ch = chunks[c];
   gm::laneCount(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type, cstate[c], &tab[0][threadIdx.x], kGmTPB);
   for (u32 k = 0; k < gm::kSlots; ++k) cnt[(u64)k * nc + c] = tab[k][threadIdx.x];
@@ -103,11 +108,13 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_streams(const u32* __restrict__ b
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_partition(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
                                                          const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
-                                                         const u32* __restrict__ base, u32 nc, u32* __restrict__ sbits) {
+                                                         const u32* __restrict__ base, const u32* __restrict__ order, u32 nc,
+                                                         u32* __restrict__ sbits) {
   __shared__ u32 pos[gm::kSlotStride][kGmTPB];
   __shared__ u32 acc[gm::kSlotStride][kGmTPB];
-  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
-  if (c >= nc) return;
+  const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
+  if (gid >= nc) return;
+  const u32 c = order[gid];
   const gm::Chunk ch = chunks[c];
   for (u32 k = 0; k < gm::kSlots; ++k) { pos[k][threadIdx.x] = base[(u64)k * nc + c]; acc[k][threadIdx.x] = 0; }
   gm::lanePartition(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type, cstate[c], &pos[0][threadIdx.x],
@@ -166,10 +173,11 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_emit(const u32* __restrict__ pack
                                                     const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
                                                     const u32* __restrict__ base, const u32* __restrict__ sb,
                                                     const u32* __restrict__ sbits, const unsigned short* __restrict__ samples,
-                                                    u32 nc, u32 nt, unsigned short* __restrict__ out) {
+                                                    const u32* __restrict__ order, u32 nc, u32 nt, unsigned short* __restrict__ out) {
   __shared__ u32 q[gm::kSlotStride][kGmTPB];
-  const u32 c = blockIdx.x * kGmTPB + threadIdx.x;
-  if (c >= nc) return;
+  const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
+  if (gid >= nc) return;
+  const u32 c = order[gid];
   const gm::Chunk ch = chunks[c];
   const u32 t = ch.task_first & 0x7FFFFFFFu;
   gm::laneEmit(packed, ch.begin, ch.end, tasks[t].type, cstate[c], t, c, nc, nt, base, sb, sbits, samples,
@@ -223,13 +231,16 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   auto take = [&](u64 bytes) { const u64 o = at; at = gm_align(at + bytes); return o; };
   const u64 o_tasks = take((u64)nt * sizeof(gm::Task));
   const u64 o_chunks = take((u64)nc * sizeof(gm::Chunk));
+  const u64 o_order = take((u64)nc * 4);
   const u64 tables_end = at;
+  const u32 ntiles = ceil_div(nc, kGmStateTPB * kGmStateE);
+  const u64 o_excl = take((u64)ntiles * kGmStateTPB * 8), o_tagg = take((u64)ntiles * 8), o_tstate = take((u64)ntiles * 4);
   const u64 o_cmap = take((u64)nc * 8);
   const u64 o_cstate = take((u64)nc * 4);
   const u64 o_base = take(n_base * 4);
   const u64 o_partial = take(((u64)ceil_div(n_base, kScanTile) + 1) * 4);
   const u64 o_sb = take(((u64)ns + 1) * 4);
-  const u64 o_sbits = take(((u64)n_coded / 32 + 2) * 4);
+  const u64 o_sbits = take(((u64)n_coded / 32 + 16) * 4);
   const u64 o_smap = take((u64)nsc * sizeof(gm::SlotMap));
   const u64 o_sstart = take(((u64)nsc + 1) * 2);
   const u32 gsize = gm::chainGroupSize(nsc), ng = ceil_div(nsc, gsize);
@@ -241,9 +252,21 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   u8* base = static_cast<u8*>(e.d_gm);
   std::memcpy(e.h_gm + o_tasks, tasks.data(), (size_t)nt * sizeof(gm::Task));
   std::memcpy(e.h_gm + o_chunks, chunks.data(), (size_t)nc * sizeof(gm::Chunk));
+  {
+    // lanes in type order (a wave then walks ONE kind of loop; a task's chunks stay together)
+    u32* order = reinterpret_cast<u32*>(e.h_gm + o_order);
+    u32 first[5] = {0, 0, 0, 0, 0};
+    for (u32 c = 0; c < nc; ++c) ++first[tasks[chunks[c].task_first & 0x7FFFFFFFu].type + 1];
+    for (int t = 1; t < 5; ++t) first[t] += first[t - 1];
+    for (u32 c = 0; c < nc; ++c) order[first[tasks[chunks[c].task_first & 0x7FFFFFFFu].type]++] = c;
+  }
   BWTC_HIP_TRY(hipMemcpyAsync(base, e.h_gm, tables_end, hipMemcpyHostToDevice, st));
   const gm::Task* d_tasks = reinterpret_cast<const gm::Task*>(base + o_tasks);
   const gm::Chunk* d_chunks = reinterpret_cast<const gm::Chunk*>(base + o_chunks);
+  const u32* d_order = reinterpret_cast<const u32*>(base + o_order);
+  u64* d_excl = reinterpret_cast<u64*>(base + o_excl);
+  u64* d_tagg = reinterpret_cast<u64*>(base + o_tagg);
+  u32* d_tstate = reinterpret_cast<u32*>(base + o_tstate);
   u64* d_cmap = reinterpret_cast<u64*>(base + o_cmap);
   u32* d_cstate = reinterpret_cast<u32*>(base + o_cstate);
   u32* d_base = reinterpret_cast<u32*>(base + o_base);
@@ -256,15 +279,17 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   unsigned short* d_w = static_cast<unsigned short*>(e.d_gm_w);
 
   BWTC_HIP_TRY(hipMemsetAsync(d_tail, 0, 16, st));
-  BWTC_HIP_TRY(hipMemsetAsync(d_sbits, 0, ((u64)n_coded / 32 + 2) * 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(d_sbits, 0, ((u64)n_coded / 32 + 16) * 4, st));
   BWTC_HIP_TRY(hipMemsetAsync(d_base + n_base - 1, 0, 4, st));
   const dim3 gc(ceil_div(nc, kGmTPB)), gs(ceil_div(nsc, kGmTPB)), tpb(kGmTPB);
-  hipLaunchKernelGGL(k_gm_map, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, nc, d_cmap);
-  hipLaunchKernelGGL(k_gm_state, dim3(1), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, state_in, d_cstate, d_tail);
-  hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, nc, d_base);
+  hipLaunchKernelGGL(k_gm_map, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_order, nc, d_cmap);
+  hipLaunchKernelGGL(k_gm_state_tile, dim3(ntiles), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, d_excl, d_tagg);
+  hipLaunchKernelGGL(k_gm_state_top, dim3(1), dim3(64), 0, st, d_tagg, ntiles, state_in, d_tstate, d_tail);
+  hipLaunchKernelGGL(k_gm_state_apply, dim3(ntiles), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, d_excl, d_tstate, d_cstate);
+  hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_order, nc, d_base);
   exclusive_scan_u32(d_base, n_base, reinterpret_cast<u32*>(base + o_partial), st);
   hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
-  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, nc, d_sbits);
+  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
   hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_tail + 1);
   unsigned short* d_gmap = reinterpret_cast<unsigned short*>(base + o_gmap);
   unsigned short* d_gL = reinterpret_cast<unsigned short*>(base + o_gL);
@@ -274,7 +299,7 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(ng, 64)), dim3(64), 0, st, d_smap, nsc, gsize, ng, d_tg, d_sstart, d_tail + 1);
   hipLaunchKernelGGL(k_gm_samples, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_sstart, d_samples);
   hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_samples,
-                     nc, nt, d_w);
+                     d_order, nc, nt, d_w);
   // total of the scan = every element counted once (else the tables do not describe the streams)
   BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + n_base - 1, 4, hipMemcpyDeviceToDevice, st));
   BWTC_HIP_TRY(e.ensure_d2h_stream());

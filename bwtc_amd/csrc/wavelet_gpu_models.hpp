@@ -237,19 +237,28 @@ BWTC_GM_HD u64 laneMapT(const u32* packed, u32 begin, u32 end) {
 //   gaps      the state is (last bit, bit before it) of the gap-coded elements;
 //   integers  two equal bits in a row fix the saturating counter; what follows is replayed.
 // Falls back to the full walk when the tail does not decide (short chunks, an INNER chunk with
-// fewer than two gap-coded elements in its last 64, integer bits that alternate over 64 elements).
+// fewer than two gap-coded elements in its last 32, integer bits that alternate over 64 elements).
 BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
   const u32 n = end - begin;
   bool quick = n >= 4;
   u64 m = 0;
   if (quick) {
-    const u32 tail = n < 64u ? n : 64u;            // elements end - tail .. end - 1
+    const u32 want = type == kTInts ? 64u : type == kTInner ? 32u : 4u;
+    const u32 tail = n < want ? n : want;          // elements end - tail .. end - 1
     u32 bits = 0, flags = 0;                       // bit e = element end - 1 - e (the LAST element is bit 0), e < 32
     u64 bits64 = 0;                                // the same for all 64 (integers)
-    for (u32 e = 0; e < tail; ++e) {
-      const u32 v = codeAt(packed, end - 1u - e);
-      if (e < 32u) { bits |= (v & 1u) << e; flags |= (v >> 1) << e; }
-      bits64 |= (u64)(v & 1u) << e;
+    {
+      // the last 64 elements lie in at most five packed words: loaded together, then unpacked
+      const u32 w_hi = (end - 1u) >> 4, w_lo = (end - tail) >> 4;
+      u32 wd[5];
+      for (u32 k = 0; k < 5; ++k) wd[k] = w_hi >= k && w_hi - k >= w_lo ? packed[w_hi - k] : 0u;
+      for (u32 e = 0; e < tail; ++e) {
+        const u32 i = end - 1u - e, k = w_hi - (i >> 4);
+        const u32 word = k == 0 ? wd[0] : k == 1 ? wd[1] : k == 2 ? wd[2] : k == 3 ? wd[3] : wd[4];
+        const u32 v = (word >> ((i & 15u) * 2u)) & 3u;
+        if (e < 32u) { bits |= (v & 1u) << e; flags |= (v >> 1) << e; }
+        bits64 |= (u64)(v & 1u) << e;
+      }
     }
     if (type == kTRoot || type == kTInner) {
       const u32 b4 = bits & 1u;
@@ -382,9 +391,11 @@ BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, 
     L = lo; x0 = lo; mask = (1u << w) - 1u;
   }
   u32 next = sb[sg + 1];
-  for (u32 wp = p0; wp < p1; wp += 32u) {          // p0 is a multiple of 32
+  Piece cur = loadPiece(sbits, p0 >> 7);           // p0 is a multiple of 128: four words per load, the next one under way
+  for (u32 wp = p0; wp < p1; wp += 32u) {
     const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
-    u32 word = sbits[wp >> 5];
+    u32 word = pieceWord(cur, (wp >> 5) & 3u);
+    if (((wp >> 5) & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
     if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
       // equal bits that move no candidate any more: nothing to do for the whole word
       if (hi - wp == 32u && ((word == 0u && ((x0 + popc(mask) - floor) >> d) == 0u) ||
@@ -452,9 +463,11 @@ BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32
   u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
   u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
   u32 next = sb[sg + 1];
+  Piece cur = loadPiece(sbits, p0 >> 7);
   for (u32 wp = p0; wp < p1; wp += 32u) {          // p0 is a multiple of 32 = kSample
     const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
-    u32 word = sbits[wp >> 5];
+    u32 word = pieceWord(cur, (wp >> 5) & 3u);
+    if (((wp >> 5) & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
     if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
       samples[wp / kSample] = (unsigned short)x;
       if (hi - wp == 32u && ((word == 0u && ((x - floor) >> d) == 0u) || (word == 0xFFFFFFFFu && (((4096u - floor) - x) >> d) == 0u))) continue;

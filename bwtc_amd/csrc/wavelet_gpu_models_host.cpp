@@ -89,7 +89,7 @@ bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& ta
     for (u32 t = 0; t < nt; ++t) sb[k * nt + t] = base[static_cast<size_t>(k) * nc + tasks[t].first_chunk];
   sb[ns] = total;
   // pass 3
-  std::vector<u32> sbits(total / 32 + 2, 0);
+  std::vector<u32> sbits(total / 32 + 16, 0);
   {
     u32 pos[kSlotStride], acc[kSlotStride];
     for (u32 c = 0; c < nc; ++c) {

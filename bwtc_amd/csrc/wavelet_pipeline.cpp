@@ -57,12 +57,12 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   w_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   // Device-modelled blocks leave only the range coders to the host.  A lane of the 16-lane engine
   // advances ITS chain five times slower than the scalar loop (9 ns against 1.7 per element), so
-  // the block's long sections -- from 32 Mi elements: a third of a second in a lane -- get a
-  // scalar task each (they set the block's latency), the others share the lanes with the sections
-  // of the blocks behind them (a third of the scalar loop's host time per element).
+  // the block's longest section(s) get a scalar task each (they set the block's latency; queue()
+  // says which), the others share the lanes with the sections of the blocks behind them (a third of
+  // the scalar loop's host time per element).
   max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P + 3) / 4)) : 0u;
   if (std::getenv("BWTC_HIP_W_ENGINES") && std::atoi(std::getenv("BWTC_HIP_W_ENGINES")) == 0) max_w_engines_ = 0;
-  w_long_chain_ = static_cast<uint64_t>(envNumber("BWTC_HIP_W_LONG_MI", 32)) << 20;
+  w_long_chain_ = static_cast<uint64_t>(envNumber("BWTC_HIP_W_LONG_MI", 8)) << 20;
   if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) w_long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests
 }
 
@@ -145,9 +145,18 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
     ++clock.blocks;
     if (job.sections_left == 0) { finishNow(job); ++clock.finished; return job.w_end_state; }
     ++clock.unfinished;
+    if (std::getenv("BWTC_HIP_DEBUG")) {
+      std::fprintf(stderr, "w-route: %zu sections, elements (Mi):", job.coder->sectionTasks());
+      for (size_t k = 0; k < job.coder->sectionTasks() && k < 12; ++k) std::fprintf(stderr, " %.1f", job.coder->sectionElements(k) / 1048576.0);
+      std::fprintf(stderr, " ...; %u lane engines at most, scalar from %.0f Mi\n", max_w_engines_, w_long_chain_ / 1048576.0);
+    }
     if (max_w_engines_) {
-      size_t n_long = 0;                              // section tasks are sorted largest first
-      while (n_long < job.coder->sectionTasks() && job.coder->sectionElements(n_long) >= w_long_chain_) ++n_long;
+      // scalar tasks: sections that a lane (five times slower per chain) would hold for longer than
+      // the block's longest section needs in the scalar loop -- those set the block's latency --
+      // and never sections below the floor; section tasks are sorted largest first
+      const uint64_t cut = std::max<uint64_t>(w_long_chain_, job.coder->largestSectionElements() / 5);
+      size_t n_long = 0;
+      while (n_long < job.coder->sectionTasks() && job.coder->sectionElements(n_long) >= cut) ++n_long;
       std::vector<std::function<void()> > own;
       for (size_t k = 0; k < n_long; ++k) {
         own.push_back([this, jobp, k] {
