@@ -995,6 +995,18 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
+  // Opt-in (BWTC_HIP_SCAN=chained): measured on MI355X the single-launch scan is SLOWER for the
+  // sorter's tables (63 us against 25 + 11 + 6 us for 8.4 M words: 2048 tiles are too few to hide
+  // the look-back hops), so the three-launch form stays the default.
+  if (std::getenv("BWTC_HIP_SCAN") && std::strcmp(std::getenv("BWTC_HIP_SCAN"), "chained") == 0) {
+    scan_chain.cap_tiles = (u32)(cap / kScanTile + 4096);
+    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scan_chain.status), ((u64)scan_chain.cap_tiles + 1) * 8));
+    BWTC_HIP_TRY(hipMemset(scan_chain.status, 0, ((u64)scan_chain.cap_tiles + 1) * 8));
+    scan_chain.ticket = scan_chain.status + scan_chain.cap_tiles;     // the last word
+    scan_chain.err = d_small + 522;                                  // kSmallError: read back with every ranking step's counts
+    scan_chain.issued = 0;
+    scan_chain.epoch = 0;
+  }
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small), 1024 * 4, hipHostMallocDefault));
   BWTC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_stage), cap + 32, hipHostMallocDefault));
   BWTC_HIP_TRY(hipEventCreateWithFlags(&ev_wait, hipEventBlockingSync | hipEventDisableTiming));
@@ -1060,6 +1072,7 @@ void BwtEngine::release() {
   if (d2h_stream) { (void)hipStreamSynchronize(d2h_stream); (void)hipStreamDestroy(d2h_stream); d2h_stream = nullptr; }
   if (ev_packed) { (void)hipEventDestroy(ev_packed); ev_packed = nullptr; }
   if (ev_models) { (void)hipEventDestroy(ev_models); ev_models = nullptr; }
+  if (scan_chain.status) { (void)hipFree(scan_chain.status); scan_chain = ScanChain(); }
   if (d_gm) { (void)hipFree(d_gm); d_gm = nullptr; gm_bytes = 0; }
   if (d_gm_w) { (void)hipFree(d_gm_w); d_gm_w = nullptr; gm_w_bytes = 0; }
   if (h_gm) { (void)hipHostFree(h_gm); h_gm = nullptr; h_gm_bytes = 0; }
@@ -1472,6 +1485,7 @@ int BwtEngine::load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* h
 
 int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf, u32 n_lf,
                          u32* freqs) {
+  BwtEngine::ScanScope scan_scope(*this);
   hipStream_t st = stream;
   // block mode: size source bytes, n = size + 1 suffixes.  raw mode: `size` is the length
   // of T including the caller's sentinel, so the source bytes that count are size - 1.

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "bwtc_hip.h"
 #include "radix_sort.hpp"
+#include "scan.hpp"
 #include "wavelet_host.hpp"
 #include "wavelet_pipeline.hpp"
 #include <future>
@@ -156,6 +157,13 @@ struct BwtEngine {
   void* d_gm_w = nullptr; u64 gm_w_bytes = 0;
   u8* h_gm = nullptr;    u64 h_gm_bytes = 0;
   int reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes);
+  ScanChain scan_chain;                // single-launch scans (scan.hpp): BWTC_HIP_SCAN=chained switches them on (slower here)
+  // while alive, the calling thread's scans go through this context's chain
+  struct ScanScope {
+    ScanChain* prev;
+    explicit ScanScope(BwtEngine& e) : prev(current_scan_chain()) { current_scan_chain() = e.scan_chain.status ? &e.scan_chain : nullptr; }
+    ~ScanScope() { current_scan_chain() = prev; }
+  };
   bool device_models = true;           // BWTC_HIP_MODELS=host: the models stay on the worker threads (all routes of round 2)
   std::vector<u32> long_count;   // host scratch of the run statistics: counts of long run lengths, all zero between calls
   // blocks of the 'B' coder between _begin and _end (wavelet_pipeline.hpp)

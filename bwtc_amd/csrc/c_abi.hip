@@ -612,12 +612,15 @@ int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n) {
   if (n * 4 > e.cap * 8) return -1;
   BWTC_HIP_TRY(hipSetDevice(e.device));
   u32* d = static_cast<u32*>(e.d_R1);
+  BwtEngine::ScanScope scan_scope(e);                // the context's single-launch scan, where it is set up
   BWTC_HIP_TRY(hipMemcpyAsync(d, data, n * 4, hipMemcpyHostToDevice, e.stream));
   exclusive_scan_u32(d, n, static_cast<u32*>(e.d_R2), e.stream);
   BWTC_HIP_TRY(hipMemcpyAsync(data, d, n * 4, hipMemcpyDeviceToHost, e.stream));
+  e.h_small[1] = 0;
+  if (e.scan_chain.err) BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 1, e.scan_chain.err, 4, hipMemcpyDeviceToHost, e.stream));
   BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
-  return 0;
+  return e.h_small[1] ? -3 : 0;
 }
 
 }  // extern "C"

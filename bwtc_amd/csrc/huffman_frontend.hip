@@ -499,6 +499,7 @@ u64 huffman_compress_bound(u64 size) {
 
 int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf, u32 n_lf,
                           const u32* freqs, u8* d_out, u64 out_cap, u64* out_bytes) {
+  BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   if (!freqs || !lf || !out_bytes || n_lf == 0 || n_lf > 256) return -1;
   if ((u64)size > e.cap) return -1;
@@ -652,6 +653,7 @@ int huffman_encode_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf
 int wavelet_section_stats_device(BwtEngine& e, const u8* d_bwt, u32 size, const u32* freqs,
                                  WaveletSectionStats* out, u32* d_run_start_arg, u8* d_run_sym_arg,
                                  const std::function<void()>* while_waiting) {
+  BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   const auto t_in = std::chrono::steady_clock::now();
   if (!freqs || !out) return -1;

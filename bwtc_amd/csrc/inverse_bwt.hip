@@ -185,6 +185,7 @@ __global__ void k_inv_check_lf(const u64* __restrict__ lfl, const u32* __restric
 }
 
 int inverse_bwt_device(BwtEngine& e, const u8* d_bwt, u8* d_out, u32 size, const u32* lf, u32 n_lf) {
+  BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   if (!lf || n_lf == 0 || n_lf > 256) return -1;
   if (size == 0) return 0;

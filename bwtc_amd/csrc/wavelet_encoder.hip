@@ -75,7 +75,7 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
       const u64 w_bytes = ((u64)e.wt_coded * 2 + 63) / 64 * 64;
       if (!job.w_owner.reserve(w_bytes + 64)) return -2;
       job.h_tail = reinterpret_cast<u32*>(job.w_owner.data() + w_bytes);
-      job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = 0xFFFFFFFFu;
+      job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = job.h_tail[3] = 0xFFFFFFFFu;
       job.gm_state_in = e.wavelet_state;
       rc = wavelet_models_device(e, d_packed, (u32)e.wt_coded, job.plan, job.coded_pos, e.wavelet_state,
                                  reinterpret_cast<uint16_t*>(job.w_owner.data()), job.h_tail);
@@ -203,7 +203,7 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   if (job.w) {
     // modelled on the device: the copy has landed (above); the passes report themselves
     const u32 n_coded = job.coded_pos.empty() ? 0u : job.coded_pos.back();
-    const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[0] < 8 && job.gm_state_in == state_in &&
+    const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[3] == 0 && job.h_tail[0] < 8 && job.gm_state_in == state_in &&
                     e.wavelet_model == 'B';
     if (ok) {
       job.w_end_state = job.h_tail[0];

@@ -217,6 +217,7 @@ int BwtEngine::reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes) {
 // before the block.
 int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
                           const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail) {
+  BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   std::vector<gm::Task> tasks;
   std::vector<gm::Chunk> chunks;
@@ -302,6 +303,7 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
                      d_order, nc, nt, d_w);
   // total of the scan = every element counted once (else the tables do not describe the streams)
   BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + n_base - 1, 4, hipMemcpyDeviceToDevice, st));
+  if (e.scan_chain.err) BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 3, e.scan_chain.err, 4, hipMemcpyDeviceToDevice, st));   // a timed-out scan
   BWTC_HIP_TRY(e.ensure_d2h_stream());
   BWTC_HIP_TRY(hipEventRecord(e.ev_models, st));
   BWTC_HIP_TRY(hipStreamWaitEvent(e.d2h_stream, e.ev_models, 0));

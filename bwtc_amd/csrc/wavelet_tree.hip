@@ -395,6 +395,7 @@ int BwtEngine::reserve_stats(u64 bytes) {
 int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run_sym, u32 n_runs, const std::vector<u32>& first_run,
                            const bwtc::wavelet::StreamPlan& plan, std::vector<u32>* coded_pos,
                            PinnedBytes* codes, bool async_copy, const u32** d_packed) {
+  BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   const auto t_entry = std::chrono::steady_clock::now();
   const u32 nsec = (u32)plan.sections.size();
@@ -495,12 +496,15 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   BWTC_HIP_TRY(hipMemsetAsync(base + o_packed, 0, ((u64)ceil_div(n, 16) + 1) * 4ull, st));
   hipLaunchKernelGGL(k_wt_compact_pack, dim3(tiles), dim3(kWtTPB), 0, st, d_code, n, d_tile, ptr32(o_packed));
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_tile + tiles, 4, hipMemcpyDeviceToHost, st));
+  e.h_small[1] = 0;
+  if (e.scan_chain.err) BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 1, e.scan_chain.err, 4, hipMemcpyDeviceToHost, st));   // a timed-out scan
   BWTC_HIP_TRY(hipMemcpyAsync(e.h_wt + h_gpos, ptr32(o_gpos), n_groups * 4ull, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(e.wait());
   coded_pos->assign((size_t)n_groups + 1, 0);
   std::memcpy(coded_pos->data(), e.h_wt + h_gpos, n_groups * 4ull);
   const u32 n_coded = e.h_small[0];
   if (n_coded > n) return -3;
+  if (e.h_small[1]) { std::fprintf(stderr, "bwtc_hip: a chained scan timed out\n"); return -3; }
   const u32 words = ceil_div(n_coded, 16);
   if (!codes->reserve(words * 4ull + 16)) return -2;
   if (words) {

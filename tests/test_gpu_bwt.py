@@ -21,12 +21,12 @@ def _load(name):
 
 # ---- primitives --------------------------------------------------------------------------
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100000, (1 << 20) + 3])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 100000, (1 << 20) + 3, 30000001])
 def test_scan(hip_ctx, n):
     rng = np.random.default_rng(n)
-    d = rng.integers(0, 1000, n).astype(np.uint32)
+    d = rng.integers(0, 1000 if n < 4000000 else 100, n).astype(np.uint32)      # the total fits 32 bits (the scan's contract)
     got = hip_ctx.test_scan(d)
-    want = np.concatenate([[0], np.cumsum(d[:-1], dtype=np.uint64)]).astype(np.uint32)
+    want = np.concatenate([np.zeros(1, np.uint64), np.cumsum(d[:-1], dtype=np.uint64)]).astype(np.uint32)
     assert (got == want).all()
 
 
@@ -320,7 +320,7 @@ def test_chained_sort_variant(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["BWTC_HIP_GRAMS=0", "BWTC_HIP_GRAMS=4", "BWTC_HIP_SPLIT_INDEX=0", "BWTC_HIP_PLANES=0",
-                                    "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12"])
+                                    "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12", "BWTC_HIP_SCAN=chained"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""

@@ -290,6 +290,42 @@ def test_wavelet_other_model_letters_on_the_device_route(hip_ctx, oracle):
         hip_ctx.wavelet_reset()
 
 
+@pytest.mark.parametrize("models", ["device", "host"])
+def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(models, oracle, monkeypatch):
+    """The adaptive models run on the GPU (wavelet_gpu_models.hip: state scan, slot space, bracketed
+    chains; the host only range-codes) or on the worker threads (BWTC_HIP_MODELS=host): either way
+    the sequential encoder's bytes, over a stream of blocks of different kinds whose model state
+    runs on from block to block, and with the scans done by the chained single-launch kernel."""
+    from bwtc_amd import hip
+    if models == "host":
+        monkeypatch.setenv("BWTC_HIP_MODELS", "host")
+    else:
+        monkeypatch.setenv("BWTC_HIP_SCAN", "chained")
+    rng = np.random.default_rng(31)
+    parts = [synth.gen_text(3 << 20, 5), synth.gen_dna(1 << 20, 6), np.full(300000, 9, np.uint8),
+             rng.integers(0, 256, 700000).astype(np.uint8), synth.gen_text((2 << 20) + 12345, 7),
+             np.tile(np.array([0, 1], np.uint8), 400000)]
+    bs = 3 << 20
+    d = np.concatenate(parts)
+    with hip.Context(0, bs) as ctx:
+        ctx.wavelet_reset()
+        pend, stream = [], b"B"
+        for off in range(0, d.size, bs):
+            blk = d[off:off + bs]
+            d_in = ctx.dmalloc(blk.size + 16)
+            try:
+                ctx.to_device(d_in, blk)
+                lf, freqs = ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+                out = np.zeros(ctx.compress_bound(blk.size), np.uint8)
+                pend.append((ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=4), out, blk.size))
+            finally:
+                ctx.dfree(d_in)
+        for t, out, n in pend:
+            stream += _packed(n) + _packed(1) + b"\x00" + out[:ctx.wavelet_encode_end(t)].tobytes()
+        stream += b"\x00"
+    assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes(), models
+
+
 def test_wavelet_start_with_begun_blocks_not_yet_in_their_stream(hip_ctx, oracle):
     """_begin lets a block join its stream one or two calls later.  A new stream started in
     between (bwtc_hip_wavelet_start) must not reach back: the begun blocks are coded with the old
