@@ -54,6 +54,19 @@ def usable_cpus():
     return n
 
 
+def _ranges(cpus):
+    """[0, 1, 2, 3, 8, 9] -> "0-3,8-9"."""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
 def mem_available_gb():
     try:
         for line in open("/proc/meminfo"):
@@ -158,6 +171,14 @@ def main():
     cores = usable_cpus()
     threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits
     ctx = hip.Context(gpu, size)
+    # Each rank's workers, the thread that feeds its GPU and (by first touch) the page-locked
+    # buffers they share stay on the NUMA node of the rank's GPU, on CPUs no other rank uses.
+    numa_node = ctx.numa_node()
+    my_cpus = farm.cpu_slice(numa_node) if os.environ.get("BWTC_BENCH_AFFINITY", "1") != "0" else []
+    if my_cpus:
+        ctx.set_worker_cpus(my_cpus)
+        os.sched_setaffinity(0, my_cpus)
+        threads = max(1, min(threads, len(my_cpus)))
 
     # distinct blocks in page-locked host memory: C3 seeds 3, 4, ... (one rank) / C4 seeds 30 + rank + 8 j
     nblk = max(1, args.blocks)
@@ -359,6 +380,8 @@ def main():
             "host_mem_per_rank_gb": round(mem_per_rank, 1),
             "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
+            "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,
+            "depth_needed": int(-(-single_ms // max(step_ms, 1e-3))) if coder == "B" else 1,
             "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,
             "host_model_s_per_block": round((m1 - m0) / blocks_done, 3) if coder == "B" else 0.0,
             "host_coder_s_per_block": round((c1 - c0) / blocks_done, 3) if coder == "B" else 0.0,

@@ -178,6 +178,7 @@ struct BwtEngine {
   bool deferred_queue = false;        // _begin is in use: a begun block joins the stream one or two calls later
   bool async_streams_copy = false;    // set by _begin around its _prepare
   HostPipeline* pipeline = nullptr;   // worker threads, lane engines, coder tasks ('B'; made by the first block)
+  std::vector<int> worker_cpus;       // bwtc_hip_set_worker_cpus: where those threads may run (empty: anywhere)
   std::map<u64, std::shared_ptr<DeviceWaveletJob> > jobs;
   u64 next_ticket = 1;
   unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH

@@ -5,8 +5,10 @@
 #include "entropy_host.hpp"
 #include "wavelet_host.hpp"
 #include "wavelet_gpu_models.hpp"
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
+#include <string>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -354,6 +356,56 @@ int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double
   if (model_seconds) *model_seconds = p ? p->clock.model_ns.load() * 1e-9 : 0.0;
   if (coder_seconds) *coder_seconds = p ? p->clock.coder_ns.load() * 1e-9 : 0.0;
   if (blocks) *blocks = p ? p->clock.blocks.load() : 0;
+  return 0;
+}
+
+int bwtc_hip_numa_node(bwtc_hip_ctx* ctx) {
+  if (!ctx) return -1;
+  char id[64] = {0};
+  if (hipDeviceGetPCIBusId(id, sizeof id, ctx->eng.device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  for (char* p = id; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');     // sysfs spells the id in lower case
+  const std::string path = std::string("/sys/bus/pci/devices/") + id + "/numa_node";
+  int node = -1;
+  if (FILE* f = std::fopen(path.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+  return node;
+}
+
+int bwtc_hip_host_cpu_slice(int numa_node, uint32_t rank, uint32_t ranks, uint32_t* cpus, uint32_t cap) {
+  if (!cpus || ranks == 0 || rank >= ranks) return -1;
+  cpu_set_t mine;
+  CPU_ZERO(&mine);
+  if (sched_getaffinity(0, sizeof mine, &mine) != 0) return -1;
+  std::vector<uint32_t> usable;
+  for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &mine)) usable.push_back((uint32_t)c);
+  if (numa_node >= 0) {
+    // "0-15,128-143" -> the node's CPUs; kept only if some of them are ours
+    char path[96];
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", numa_node);
+    std::vector<uint32_t> on_node;
+    if (FILE* f = std::fopen(path, "r")) {
+      unsigned a = 0, b = 0;
+      for (;;) {
+        if (std::fscanf(f, "%u", &a) != 1) break;
+        b = a;
+        int ch = std::fgetc(f);
+        if (ch == '-') { if (std::fscanf(f, "%u", &b) != 1) break; ch = std::fgetc(f); }
+        for (unsigned c = a; c <= b && c < (unsigned)CPU_SETSIZE; ++c) if (CPU_ISSET(c, &mine)) on_node.push_back(c);
+        if (ch != ',') break;
+      }
+      std::fclose(f);
+    }
+    if (!on_node.empty()) usable.swap(on_node);
+  }
+  const size_t n = usable.size(), b = n * rank / ranks, e = n * (rank + 1) / ranks;
+  uint32_t k = 0;
+  for (size_t i = b; i < e && k < cap; ++i) cpus[k++] = usable[i];
+  return (int)k;
+}
+
+int bwtc_hip_set_worker_cpus(bwtc_hip_ctx* ctx, const uint32_t* cpus, uint32_t n) {
+  if (!ctx || (n && !cpus)) return -1;
+  ctx->eng.worker_cpus.assign(cpus, cpus + n);
+  if (ctx->eng.pipeline) ctx->eng.pipeline->setWorkerCpus(ctx->eng.worker_cpus);
   return 0;
 }
 

@@ -69,7 +69,10 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
     job.copying = async_copy;
     job.codes = job.codes_owner.data();
     const auto t2 = std::chrono::steady_clock::now();
-    if (!e.pipeline) e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
+    if (!e.pipeline) {
+      e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
+      if (!e.worker_cpus.empty()) e.pipeline->setWorkerCpus(e.worker_cpus);
+    }
     if (on_gpu && e.wt_coded) {
       if (!e.w_free.empty()) { job.w_owner.swap(*e.w_free.back()); e.w_free.pop_back(); }
       const u64 w_bytes = ((u64)e.wt_coded * 2 + 63) / 64 * 64;

@@ -20,6 +20,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -41,6 +43,14 @@ class WorkerPool {
  public:
   explicit WorkerPool(unsigned threads) : seq_(0), stop_(false) {
     for (unsigned i = 0; i < (threads ? threads : 1u); ++i) workers_.push_back(std::thread([this] { loop(); }));
+  }
+  // the workers may run on exactly these CPUs from now on (empty: anywhere the process may)
+  void setCpus(const std::vector<int>& cpus) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (cpus.empty()) { if (sched_getaffinity(0, sizeof set, &set) != 0) return; }
+    else for (size_t i = 0; i < cpus.size(); ++i) if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+    for (size_t i = 0; i < workers_.size(); ++i) (void)pthread_setaffinity_np(workers_[i].native_handle(), sizeof set, &set);
   }
   ~WorkerPool() {
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
@@ -249,6 +259,7 @@ class HostPipeline {
   // a block without coded elements (or coded elsewhere): closes the record right away
   static void finishNow(WaveletJob& job);
   unsigned threads() const { return pool_.size(); }
+  void setWorkerCpus(const std::vector<int>& cpus) { pool_.setCpus(cpus); }
   // Lets a worker thread drop the last reference to a collected block: its record, section
   // outputs and tables are a few hundred MB of heap, and returning them to the system costs the
   // caller's thread -- the one that feeds the GPU -- several milliseconds per block.

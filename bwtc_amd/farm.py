@@ -58,6 +58,26 @@ class Farm:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    # ---- host CPUs -------------------------------------------------------------------------------
+    def all_gather_int(self, v):
+        """Every rank's value of a small integer, in rank order."""
+        if self.world == 1:
+            return [int(v)]
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else torch.device("cpu")
+        mine = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return [int(p.item()) for p in parts]
+
+    def cpu_slice(self, numa_node=-1):
+        """CPUs for this rank's worker threads: the ranks whose GPUs sit on the same NUMA node split
+        that node's CPUs (all usable CPUs when the node is unknown) into disjoint contiguous
+        slices, in rank order.  One process per GPU on ONE host, as the bench and the farm run."""
+        from bwtc_amd import hip
+        nodes = self.all_gather_int(numa_node)
+        same = [r for r in range(self.world) if nodes[r] == nodes[self.rank]]
+        return hip.host_cpu_slice(numa_node, same.index(self.rank), len(same))
+
     # ---- timing contract of bench.py -----------------------------------------------------
     def timed(self, step, steps, warmup, drain=None):
         """warmup untimed steps, then `steps` steps bracketed by barrier+synchronize on both

@@ -42,7 +42,7 @@ EXPORTS = [
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
     "bwtc_hip_wavelet_encode_device_prepare", "bwtc_hip_wavelet_encode_queue",
-    "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_depth", "bwtc_hip_numa_node", "bwtc_hip_host_cpu_slice", "bwtc_hip_set_worker_cpus", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
 ]
@@ -86,6 +86,9 @@ def load():
     L.bwtc_hip_copy_wait.argtypes = [_vp]
     L.bwtc_hip_wavelet_host_clock.argtypes = [_vp, _vp, _vp, _vp]
     L.bwtc_hip_wavelet_host_progress.argtypes = [_vp, _vp, _vp]
+    L.bwtc_hip_numa_node.argtypes = [_vp]
+    L.bwtc_hip_host_cpu_slice.argtypes = [ctypes.c_int, _u32, _u32, _vp, _u32]
+    L.bwtc_hip_set_worker_cpus.argtypes = [_vp, _vp, _u32]
     L.bwtc_hip_synth.argtypes = [ctypes.c_char, _u64, _u64, _vp]
     L.bwtc_hip_n_lf.restype = _u32
     L.bwtc_hip_n_lf.argtypes = [_u32, _u32]
@@ -240,6 +243,15 @@ class Context:
         _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
                "bwtc_hip_wavelet_host_clock")
         return m.value, c.value, b.value
+
+    def numa_node(self):
+        """NUMA node of the context's GPU, -1 when the system does not say."""
+        return int(self.lib.bwtc_hip_numa_node(self.handle))
+
+    def set_worker_cpus(self, cpus):
+        """The context's worker threads may run on exactly these CPUs (empty: no restriction)."""
+        a = np.ascontiguousarray(cpus, np.uint32)
+        _check(self.lib.bwtc_hip_set_worker_cpus(self.handle, _ptr(a) if a.size else None, a.size), "bwtc_hip_set_worker_cpus")
 
     def wavelet_host_progress(self):
         """(blocks that joined the host half, blocks whose record the workers have finished)."""
@@ -477,6 +489,17 @@ class Context:
         data = np.array(data, dtype=np.uint32, copy=True)
         _check(self.lib.bwtc_hip_test_scan_u32(self.handle, _ptr(data), data.size), "bwtc_hip_test_scan")
         return data
+
+
+def host_cpu_slice(numa_node, rank, ranks):
+    """CPUs for the workers of context `rank` of `ranks` contexts that share NUMA node `numa_node`
+    (-1: no node restriction): a contiguous slice of what this process may use.  Host only."""
+    L = load()
+    buf = np.zeros(4096, np.uint32)
+    n = L.bwtc_hip_host_cpu_slice(int(numa_node), int(rank), int(ranks), _ptr(buf), buf.size)
+    if n < 0:
+        raise BwtcHipError("bwtc_hip_host_cpu_slice failed with code %d" % n)
+    return [int(c) for c in buf[:n]]
 
 
 def synth_into(kind, seed, out):

@@ -20,6 +20,9 @@
 // The bytes are those of the sequential encoder whatever the number of devices; the same device
 // may be listed twice (two contexts on one GPU), which is how the GPU test checks that.
 #pragma once
+#include <pthread.h>
+#include <sched.h>
+
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -59,6 +62,25 @@ class BlockFarm {
         if (!w->d_comp) hipFatal(-2, "farm record buffer");
       }
       m_workers.push_back(std::move(w));
+    }
+    // Every context's worker threads on the NUMA node of its GPU, on CPUs of their own: the contexts
+    // of one node split that node's CPUs (bwtc_hip_host_cpu_slice); BWTC_HIP_FARM_AFFINITY=0 leaves
+    // the threads where the system puts them.
+    const char* aff = std::getenv("BWTC_HIP_FARM_AFFINITY");
+    if (!(aff && aff[0] == '0')) {
+      std::vector<int> node(m_workers.size());
+      for (size_t d = 0; d < m_workers.size(); ++d) node[d] = bwtc_hip_numa_node(m_workers[d]->ctx);
+      for (size_t d = 0; d < m_workers.size(); ++d) {
+        uint32_t idx = 0, cnt = 0;
+        for (size_t o = 0; o < m_workers.size(); ++o) if (node[o] == node[d]) { if (o < d) ++idx; ++cnt; }
+        std::vector<uint32_t> cpus(4096);
+        const int n = bwtc_hip_host_cpu_slice(node[d], idx, cnt, cpus.data(), (uint32_t)cpus.size());
+        if (n > 0) {
+          m_workers[d]->cpus.assign(cpus.begin(), cpus.begin() + n);
+          hipFatal(bwtc_hip_set_worker_cpus(m_workers[d]->ctx, cpus.data(), (uint32_t)n), "bwtc_hip_set_worker_cpus");
+          m_threadsPerContext = std::max(1u, std::min(m_threadsPerContext, (unsigned)n));
+        }
+      }
     }
     for (size_t d = 0; d < m_workers.size(); ++d) m_workers[d]->thread = std::thread([this, d] { run(*m_workers[d]); });
   }
@@ -142,6 +164,7 @@ class BlockFarm {
     std::deque<Job> jobs;                 // assigned, not yet taken (guarded by the farm's mutex)
     std::deque<Pending> pending;          // 'B': queued on the context, record not collected yet (worker's own)
     std::vector<byte*> outFree;           // 'B': record buffers not in use (at most depth + 1 exist per worker)
+    std::vector<uint32_t> cpus;           // where this context's worker threads (and its feeding thread) run
     size_t taken = 0;                     // jobs taken so far: job number t uses device buffer t & 1
     std::thread thread;
   };
@@ -174,6 +197,12 @@ class BlockFarm {
 
   // one worker = one thread = one context
   void run(Worker& w) {
+    if (!w.cpus.empty()) {                    // the thread that feeds the GPU sits with its workers
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      for (size_t i = 0; i < w.cpus.size(); ++i) if (w.cpus[i] < CPU_SETSIZE) CPU_SET(w.cpus[i], &set);
+      (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
     bool have = false, uploaded = false;      // `cur` taken / its upload issued
     Job cur;
     for (;;) {

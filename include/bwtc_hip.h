@@ -215,6 +215,22 @@ int bwtc_hip_wavelet_encode_queue(bwtc_hip_ctx* ctx, uint64_t ticket, uint32_t s
                                   uint32_t* state_out);
 /* Blocks that may be between _begin and _end at once on this context. */
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
+/* Host CPUs for the worker threads of the contexts of one node (one context per GPU):
+ * the 'B' coder's host half is memory- and cache-hungry, so a context's workers -- and the
+ * page-locked buffers they read, placed by first touch / the caller's policy -- belong on the NUMA
+ * node of its GPU, and contexts must not share cores.
+ *   _numa_node        NUMA node of the context's GPU (PCI bus id -> /sys/bus/pci/devices/<id>/numa_node),
+ *                     -1 when the system does not say;
+ *   _host_cpu_slice   host-only: the CPUs this process may use (its affinity mask), cut down to those
+ *                     of `numa_node` when that is >= 0 and the node has any, split into `ranks`
+ *                     contiguous slices; slice `rank` goes to cpus[0..], the return value is its size
+ *                     (0: nothing to hand out, negative: bad arguments).  Callers give rank / ranks
+ *                     among the contexts that share the node;
+ *   _set_worker_cpus  the context's worker threads (existing ones and those made later) may run on
+ *                     exactly these CPUs; n = 0 lifts the restriction.  The calling thread is left alone. */
+int bwtc_hip_numa_node(bwtc_hip_ctx* ctx);
+int bwtc_hip_host_cpu_slice(int numa_node, uint32_t rank, uint32_t ranks, uint32_t* cpus, uint32_t cap);
+int bwtc_hip_set_worker_cpus(bwtc_hip_ctx* ctx, const uint32_t* cpus, uint32_t n);
 /* Host time the context's worker threads have spent so far in the two host stages of the wavelet
  * coder (adaptive models, range coders; seconds summed over threads) and the blocks queued. */
 int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds,

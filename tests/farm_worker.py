@@ -26,8 +26,14 @@ def main():
     records = {i: zlib.compress(("block %d" % i).encode() * 10) for i in mine}
     ordered = farm.gather_records(records, n_blocks)
     total_units = farm.sum(len(mine))
+    # host CPUs of this rank's workers: every rank reports the same NUMA node here (a made-up one
+    # for half of the ranks when FARM_TWO_NODES is set), the slices must not overlap
+    node = farm.rank % 2 if os.environ.get("FARM_TWO_NODES") else -1
+    cpus = farm.cpu_slice(node)
+    os.sched_setaffinity(0, cpus or os.sched_getaffinity(0))
     res = {"rank": farm.rank, "world": farm.world, "mine": mine, "elapsed": elapsed,
-           "calls": len(calls), "total_units": total_units}
+           "calls": len(calls), "total_units": total_units, "cpus": cpus, "node": node,
+           "affinity_now": sorted(os.sched_getaffinity(0))}
     if farm.rank == 0:
         res["ordered"] = [zlib.decompress(r).decode()[:7] for r in ordered]
     with open("%s.%d" % (out_path, farm.rank), "w") as f:

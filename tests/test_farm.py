@@ -45,6 +45,41 @@ def test_gloo_farm(tmp_path, world, n_blocks):
     assert res[0]["ordered"] == ["block %d" % i for i in range(n_blocks)]
 
 
+@pytest.mark.parametrize("world,two_nodes", [(2, False), (3, False), (2, True)])
+def test_gloo_farm_ranks_get_disjoint_cpu_slices(tmp_path, world, two_nodes):
+    """Every rank pins its worker threads (and itself) to its own slice of the host's CPUs: the
+    ranks of one NUMA node split that node's CPUs; no CPU is handed out twice."""
+    out = str(tmp_path / "res")
+    port = _free_port()
+    usable = sorted(os.sched_getaffinity(0))
+    if len(usable) < world:
+        pytest.skip("fewer CPUs than ranks")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if two_nodes:
+            env["FARM_TWO_NODES"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "farm_worker.py"), out, "4"], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+    seen = []
+    for r in res:
+        assert r["cpus"], "a rank got no CPU"
+        assert r["affinity_now"] == sorted(r["cpus"])          # the rank really runs there
+        assert set(r["cpus"]) <= set(usable)
+        seen += r["cpus"]
+    if not two_nodes:
+        assert len(seen) == len(set(seen)), "a CPU was handed to two ranks"
+        assert abs(len(res[0]["cpus"]) - len(res[-1]["cpus"])) <= 1
+    else:
+        # ranks on different (made-up) nodes: each is alone on its node; a node the system does not
+        # know falls back to all usable CPUs, a known one is cut to its CPUs
+        for r in res:
+            assert len(r["cpus"]) >= 1
+
+
 def test_frame_stream_matches_oracle_framing(oracle):
     import numpy as np
     from bwtc_amd.farm import frame_stream
