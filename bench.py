@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus-blocks", type=int, default=16,
+                    help="BWTC_CORPUS=<file>: how many blocks of --size-mib of it are coded (reported as `corpus`)")
     args = ap.parse_args()
     coder = None if args.bwt_only else args.coder
 
@@ -269,6 +271,55 @@ def main():
     finished = (f1 - f0) if coder == "B" else args.steps
     finished = int(-farm.max(-finished))                 # the slowest rank's count
 
+    # a real corpus (enwik8 / enwik9 ...) when one is supplied, cut into blocks of
+    # the same size, as ONE closed stream: first block begun -> last record collected.  The
+    # synthetic generator has 64 tokens; this is the protection against tuning to it.
+    corpus = None
+    cpath = os.environ.get("BWTC_CORPUS")
+    if cpath and rank == 0 and coder in ("B", "H"):
+        try:
+            fsize = os.path.getsize(cpath)
+            nb = max(1, min(args.corpus_blocks, (fsize + size - 1) // size))
+            cblocks = []
+            with open(cpath, "rb") as f:
+                for _ in range(nb):
+                    raw = f.read(size)
+                    if not raw:
+                        break
+                    b = ctx.host_alloc(len(raw))
+                    b[:] = np.frombuffer(raw, np.uint8)
+                    cblocks.append(b)
+            ctx.wavelet_reset()
+            cring = [np.empty(ctx.compress_bound(size), np.uint8) for _ in range(depth + 1)]
+            cpend, cbytes, t0 = [], 0, time.perf_counter()
+            ctx.to_device_async(d_in[0], cblocks[0])
+            for i, blk in enumerate(cblocks):
+                if coder == "B" and len(cpend) >= depth:
+                    cbytes += ctx.wavelet_encode_end(cpend.pop(0))
+                ctx.copy_wait()
+                if i + 1 < len(cblocks):
+                    ctx.to_device_async(d_in[(i + 1) % 2], cblocks[i + 1])
+                lf, freqs = ctx.bwt_block_device(d_in[i % 2], d_out, blk.size, 8)
+                if coder == "B":
+                    cpend.append(ctx.wavelet_encode_device_begin(d_out, blk.size, lf, freqs, cring[i % (depth + 1)], threads))
+                else:
+                    n = ctx.huffman_encode_device(d_out, blk.size, lf, freqs, d_comp)
+                    rc = ctx.lib.bwtc_hip_memcpy_to_host(ctx.handle, h_rec.ctypes.data, d_comp, n)
+                    if rc:
+                        raise hip.BwtcHipError("bwtc_hip_memcpy_to_host failed with code %d" % rc)
+                    cbytes += n
+            while cpend:
+                cbytes += ctx.wavelet_encode_end(cpend.pop(0))
+            wall = time.perf_counter() - t0
+            total = sum(b.size for b in cblocks)
+            corpus = {"path": os.path.basename(cpath), "bytes": int(total), "blocks": len(cblocks),
+                      "compressed_bytes": int(cbytes), "ratio": round(cbytes / max(total, 1), 4),
+                      "MBps": round(total / 1e6 / wall, 2), "wall_s": round(wall, 3),
+                      "what": "the file's first blocks as one closed stream (first block begun -> last record collected), "
+                              "the stream's own model state from block to block"}
+        except (OSError, hip.BwtcHipError) as ex:
+            corpus = {"path": cpath, "error": str(ex)}
+
     # the spec peak beside what a plain device copy reaches on this box
     copy_gbs = None
     if rank == 0:
@@ -393,6 +444,8 @@ def main():
         if coder == "B" and cores // max(world, 1) < 16:
             out["warning"] = ("only %d host threads per rank: the 'B' coder's host half needs about 16 per GPU "
                               "to keep up with the device half" % threads)
+        if corpus is not None:
+            out["corpus"] = corpus
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size_mib or args.size_mib, seeds[0], coder or "", args.cpu_runs)
         print(json.dumps(out), flush=True)

@@ -154,3 +154,58 @@ def test_cli_roundtrip_1GiB_single_block_default_coder(tmp_path):
     assert r.returncode == 0, r.stderr
     back = np.fromfile(out, np.uint8)
     assert back.size == data.size and (back == data).all()
+
+
+def _real_text(limit):
+    """Real (not generated) text: the file BWTC_CORPUS names when there is one (SURVEY.md 8(d):
+    enwik8 / enwik9), else Python sources and documentation found on the box, concatenated in
+    sorted order -- anything written by people, so that the coders also see inputs that the
+    64-token generator never makes (other section sizes, other run statistics)."""
+    path = os.environ.get("BWTC_CORPUS")
+    if path and os.path.exists(path):
+        with open(path, "rb") as f:
+            return f.read(limit), os.path.basename(path)
+    buf = bytearray()
+    import sysconfig
+    roots = [sysconfig.get_paths()["stdlib"], "/usr/share/common-licenses"]
+    seen = 0
+    for root in roots:                                   # bounded walk: the standard library only, no site-packages
+        for dirpath, dirnames, filenames in os.walk(root):
+            dirnames[:] = sorted(d for d in dirnames if d not in ("site-packages", "dist-packages", "__pycache__", "test", "tests"))
+            for name in sorted(filenames):
+                seen += 1
+                if len(buf) >= limit or seen > 20000:
+                    break
+                if not (name.endswith(".py") or name.endswith(".txt") or root.endswith("licenses")):
+                    continue
+                try:
+                    with open(os.path.join(dirpath, name), "rb") as f:
+                        buf += f.read(limit - len(buf))
+                except OSError:
+                    pass
+            if len(buf) >= limit or seen > 20000:
+                break
+    return bytes(buf), "local files"
+
+
+def test_real_text_roundtrip_and_oracle_parity(tmp_path, oracle):
+    """BWTC_CORPUS (or real text found on the box) through `compress` (default coder 'B', models
+    on the GPU) and `uncompress`; the stream is also the oracle's, byte for byte."""
+    data, name = _real_text(24 << 20)
+    if len(data) < (1 << 20):
+        pytest.skip("no real text to be found here")
+    src = tmp_path / "corpus.bin"
+    dst = tmp_path / "corpus.bwtc"
+    out = tmp_path / "corpus.out"
+    src.write_bytes(data)
+    exe = os.path.join(ROOT, "bwtc_amd", "host", "compress")
+    unexe = os.path.join(ROOT, "bwtc_amd", "host", "uncompress")
+    r = subprocess.run([exe, "-m", "50", "-v", "1", str(src), str(dst)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    stream = dst.read_bytes()
+    arr = np.frombuffer(data, np.uint8)
+    assert stream == oracle.oracle_compress_B(arr, int(50 * 1000000 * 0.185), 8).tobytes(), name
+    r = subprocess.run([unexe, str(dst), str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+    print("real text (%s): %d -> %d bytes, ratio %.3f" % (name, len(data), len(stream), len(stream) / len(data)))
