@@ -274,6 +274,7 @@ def main():
     # a real corpus (enwik8 / enwik9 ...) when one is supplied, cut into blocks of
     # the same size, as ONE closed stream: first block begun -> last record collected.  The
     # synthetic generator has 64 tokens; this is the protection against tuning to it.
+    kt_main, st_main = ctx.kernel_timers(), ctx.stats()    # of the timed region's blocks, before another stream runs
     corpus = None
     cpath = os.environ.get("BWTC_CORPUS")
     if cpath and rank == 0 and coder in ("B", "H"):
@@ -341,8 +342,7 @@ def main():
             copy_gbs = None
 
     if rank == 0:
-        kt = ctx.kernel_timers()
-        st = ctx.stats()
+        kt, st = kt_main, st_main
         total_mb = world * args.steps * size / 1e6
         r_eff = st.active_sum / max(st.n, 1)
         roof = None
