@@ -21,8 +21,11 @@
 #include "scan.hpp"
 #include "wavelet_host.hpp"
 #include "wavelet_pipeline.hpp"
+#include <condition_variable>
 #include <future>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <utility>
 #include <cstdlib>
@@ -72,6 +75,67 @@ class PinnedBytes {
   uint8_t* p_;
   size_t n_;
   bool locked_;
+};
+
+// Page-locked buffers of one size class, recycled between blocks.  Locking a gigabyte of pages
+// takes 60 ms: once blocks overlap, a helper thread allocates a few buffers AHEAD of the thread that
+// feeds the GPU (never more than `limit` in all), so that a stream's first blocks do not each stop
+// for it.
+class PinnedPool {
+ public:
+  ~PinnedPool() { stop(); }
+  // a recycled (or pre-allocated) buffer, if there is one
+  bool take(PinnedBytes* into) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (free_.empty()) return false;
+    into->swap(*free_.back());
+    free_.pop_back();
+    cv_.notify_all();
+    return true;
+  }
+  void give(PinnedBytes* from, size_t keep_at_most) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (from->size() && free_.size() < keep_at_most) {
+      free_.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
+      free_.back()->swap(*from);
+    }
+  }
+  // the caller allocated one itself (counts against the limit of the helper)
+  void noteAllocated() { std::lock_guard<std::mutex> g(mu_); ++made_; }
+  // from now on keep up to two spare buffers of `bytes` ready, `limit` buffers in all
+  void allocateAhead(int device, size_t bytes, unsigned limit) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (running_ || bytes == 0) return;
+    running_ = true; quit_ = false;
+    helper_ = std::thread([this, device, bytes, limit] {
+      (void)hipSetDevice(device);
+      std::unique_lock<std::mutex> l(mu_);
+      while (!quit_ && made_ < limit) {
+        if (free_.size() >= 2) { cv_.wait(l); continue; }
+        l.unlock();
+        std::unique_ptr<PinnedBytes> b(new PinnedBytes());
+        const bool ok = b->reserve(bytes);
+        l.lock();
+        if (!ok) break;
+        ++made_;
+        free_.push_back(std::move(b));
+      }
+    });
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> g(mu_); quit_ = true; cv_.notify_all(); }
+    if (helper_.joinable()) helper_.join();
+    std::lock_guard<std::mutex> g(mu_);
+    running_ = false;
+  }
+  void clear() { stop(); std::lock_guard<std::mutex> g(mu_); free_.clear(); made_ = 0; }
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::unique_ptr<PinnedBytes> > free_;
+  std::thread helper_;
+  unsigned made_ = 0;
+  bool running_ = false, quit_ = false;
 };
 
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
@@ -183,8 +247,7 @@ struct BwtEngine {
   u64 next_ticket = 1;
   unsigned max_inflight = 16;          // BWTC_HIP_WAVELET_DEPTH
   u64 huge_group_elements = 32u << 20; // BWTC_HIP_HUGE_MI: groups this large are modelled by scalar tasks, not lanes
-  std::vector<std::unique_ptr<PinnedBytes> > codes_free;              // recycled: no fresh pages per block
-  std::vector<std::unique_ptr<PinnedBytes> > w_free;
+  PinnedPool codes_pool, w_pool;                                       // recycled: no fresh pages per block
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead

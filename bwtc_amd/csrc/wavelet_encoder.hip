@@ -54,7 +54,7 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
   const u32* d_run_start = e.d_run_start[job.run_buf];
   const u8* d_run_sym = e.d_run_sym[job.run_buf];
   if (on_device) {
-    if (!e.codes_free.empty()) { job.codes_owner.swap(*e.codes_free.back()); e.codes_free.pop_back(); }
+    const bool codes_recycled = e.codes_pool.take(&job.codes_owner);
     // The adaptive models on the device (wavelet_gpu_models.hip) need the carried state BEFORE this
     // block: known when every block begun before it has joined the stream -- the _begin flow, where
     // the block before the previous one joined while the scanner ran.  (_prepare / _queue callers
@@ -66,6 +66,7 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
     const u32* d_packed = nullptr;
     int rc = wavelet_streams_device(e, d_run_start, d_run_sym, n_runs, st.first_run, job.plan, &job.coded_pos, &job.codes_owner, async_copy, &d_packed);
     if (rc) return rc;
+    if (!codes_recycled) e.codes_pool.noteAllocated();
     job.copying = async_copy;
     job.codes = job.codes_owner.data();
     const auto t2 = std::chrono::steady_clock::now();
@@ -74,9 +75,15 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
       if (!e.worker_cpus.empty()) e.pipeline->setWorkerCpus(e.worker_cpus);
     }
     if (on_gpu && e.wt_coded) {
-      if (!e.w_free.empty()) { job.w_owner.swap(*e.w_free.back()); e.w_free.pop_back(); }
+      const bool w_recycled = e.w_pool.take(&job.w_owner);
       const u64 w_bytes = ((u64)e.wt_coded * 2 + 63) / 64 * 64;
+      const size_t had = job.w_owner.size();
       if (!job.w_owner.reserve(w_bytes + 64)) return -2;
+      if (!w_recycled || job.w_owner.size() != had) e.w_pool.noteAllocated();
+      if (e.jobs.size() >= 2) {                       // blocks overlap: the next ones' buffers are made ahead, off this thread
+        e.w_pool.allocateAhead(e.device, (size_t)(w_bytes + w_bytes / 64 + 64), e.max_inflight + 1);
+        e.codes_pool.allocateAhead(e.device, job.codes_owner.size(), e.max_inflight + 1);
+      }
       job.h_tail = reinterpret_cast<u32*>(job.w_owner.data() + w_bytes);
       job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = job.h_tail[3] = 0xFFFFFFFFu;
       job.gm_state_in = e.wavelet_state;
@@ -322,14 +329,8 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t_finished).count());
   e.jobs.erase(it);
   // keep the two big buffers: fresh ones would be paged in again for every block
-  if (job.codes_owner.size() && e.codes_free.size() < e.max_inflight) {
-    e.codes_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
-    e.codes_free.back()->swap(job.codes_owner);
-  }
-  if (job.w_owner.size() && e.w_free.size() < e.max_inflight) {
-    e.w_free.push_back(std::unique_ptr<PinnedBytes>(new PinnedBytes()));
-    e.w_free.back()->swap(job.w_owner);
-  }
+  e.codes_pool.give(&job.codes_owner, e.max_inflight + 2);
+  e.w_pool.give(&job.w_owner, e.max_inflight + 2);
   if (job.prob.size() && e.prob_free.size() < e.max_inflight) {
     e.prob_free.push_back(std::unique_ptr<RawBuffer<uint16_t> >(new RawBuffer<uint16_t>()));
     e.prob_free.back()->swap(job.prob);
@@ -367,8 +368,8 @@ void wavelet_pipeline_release(BwtEngine& e) {
                  e.pipeline->clock.coder_ns.load() * 1e-9);
   delete e.pipeline;                              // joins the workers (engines retire when nothing is queued)
   e.pipeline = nullptr;
-  e.codes_free.clear();
-  e.w_free.clear();
+  e.codes_pool.clear();
+  e.w_pool.clear();
   e.prob_free.clear();
 }
 

@@ -771,7 +771,7 @@ namespace {
 struct SectionPlan {
   bool ok;
   std::vector<uint8_t> prefix;
-  uint32_t n_nodes, n_groups;
+  uint32_t n_nodes, n_groups, n_leaves;
   std::vector<uint32_t> level_first;
   std::vector<uint8_t> types;
   std::vector<uint32_t> pool;
@@ -780,7 +780,7 @@ struct SectionPlan {
   struct Length { uint32_t len, off, steps; };
   std::vector<Length> lengths;
   uint64_t max_elements;
-  SectionPlan() : ok(true), n_nodes(0), n_groups(0), max_elements(0) {
+  SectionPlan() : ok(true), n_nodes(0), n_groups(0), n_leaves(0), max_elements(0) {
     std::memset(symtab, 0, sizeof symtab);
     std::memset(symcode, 0, sizeof symcode);
   }
@@ -824,6 +824,7 @@ void planSection(const SectionRuns& in, SectionPlan* sec) {
     }
   }
   if (leaves > 256) { sec->ok = false; return; }
+  sec->n_leaves = static_cast<uint32_t>(leaves);
   sec->n_nodes = static_cast<uint32_t>(types.size());
 
   // the integer levels: union trie of the section's length codes
@@ -900,6 +901,13 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   const unsigned hc = std::thread::hardware_concurrency();
   parallelFor(nsec, std::max(1u, std::min(8u, hc ? hc : 1u)), weight.data(), [&](size_t s) { planSection(sections[s], &local[s]); });
 
+  // dense ids when they fit: one per symbol-tree node, one per (integer node, symbol leaf)
+  uint64_t n_ids = 0;
+  for (size_t s = 0; s < nsec; ++s)
+    if (local[s].ok) n_ids += local[s].n_nodes + static_cast<uint64_t>(local[s].n_groups - local[s].n_nodes) * std::max<uint32_t>(1, local[s].n_leaves);
+  const bool dense = n_ids > 0 && n_ids <= kMaxDenseIds && !std::getenv("BWTC_HIP_SPARSE_STEP_KEYS");
+  plan->id_group.clear();
+  uint32_t id_next = 0;
   plan->sections.assign(nsec, StreamPlan::Section());
   plan->group_type.clear();
   plan->symtab.assign(nsec * 512, 0);
@@ -922,7 +930,21 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
     plan->group_type.insert(plan->group_type.end(), in.types.begin(), in.types.end());
     const uint32_t poolBase = static_cast<uint32_t>(plan->pool.size());
     const uint32_t groupBits = sec.group_base << kStepGroupShift;
-    for (size_t i = 0; i < in.pool.size(); ++i) plan->pool.push_back(in.pool[i] + groupBits);
+    if (dense) {
+      const uint32_t span = std::max<uint32_t>(1, in.n_leaves), id0 = id_next;
+      for (uint32_t g = 0; g < in.n_groups; ++g) {
+        const uint32_t width = g < in.n_nodes ? 1u : span;
+        plan->id_group.insert(plan->id_group.end(), width, sec.group_base + g);
+        id_next += width;
+      }
+      for (size_t i = 0; i < in.pool.size(); ++i) {
+        const uint32_t g = in.pool[i] >> kStepGroupShift;
+        const uint32_t id = id0 + (g < in.n_nodes ? g : in.n_nodes + (g - in.n_nodes) * span);
+        plan->pool.push_back((id << kStepLeafShift) | (in.pool[i] & 1u));
+      }
+    } else {
+      for (size_t i = 0; i < in.pool.size(); ++i) plan->pool.push_back(in.pool[i] + groupBits);
+    }
     for (uint32_t c = 0; c < 256; ++c) {
       if (!(in.symtab[c * 2 + 1] & 255u)) continue;
       plan->symtab[(s * 256 + c) * 2] = in.symtab[c * 2] + poolBase;
@@ -1251,7 +1273,7 @@ bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>&
           if (plan.over[i * 4] == len) { loff = plan.over[i * 4 + 1]; lsteps = plan.over[i * 4 + 2]; }
       }
       if (lsteps == 0) return false;
-      for (uint32_t i = 0; i < lsteps; ++i) key.push_back(plan.pool[loff + i] | (((meta >> 8) & 255u) << kStepLeafShift));
+      for (uint32_t i = 0; i < lsteps; ++i) key.push_back(plan.pool[loff + i] + (((meta >> 8) & 255u) << kStepLeafShift));
     }
   }
   const size_t n = key.size();
@@ -1260,7 +1282,10 @@ bool expandStreamsOnHost(const StreamPlan& plan, const std::vector<SectionRuns>&
   auto sortKey = [&](uint32_t i) { return key[i] >> kStepLeafShift; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sortKey(a) < sortKey(b); });
   const size_t groups = plan.group_type.size();
-  auto groupOf = [&](size_t j) { return (key[order[j]] >> kStepGroupShift) & groupMask; };
+  const bool dense = !plan.id_group.empty();
+  auto groupOf = [&](size_t j) {
+    return dense ? plan.id_group[key[order[j]] >> kStepLeafShift] : (key[order[j]] >> kStepGroupShift) & groupMask;
+  };
   // The gap flags once more the way the reference derives them -- changed = the bit differs from
   // the previous bit of the node, OR-ed down each run -- as a check of the prefix rule above.
   {

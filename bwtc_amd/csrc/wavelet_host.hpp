@@ -58,7 +58,8 @@ inline bool isWaveletModel(char c) { return c == 'B' || c == 'b' || c == 'u'; }
 constexpr uint32_t kStepBitShift = 0;      // step word: bit 0 = the bit,
 constexpr uint32_t kStepGapShift = 1;      //   bit 1 = gap flag (symbol-tree steps); bits 0-1 are below the sort key
 constexpr uint32_t kStepLeafShift = 2;     //   bits 2..9 = rank of the symbol leaf (integer steps),
-constexpr uint32_t kStepGroupShift = 10;   //   bits 10..31 = group number (block-wide)
+constexpr uint32_t kStepGroupShift = 10;   //   bits 10..31 = group number (block-wide); or bits 2..31 = dense id (StreamPlan::id_group)
+constexpr uint32_t kMaxDenseIds = 1u << 22;
 constexpr uint32_t kMaxGroups = 1u << 22;
 constexpr uint32_t kLenDense = 512;        // run lengths below this are looked up in a dense table (uploaded with every block: 4 KiB per section)
 
@@ -82,6 +83,12 @@ struct StreamPlan {
   std::vector<uint32_t> over;              // x {length, pool offset, steps, 0}, ascending by length
   std::vector<uint32_t> pool;              // step words
   uint64_t max_elements;                   // upper bound of the number of steps of the block
+  // Dense sort keys: instead of (group, leaf rank) as two bit fields -- 8 bits of leaf rank under every
+  // group number, nearly all of them unused -- a step word carries  id << 2 | gap << 1 | bit  with
+  // id = id_base(group) + leaf rank, where a symbol-tree node takes one id and an integer node as
+  // many as its section has symbol leaves.  A 256 MiB text block has some 40 000 ids: the step sort
+  // needs two 8-bit passes instead of three.  id_group[id] = the id's group; empty: the two-field layout.
+  std::vector<uint32_t> id_group;
 };
 
 // false: the shapes need something the device path does not do (too many groups, a symbol code

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
       }
     }
 #pragma unroll
-    for (int u = 0; u < kU; ++u) w[u] = t.pool[addr[u]] | extra[u];       // past the end: pool[0], not stored
+    for (int u = 0; u < kU; ++u) w[u] = t.pool[addr[u]] + extra[u];       // past the end: pool[0], not stored (+: a dense id takes the leaf rank as a summand)
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const u32 j = jb + (u32)u * kWtTPB;
@@ -250,8 +250,12 @@ constexpr u8 kWtSkip = 0xFF;
 
 // sorted order: what encodeTreeBF does with the bit -> code[j] = bit | gap << 1, or kWtSkip;
 // coded elements per tile -> tile_count; first element of every group -> group_start
+__device__ __forceinline__ u32 wt_group_of(u32 k, const u32* __restrict__ id_group) {
+  return id_group ? id_group[k >> kStepLeafShift] : (k >> kStepGroupShift) & kStepGroupMask;
+}
+
 __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ key, u32 n,
-                                                      const u8* __restrict__ group_type,
+                                                      const u8* __restrict__ group_type, const u32* __restrict__ id_group,
                                                       u8* __restrict__ code,
                                                       u32* __restrict__ tile_count,
                                                       u32* __restrict__ group_start) {
@@ -265,16 +269,19 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
     k[e] = j < n ? key[j] : 0u;
     kp[e] = (j < n && j) ? key[j - 1] : 0u;
   }
+  u32 grp[kWtE], grp_prev[kWtE];
+#pragma unroll
+  for (int e = 0; e < kWtE; ++e) { grp[e] = wt_group_of(k[e], id_group); grp_prev[e] = wt_group_of(kp[e], id_group); }   // k = 0 past the end: id / group 0 exists
   u8 type[kWtE];
 #pragma unroll
-  for (int e = 0; e < kWtE; ++e) type[e] = group_type[(k[e] >> kStepGroupShift) & kStepGroupMask];   // k = 0 past the end: group 0 exists
+  for (int e = 0; e < kWtE; ++e) type[e] = group_type[grp[e]];
   u32 coded = 0;
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) {
     const u32 j = base + e * kWtTPB + threadIdx.x;
     if (j < n) {
-      const u32 g = (k[e] >> kStepGroupShift) & kStepGroupMask;
-      const bool first = j == 0 || ((kp[e] >> kStepGroupShift) & kStepGroupMask) != g;
+      const u32 g = grp[e];
+      const bool first = j == 0 || grp_prev[e] != g;
       if (first) group_start[g] = j;
       const u32 bit = k[e] & 1u;
       u8 c;
@@ -405,7 +412,9 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   if (plan.max_elements + kWtTile >= (1ull << 32)) return -5;       // step indices are 32 bit
   BWTC_HIP_TRY(hipSetDevice(e.device));
   const u64 cap = plan.max_elements;
-  const int key_bits = (int)kStepGroupShift + bit_width_u64(n_groups ? n_groups - 1 : 0);
+  const bool dense_ids = !plan.id_group.empty();
+  const int key_bits = dense_ids ? (int)kStepLeafShift + bit_width_u64(plan.id_group.size() - 1)
+                                 : (int)kStepGroupShift + bit_width_u64(n_groups ? n_groups - 1 : 0);
 
   // workspace layout
   u64 at = 0;
@@ -418,6 +427,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u64 o_over = take(plan.over.size() * 4ull + 16);
   const u64 o_pool = take(plan.pool.size() * 4ull + 16);
   const u64 o_gtype = take(n_groups + 16);
+  const u64 o_idgroup = take(plan.id_group.size() * 4ull + 16);
   const u64 tables_end = at;
   const u64 o_gstart = take((n_groups + 1) * 4ull);
   const u64 o_gpos = take((n_groups + 1) * 4ull);
@@ -450,6 +460,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
     if (!plan.over.empty()) std::memcpy(h + o_over, plan.over.data(), plan.over.size() * 4ull);
     if (!plan.pool.empty()) std::memcpy(h + o_pool, plan.pool.data(), plan.pool.size() * 4ull);
     std::memcpy(h + o_gtype, plan.group_type.data(), n_groups);
+    if (dense_ids) std::memcpy(h + o_idgroup, plan.id_group.data(), plan.id_group.size() * 4ull);
     BWTC_HIP_TRY(hipMemcpyAsync(base, h, tables_end, hipMemcpyHostToDevice, st));
   }
   WtTables t;
@@ -462,6 +473,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   t.over = reinterpret_cast<const uint4*>(base + o_over);
   t.pool = ptr32(o_pool);
   const u8* d_gtype = base + o_gtype;
+  const u32* d_idgroup = dense_ids ? ptr32(o_idgroup) : nullptr;
 
   if (std::getenv("BWTC_HIP_DEBUG"))
     std::fprintf(stderr, "streams: tables of %llu bytes staged and queued %.2f ms after entry\n", (unsigned long long)tables_end,
@@ -488,7 +500,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 tiles = ceil_div(n, kWtTile);
   u8* d_code = base + o_code;
   u32* d_tile = ptr32(o_tile);
-  hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_code, d_tile, d_gstart);
+  hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_tile + tiles, 0, 4, st));
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
   hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB / kWave)), dim3(kWtTPB), 0, st, d_gstart,
