@@ -905,7 +905,10 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
   uint64_t n_ids = 0;
   for (size_t s = 0; s < nsec; ++s)
     if (local[s].ok) n_ids += local[s].n_nodes + static_cast<uint64_t>(local[s].n_groups - local[s].n_nodes) * std::max<uint32_t>(1, local[s].n_leaves);
-  const bool dense = n_ids > 0 && n_ids <= kMaxDenseIds && !std::getenv("BWTC_HIP_SPARSE_STEP_KEYS");
+  // Opt-in (BWTC_HIP_DENSE_STEP_KEYS=1).  Measured on the 256 MiB text block: 66 000 ids are 17
+  // bits, still three 8-bit passes like the 19 bits of the two-field layout, and the id -> group
+  // look-ups cost the select kernel half a millisecond; it pays only below 65 536 ids.
+  const bool dense = n_ids > 0 && n_ids <= kMaxDenseIds && std::getenv("BWTC_HIP_DENSE_STEP_KEYS") != nullptr;
   plan->id_group.clear();
   uint32_t id_next = 0;
   plan->sections.assign(nsec, StreamPlan::Section());
