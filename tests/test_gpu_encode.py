@@ -299,6 +299,7 @@ def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(mod
     from bwtc_amd import hip
     if models == "host":
         monkeypatch.setenv("BWTC_HIP_MODELS", "host")
+        monkeypatch.setenv("BWTC_HIP_DENSE_STEP_KEYS", "1")      # and the opt-in dense sort ids of the steps
     else:
         monkeypatch.setenv("BWTC_HIP_SCAN", "chained")
     rng = np.random.default_rng(31)
