@@ -325,21 +325,31 @@ BWTC_GM_HD void laneCount(const u32* packed, u32 begin, u32 end, u32 type, u32 s
 #else
 #define BWTC_GM_OR(ptr, val) (*(ptr) |= (val))
 #endif
+// `shared`: bit k set = the word slot k is filling also holds bits of the chunk before (it did not
+// start on a word border): that one is OR-ed in; the words after it are this chunk's alone and are
+// stored (an atomic costs a 64-byte round trip to memory, and there would be one per 32 elements).
 template <u32 TYPE>
-BWTC_GM_HD void lanePartitionT(const u32* packed, u32 begin, u32 end, u32 state, u32* pos, u32* acc, u32 stride, u32* sbits) {
+BWTC_GM_HD void lanePartitionT(const u32* packed, u32 begin, u32 end, u32 state, u32* pos, u32* acc, u32 stride, u32* sbits,
+                               u32& shared) {
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
   forElements(packed, begin, end, [&](u32, u32 v) {
     const u32 slot = stepMachinesT<TYPE>(v, m);
     const u32 p = pos[slot * stride];
     u32 a = acc[slot * stride] | ((v & 1u) << (p & 31u));
-    if ((p & 31u) == 31u) { if (a) BWTC_GM_OR(&sbits[p >> 5], a); a = 0; }
+    if ((p & 31u) == 31u) {
+      if ((shared >> slot) & 1u) { if (a) BWTC_GM_OR(&sbits[p >> 5], a); shared &= ~(1u << slot); }
+      else sbits[p >> 5] = a;
+      a = 0;
+    }
     acc[slot * stride] = a;
     pos[slot * stride] = p + 1;
   });
 }
 BWTC_GM_HD void lanePartition(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32* pos, u32* acc,
                               u32 stride, u32* sbits) {
-  BWTC_GM_BY_TYPE(type, lanePartitionT<TYPE>(packed, begin, end, state, pos, acc, stride, sbits));
+  u32 shared = 0;
+  for (u32 k = 0; k < kSlots; ++k) shared |= ((pos[k * stride] & 31u) != 0u ? 1u : 0u) << k;
+  BWTC_GM_BY_TYPE(type, lanePartitionT<TYPE>(packed, begin, end, state, pos, acc, stride, sbits, shared));
   for (u32 k = 0; k < kSlots; ++k) {
     const u32 a = acc[k * stride];
     if (a) BWTC_GM_OR(&sbits[(pos[k * stride] - 1u) >> 5], a);       // a != 0: at least one bit since the last flush
@@ -464,20 +474,41 @@ BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32
   u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
   u32 next = sb[sg + 1];
   Piece cur = loadPiece(sbits, p0 >> 7);
-  for (u32 wp = p0; wp < p1; wp += 32u) {          // p0 is a multiple of 32 = kSample
-    const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
-    u32 word = pieceWord(cur, (wp >> 5) & 3u);
-    if (((wp >> 5) & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
-    if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
-      samples[wp / kSample] = (unsigned short)x;
-      if (hi - wp == 32u && ((word == 0u && ((x - floor) >> d) == 0u) || (word == 0xFFFFFFFFu && (((4096u - floor) - x) >> d) == 0u))) continue;
-      for (u32 p = wp; p < hi; ++p, word >>= 1) x = moved(x, word & 1u, floor, d);
-    } else {
-      for (u32 p = wp; p < hi; ++p, word >>= 1) {
-        while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
-        if (p == wp) samples[wp / kSample] = (unsigned short)x;
-        x = moved(x, word & 1u, floor, d);
+  // eight words = eight samples = one 16-byte store (a 2-byte store per sample cost a sector each)
+  for (u32 gp = p0; gp < p1; gp += 256u) {
+    u32 sm[4] = {0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (u32 wk = 0; wk < 8; ++wk) {
+      const u32 wp = gp + wk * 32u;
+      if (wp >= p1) break;
+      const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
+      u32 word = pieceWord(cur, wk & 3u);
+      if ((wk & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
+      u32 sample;
+      if (next >= hi || sg + 1u >= ns) {           // no chain starts inside this word
+        sample = x;
+        if (!(hi - wp == 32u && ((word == 0u && ((x - floor) >> d) == 0u) || (word == 0xFFFFFFFFu && (((4096u - floor) - x) >> d) == 0u))))
+          for (u32 p = wp; p < hi; ++p, word >>= 1) x = moved(x, word & 1u, floor, d);
+      } else {
+        sample = x;
+        for (u32 p = wp; p < hi; ++p, word >>= 1) {
+          while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
+          if (p == wp) sample = x;
+          x = moved(x, word & 1u, floor, d);
+        }
       }
+      sm[wk >> 1] |= sample << ((wk & 1u) * 16u);
+    }
+    if (gp + 256u <= p1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      *reinterpret_cast<uint4*>(samples + gp / kSample) = make_uint4(sm[0], sm[1], sm[2], sm[3]);
+#else
+      for (u32 wk = 0; wk < 8; ++wk) samples[gp / kSample + wk] = (unsigned short)(sm[wk >> 1] >> ((wk & 1u) * 16u));
+#endif
+    } else {
+      for (u32 wk = 0; wk < 8 && gp + wk * 32u < p1; ++wk) samples[gp / kSample + wk] = (unsigned short)(sm[wk >> 1] >> ((wk & 1u) * 16u));
     }
   }
 }
