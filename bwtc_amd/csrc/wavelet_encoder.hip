@@ -213,6 +213,7 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   if (job.w) {
     // modelled on the device: the copy has landed (above); the passes report themselves
     const u32 n_coded = job.coded_pos.empty() ? 0u : job.coded_pos.back();
+    if (std::getenv("BWTC_HIP_TEST_MODELS_FALLBACK")) job.h_tail[1] |= 0x80u;    // tests: pretend the passes flagged the block
     const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[3] == 0 && job.h_tail[0] < 8 && job.gm_state_in == state_in &&
                     e.wavelet_model == 'B';
     if (ok) {

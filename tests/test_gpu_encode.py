@@ -290,7 +290,7 @@ def test_wavelet_other_model_letters_on_the_device_route(hip_ctx, oracle):
         hip_ctx.wavelet_reset()
 
 
-@pytest.mark.parametrize("models", ["device", "host"])
+@pytest.mark.parametrize("models", ["device", "host", "fallback"])
 def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(models, oracle, monkeypatch):
     """The adaptive models run on the GPU (wavelet_gpu_models.hip: state scan, slot space, bracketed
     chains; the host only range-codes) or on the worker threads (BWTC_HIP_MODELS=host): either way
@@ -300,6 +300,10 @@ def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(mod
     if models == "host":
         monkeypatch.setenv("BWTC_HIP_MODELS", "host")
         monkeypatch.setenv("BWTC_HIP_DENSE_STEP_KEYS", "1")      # and the opt-in dense sort ids of the steps
+    elif models == "fallback":
+        # the device passes run, then every block is treated as flagged: its models are redone on the
+        # worker threads from the packed streams (the route that keeps a surprise from costing bytes)
+        monkeypatch.setenv("BWTC_HIP_TEST_MODELS_FALLBACK", "1")
     else:
         monkeypatch.setenv("BWTC_HIP_SCAN", "chained")
     rng = np.random.default_rng(31)
