@@ -250,10 +250,12 @@ constexpr u8 kWtSkip = 0xFF;
 
 // sorted order: what encodeTreeBF does with the bit -> code[j] = bit | gap << 1, or kWtSkip;
 // coded elements per tile -> tile_count; first element of every group -> group_start
+template <bool DENSE>
 __device__ __forceinline__ u32 wt_group_of(u32 k, const u32* __restrict__ id_group) {
-  return id_group ? id_group[k >> kStepLeafShift] : (k >> kStepGroupShift) & kStepGroupMask;
+  return DENSE ? id_group[k >> kStepLeafShift] : (k >> kStepGroupShift) & kStepGroupMask;
 }
 
+template <bool DENSE>
 __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ key, u32 n,
                                                       const u8* __restrict__ group_type, const u32* __restrict__ id_group,
                                                       u8* __restrict__ code,
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
   }
   u32 grp[kWtE], grp_prev[kWtE];
 #pragma unroll
-  for (int e = 0; e < kWtE; ++e) { grp[e] = wt_group_of(k[e], id_group); grp_prev[e] = wt_group_of(kp[e], id_group); }   // k = 0 past the end: id / group 0 exists
+  for (int e = 0; e < kWtE; ++e) { grp[e] = wt_group_of<DENSE>(k[e], id_group); grp_prev[e] = wt_group_of<DENSE>(kp[e], id_group); }   // k = 0 past the end: id / group 0 exists
   u8 type[kWtE];
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) type[e] = group_type[grp[e]];
@@ -500,7 +502,8 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 tiles = ceil_div(n, kWtTile);
   u8* d_code = base + o_code;
   u32* d_tile = ptr32(o_tile);
-  hipLaunchKernelGGL(k_wt_select, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
+  if (dense_ids) hipLaunchKernelGGL(k_wt_select<true>, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
+  else hipLaunchKernelGGL(k_wt_select<false>, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
   BWTC_HIP_TRY(hipMemsetAsync(d_tile + tiles, 0, 4, st));
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
   hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB / kWave)), dim3(kWtTPB), 0, st, d_gstart,
