@@ -166,7 +166,8 @@ def main():
     # only for streams of 256 blocks and more; everything shorter runs 16 deep.
     mem_per_rank = mem_available_gb() / world_hint
     stream_blocks = max(args.warmup, 16) + args.steps
-    deep = stream_blocks >= 256 and has_avx512()
+    # (deep pipelines are for the host-model routes; with the models on the GPU 16 blocks are enough)
+    deep = stream_blocks >= 256 and has_avx512() and os.environ.get("BWTC_HIP_MODELS") == "host"
     auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
