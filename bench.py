@@ -247,6 +247,13 @@ def main():
     fill_blocks = max(args.warmup, depth if coder == "B" else 0)
     for _ in range(fill_blocks):
         step()                                           # nothing is collected here: the pipeline fills
+    # ... and runs until it is in its steady state (full steps: one block begun, one record
+    # collected): a stream's first seconds -- page-locked buffers being made, lanes filling with the
+    # sections of several blocks -- are its start-up, reported in fill_ms and in the closed loop
+    settle = 2 * depth if coder == "B" else 0
+    for _ in range(settle):
+        step()
+    fill_blocks += settle
     fill_ms = 1e3 * (time.perf_counter() - t0)
     ctx.reset_kernel_timers()
     clock["gpu_s"] = clock["collect_s"] = 0.0

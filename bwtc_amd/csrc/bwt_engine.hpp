@@ -102,7 +102,7 @@ class PinnedPool {
   }
   // the caller allocated one itself (counts against the limit of the helper)
   void noteAllocated() { std::lock_guard<std::mutex> g(mu_); ++made_; }
-  // from now on keep up to two spare buffers of `bytes` ready, `limit` buffers in all
+  // from now on keep up to four spare buffers of `bytes` ready, `limit` buffers in all
   void allocateAhead(int device, size_t bytes, unsigned limit) {
     std::lock_guard<std::mutex> g(mu_);
     if (running_ || bytes == 0) return;
@@ -111,7 +111,7 @@ class PinnedPool {
       (void)hipSetDevice(device);
       std::unique_lock<std::mutex> l(mu_);
       while (!quit_ && made_ < limit) {
-        if (free_.size() >= 2) { cv_.wait(l); continue; }
+        if (free_.size() >= 4) { cv_.wait(l); continue; }
         l.unlock();
         std::unique_ptr<PinnedBytes> b(new PinnedBytes());
         const bool ok = b->reserve(bytes);

@@ -80,7 +80,7 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
       const size_t had = job.w_owner.size();
       if (!job.w_owner.reserve(w_bytes + 64)) return -2;
       if (!w_recycled || job.w_owner.size() != had) e.w_pool.noteAllocated();
-      if (e.jobs.size() >= 2) {                       // blocks overlap: the next ones' buffers are made ahead, off this thread
+      if (e.max_inflight > 2) {                       // a pipelined context: the next blocks' buffers are made ahead, off this thread
         e.w_pool.allocateAhead(e.device, (size_t)(w_bytes + w_bytes / 64 + 64), e.max_inflight + 1);
         e.codes_pool.allocateAhead(e.device, job.codes_owner.size(), e.max_inflight + 1);
       }
