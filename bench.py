@@ -173,6 +173,8 @@ def main():
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
     threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits
+    if os.environ.get("BWTC_BENCH_THREADS"):
+        threads = max(1, int(os.environ["BWTC_BENCH_THREADS"]))
     ctx = hip.Context(gpu, size)
     # Each rank's workers, the thread that feeds its GPU and (by first touch) the page-locked
     # buffers they share stay on the NUMA node of the rank's GPU, on CPUs no other rank uses.

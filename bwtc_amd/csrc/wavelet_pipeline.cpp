@@ -60,7 +60,9 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   // the block's longest section(s) get a scalar task each (they set the block's latency; queue()
   // says which), the others share the lanes with the sections of the blocks behind them (a third of
   // the scalar loop's host time per element).
-  max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P + 3) / 4)) : 0u;
+  // (engines: the lanes cost 0.25 core-seconds per text block, the scalar chain 0.47; measured with 16
+  // threads and 51 ms of GPU per block: 2 engines 91 ms per block, 4 just short, 6 and 8 keep up)
+  max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P * 3 + 7) / 8)) : 0u;
   if (std::getenv("BWTC_HIP_W_ENGINES") && std::atoi(std::getenv("BWTC_HIP_W_ENGINES")) == 0) max_w_engines_ = 0;
   w_long_chain_ = static_cast<uint64_t>(envNumber("BWTC_HIP_W_LONG_MI", 8)) << 20;
   if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) w_long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests
