@@ -125,7 +125,55 @@ def cpu_baseline(size_mib, seed, coder, runs):
     }
 
 
+def _cpu_c4_worker(cpu, size_mib, seed, coder):
+    """One of the pinned single-thread runs of cpu_baseline_c4 (a process of its own: bench.py
+    --cpu-c4-worker cpu size seed coder): its own block, its own core; prints seconds and the kind."""
+    os.sched_setaffinity(0, {cpu})
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from bwtc_amd import hip
+    d = hip.synth_into("t", seed, np.empty(size_mib << 20, np.uint8))
+    use_ref = oracle_lib.ref() is not None
+    t0 = time.perf_counter()
+    bwt, lf, fr = (oracle_lib.ref_bwt_block if use_ref else oracle_lib.oracle_bwt_block)(d, 8)
+    if coder == "H":
+        oracle_lib.oracle_huffman_encode_block(bwt, lf, fr)
+    elif coder == "B":
+        oracle_lib.oracle_wavelet_encode_block(bwt, lf, fr)
+    print("%.4f %s" % (time.perf_counter() - t0, "reference" if use_ref else "port"), flush=True)
+
+
+def cpu_baseline_c4(size_mib, coder, cpus, n=8):
+    """SURVEY.md 8(d), the CPU analogue of one block per GPU: n independent single-thread runs of the
+    CPU path, each on its own block (C4 seeds 30...) and pinned to its own core, at the same time."""
+    import subprocess
+    cpus = sorted(cpus)[:n]
+    if len(cpus) < n:
+        return {"error": "only %d CPUs usable, %d needed" % (len(cpus), n)}
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-c4-worker", str(cpus[i]), str(size_mib),
+                               str(30 + i), coder or "-"], stdout=subprocess.PIPE, text=True) for i in range(n)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+            sec, kind = out.split()[-2:]
+            res.append((float(sec), kind))
+        except (subprocess.TimeoutExpired, ValueError):
+            p.kill()
+            return {"error": "a CPU run did not finish"}
+    wall = time.perf_counter() - t0
+    mb = n * (size_mib << 20) / 1e6
+    return {"value": round(mb / max(r[0] for r in res), 3), "unit": "MB/s", "cores": n, "kind": res[0][1],
+            "per_run_s": [round(r[0], 2) for r in res], "wall_s": round(wall, 2),
+            "sample": "%d blocks of %d MiB (C4 seeds 30..%d), one single-thread run each, pinned to CPUs %s, all at once; "
+                      "value = all their bytes / the slowest run" % (n, size_mib, 30 + n - 1, _ranges(cpus))}
+
+
 def main():
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-c4-worker":
+        _cpu_c4_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -142,6 +190,8 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-c4", action="store_true",
+                    help="also time 8 pinned single-thread CPU runs at once (the CPU analogue of the 8-GPU row): cpu_baseline_c4")
     ap.add_argument("--corpus-blocks", type=int, default=16,
                     help="BWTC_CORPUS=<file>: how many blocks of --size-mib of it are coded (reported as `corpus`)")
     args = ap.parse_args()
@@ -456,6 +506,8 @@ def main():
                               "to keep up with the device half" % threads)
         if corpus is not None:
             out["corpus"] = corpus
+        if args.cpu_c4 and world == 1:
+            out["cpu_baseline_c4"] = cpu_baseline_c4(args.cpu_size_mib or args.size_mib, coder or "", my_cpus or sorted(os.sched_getaffinity(0)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size_mib or args.size_mib, seeds[0], coder or "", args.cpu_runs)
         print(json.dumps(out), flush=True)
