@@ -122,11 +122,12 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_partition(const u32* __restrict__
 }
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_bracket(const u32* __restrict__ sbits, const u32* __restrict__ sb, u32 ns, u32 nt,
-                                                       u32 total, u32 nsc, gm::SlotMap* __restrict__ smap, u32* __restrict__ err) {
+                                                       u32 total, u32 nsc, gm::SlotMap* __restrict__ smap,
+                                                       gm::SlotMap* __restrict__ snaps, u32* __restrict__ err) {
   const u32 j = blockIdx.x * kGmTPB + threadIdx.x;
   if (j >= nsc) return;
   u32 e = 0;
-  smap[j] = gm::laneBracket(sbits, sb, ns, nt, total, j, &e);
+  smap[j] = gm::laneBracket(sbits, sb, ns, nt, total, j, snaps, &e);
   if (e) atomicOr(err, e);
 }
 
@@ -161,27 +162,23 @@ __global__ __launch_bounds__(64) void k_gm_chain_fill(const gm::SlotMap* __restr
   if (e) atomicOr(err, e);
 }
 
-__global__ __launch_bounds__(kGmTPB) void k_gm_samples(const u32* __restrict__ sbits, const u32* __restrict__ sb, u32 ns, u32 nt,
-                                                       u32 total, u32 nsc, const unsigned short* __restrict__ sstart,
-                                                       unsigned short* __restrict__ samples) {
-  const u32 j = blockIdx.x * kGmTPB + threadIdx.x;
-  if (j >= nsc) return;
-  gm::laneSamples(sbits, sb, ns, nt, total, j, sstart, samples);
-}
-
 __global__ __launch_bounds__(kGmTPB) void k_gm_emit(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
                                                     const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
                                                     const u32* __restrict__ base, const u32* __restrict__ sb,
-                                                    const u32* __restrict__ sbits, const unsigned short* __restrict__ samples,
-                                                    const u32* __restrict__ order, u32 nc, u32 nt, unsigned short* __restrict__ out) {
+                                                    const u32* __restrict__ sbits, const gm::SlotMap* __restrict__ snaps,
+                                                    const gm::SlotMap* __restrict__ smap, const unsigned short* __restrict__ sstart,
+                                                    const u32* __restrict__ order, u32 nc, u32 nt, unsigned short* __restrict__ out,
+                                                    u32* __restrict__ err) {
   __shared__ u32 q[gm::kSlotStride][kGmTPB];
   const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
   if (gid >= nc) return;
   const u32 c = order[gid];
   const gm::Chunk ch = chunks[c];
   const u32 t = ch.task_first & 0x7FFFFFFFu;
-  gm::laneEmit(packed, ch.begin, ch.end, tasks[t].type, cstate[c], t, c, nc, nt, base, sb, sbits, samples,
-               &q[0][threadIdx.x], kGmTPB, out);
+  u32 e = 0;
+  gm::laneEmit(packed, ch.begin, ch.end, tasks[t].type, cstate[c], t, c, nc, nt, base, sb, sbits, snaps, smap, sstart,
+               &q[0][threadIdx.x], kGmTPB, out, &e);
+  if (e) atomicOr(err, e);
 }
 
 static inline u64 gm_align(u64 v) { return (v + 255) / 256 * 256; }
@@ -246,7 +243,7 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   const u64 o_sstart = take(((u64)nsc + 1) * 2);
   const u32 gsize = gm::chainGroupSize(nsc), ng = ceil_div(nsc, gsize);
   const u64 o_gmap = take((u64)ng * 64), o_gL = take((u64)ng * 2), o_tg = take((u64)ng * 2);
-  const u64 o_samples = take(((u64)n_coded / gm::kSample + 2) * 2);
+  const u64 o_snaps = take(((u64)n_coded / gm::kSample + 4) * sizeof(gm::SlotMap));
   const u64 o_tail = take(16);
   int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
   if (rc) return rc;
@@ -275,7 +272,7 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   u32* d_sbits = reinterpret_cast<u32*>(base + o_sbits);
   gm::SlotMap* d_smap = reinterpret_cast<gm::SlotMap*>(base + o_smap);
   unsigned short* d_sstart = reinterpret_cast<unsigned short*>(base + o_sstart);
-  unsigned short* d_samples = reinterpret_cast<unsigned short*>(base + o_samples);
+  gm::SlotMap* d_snaps = reinterpret_cast<gm::SlotMap*>(base + o_snaps);
   u32* d_tail = reinterpret_cast<u32*>(base + o_tail);              // [0] state after the block, [1] error flags
   unsigned short* d_w = static_cast<unsigned short*>(e.d_gm_w);
 
@@ -291,16 +288,15 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   exclusive_scan_u32(d_base, n_base, reinterpret_cast<u32*>(base + o_partial), st);
   hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
   hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
-  hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_snaps, d_tail + 1);
   unsigned short* d_gmap = reinterpret_cast<unsigned short*>(base + o_gmap);
   unsigned short* d_gL = reinterpret_cast<unsigned short*>(base + o_gL);
   unsigned short* d_tg = reinterpret_cast<unsigned short*>(base + o_tg);
   hipLaunchKernelGGL(k_gm_chain_group, dim3(ng), dim3(64), 0, st, d_smap, nsc, gsize, d_gmap, d_gL);
   hipLaunchKernelGGL(k_gm_chain_top, dim3(1), dim3(1024), 0, st, d_gmap, d_gL, ng, d_tg, d_tail + 1);
   hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(ng, 64)), dim3(64), 0, st, d_smap, nsc, gsize, ng, d_tg, d_sstart, d_tail + 1);
-  hipLaunchKernelGGL(k_gm_samples, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_sstart, d_samples);
-  hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_samples,
-                     d_order, nc, nt, d_w);
+  hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_snaps, d_smap,
+                     d_sstart, d_order, nc, nt, d_w, d_tail + 1);
   // total of the scan = every element counted once (else the tables do not describe the streams)
   BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + n_base - 1, 4, hipMemcpyDeviceToDevice, st));
   if (e.scan_chain.err) BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 3, e.scan_chain.err, 4, hipMemcpyDeviceToDevice, st));   // a timed-out scan

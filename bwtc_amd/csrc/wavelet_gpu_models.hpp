@@ -22,9 +22,10 @@
 // neighbouring candidates -- the pair (v, v+1) with (bound - v) = 0 mod 2^d -- so the whole map
 // "value at the chunk's start -> value at its end" is carried as (image of the lowest candidate,
 // bit mask of the surviving increments): O(1) per step.  A short serial walk over a chain's
-// chunks (one table look-up each) then gives every slot-chunk its TRUE start value, a second
-// pass over slot space leaves the true value at every 32nd position, and the last pass walks
-// the elements in coding order with exact predictors and writes, per element,
+// chunks (one table look-up each) then gives every slot-chunk its TRUE start value; the bracket
+// pass has also left the bracket as it stood at every 32nd position, which that start value
+// resolves to the true value there; and the last pass walks the elements in coding order with
+// exact predictors (each started from the nearest such position) and writes, per element,
 //     w = bit << 15 | probability of the coded bit (12 bits),
 // which is all the range coder needs (wavelet_rc.hpp, runChainW).  Nothing is approximated: the
 // bytes are those of the sequential encoder, and an input the scheme cannot bracket raises an
@@ -51,7 +52,7 @@ typedef uint64_t u64;
 constexpr u32 kChunk = 2048;       // elements per chunk: tasks cut along an aligned grid of the packed stream
 constexpr u32 kSlotChunk = 2048;   // slot-space positions per slot-chunk
 constexpr u32 kWarm = 256;         // updates from the extreme values before a slot-chunk (bracket < 2^d after ~175)
-constexpr u32 kSample = 32;        // true values are kept at every kSample-th slot-space position
+constexpr u32 kSample = 32;        // the bracket is kept at every kSample-th slot-space position
 constexpr u32 kSlots = 15;
 constexpr u32 kSlotStride = 16;    // rows of the per-lane slot tables
 enum TaskType { kTRoot = 0, kTGaps = 1, kTInner = 2, kTInts = 3 };
@@ -383,7 +384,11 @@ BWTC_GM_HD void bracketStep(u32& x0, u32& mask, u32 bit, u32 floor, u32 d) {
 struct SlotMap { u32 lo_x0; u32 mask; };           // lo_x0 = bracket base L | x0 at the chunk's end << 16
 
 // pass 4: slot-chunk j = positions [j * kSlotChunk, ...): its map from start value to end value
-BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j, u32* err) {
+// Also leaves, at every kSample-th position, the bracket as it stands there: snaps[p / kSample] =
+// {image of the lowest candidate, mask}.  With the chunk's true start value t (pass 5) the true
+// value at that position is  x0 + popcount(mask & ((1 << (t - L)) - 1))  -- no second walk over slot
+// space is needed for the values the last pass starts from.
+BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j, SlotMap* snaps, u32* err) {
   const u32 p0 = j * kSlotChunk, p1 = p0 + kSlotChunk < total ? p0 + kSlotChunk : total;
   u32 sg = streamAt(sb, ns, p0);
   u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
@@ -402,24 +407,44 @@ BWTC_GM_HD SlotMap laneBracket(const u32* sbits, const u32* sb, u32 ns, u32 nt, 
   }
   u32 next = sb[sg + 1];
   Piece cur = loadPiece(sbits, p0 >> 7);           // p0 is a multiple of 128: four words per load, the next one under way
-  for (u32 wp = p0; wp < p1; wp += 32u) {
-    const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
-    u32 word = pieceWord(cur, (wp >> 5) & 3u);
-    if (((wp >> 5) & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
-    if (next >= hi || sg + 1u >= ns) {             // no chain starts inside this word
-      // equal bits that move no candidate any more: nothing to do for the whole word
-      if (hi - wp == 32u && ((word == 0u && ((x0 + popc(mask) - floor) >> d) == 0u) ||
-                             (word == 0xFFFFFFFFu && (((4096u - floor) - x0) >> d) == 0u))) continue;
-      for (u32 p = wp; p < hi; ++p, word >>= 1) bracketStep(x0, mask, word & 1u, floor, d);
-    } else {
-      for (u32 p = wp; p < hi; ++p, word >>= 1) {
-        while (p >= next && sg + 1u < ns) {        // another chain starts here: fresh predictor, known exactly
-          ++sg; next = sb[sg + 1];
-          k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
-          x0 = slotInit(k); mask = 0;
+  for (u32 gp = p0; gp < p1; gp += 64u) {          // two words = two snapshots = one 16-byte store
+    SlotMap sn[2] = {SlotMap{0, 0}, SlotMap{0, 0}};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (u32 wk = 0; wk < 2; ++wk) {
+      const u32 wp = gp + wk * 32u;
+      if (wp >= p1) break;
+      const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
+      u32 word = pieceWord(cur, (wp >> 5) & 3u);
+      if (((wp >> 5) & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
+      if (next >= hi || sg + 1u >= ns) {           // no chain starts inside this word
+        sn[wk] = SlotMap{x0, mask};
+        // equal bits that move no candidate any more: nothing to do for the whole word
+        if (!(hi - wp == 32u && ((word == 0u && ((x0 + popc(mask) - floor) >> d) == 0u) ||
+                                 (word == 0xFFFFFFFFu && (((4096u - floor) - x0) >> d) == 0u))))
+          for (u32 p = wp; p < hi; ++p, word >>= 1) bracketStep(x0, mask, word & 1u, floor, d);
+      } else {
+        for (u32 p = wp; p < hi; ++p, word >>= 1) {
+          while (p >= next && sg + 1u < ns) {      // another chain starts here: fresh predictor, known exactly
+            ++sg; next = sb[sg + 1];
+            k = sg / nt; floor = slotFloor(k); d = slotDelay(k);
+            x0 = slotInit(k); mask = 0;
+          }
+          if (p == wp) sn[wk] = SlotMap{x0, mask};
+          bracketStep(x0, mask, word & 1u, floor, d);
         }
-        bracketStep(x0, mask, word & 1u, floor, d);
       }
+    }
+    if (gp + 64u <= p1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      *reinterpret_cast<uint4*>(snaps + gp / kSample) = make_uint4(sn[0].lo_x0, sn[0].mask, sn[1].lo_x0, sn[1].mask);
+#else
+      snaps[gp / kSample] = sn[0]; snaps[gp / kSample + 1] = sn[1];
+#endif
+    } else {
+      snaps[gp / kSample] = sn[0];
+      if (gp + 32u < p1) snaps[gp / kSample + 1] = sn[1];
     }
   }
   return SlotMap{L | (x0 << 16), mask};
@@ -461,56 +486,6 @@ BWTC_GM_HD void laneChainFill(const SlotMap* smap, u32 nsc, u32 gsize, u32 g, co
   const u32 j0 = g * gsize, j1 = j0 + gsize < nsc ? j0 + gsize : nsc;
   u32 t = tg[g];
   for (u32 j = j0; j < j1; ++j) { sstart[j] = (unsigned short)t; t = slotMapApply(smap[j], t, err); }
-}
-
-// pass 6: slot-chunk j again, from its true start value: the value at every kSample-th position.
-// A word of equal bits under a predictor that those bits no longer move (the common case once a
-// node's bits are predictable) is skipped whole.
-BWTC_GM_HD void laneSamples(const u32* sbits, const u32* sb, u32 ns, u32 nt, u32 total, u32 j,
-                            const unsigned short* sstart, unsigned short* samples) {
-  const u32 p0 = j * kSlotChunk, p1 = p0 + kSlotChunk < total ? p0 + kSlotChunk : total;
-  u32 sg = streamAt(sb, ns, p0);
-  u32 k = sg / nt, floor = slotFloor(k), d = slotDelay(k);
-  u32 x = sb[sg] == p0 ? slotInit(k) : (u32)sstart[j];
-  u32 next = sb[sg + 1];
-  Piece cur = loadPiece(sbits, p0 >> 7);
-  // eight words = eight samples = one 16-byte store (a 2-byte store per sample cost a sector each)
-  for (u32 gp = p0; gp < p1; gp += 256u) {
-    u32 sm[4] = {0, 0, 0, 0};
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (u32 wk = 0; wk < 8; ++wk) {
-      const u32 wp = gp + wk * 32u;
-      if (wp >= p1) break;
-      const u32 hi = wp + 32u < p1 ? wp + 32u : p1;
-      u32 word = pieceWord(cur, wk & 3u);
-      if ((wk & 3u) == 3u) cur = loadPiece(sbits, (wp >> 7) + 1u);
-      u32 sample;
-      if (next >= hi || sg + 1u >= ns) {           // no chain starts inside this word
-        sample = x;
-        if (!(hi - wp == 32u && ((word == 0u && ((x - floor) >> d) == 0u) || (word == 0xFFFFFFFFu && (((4096u - floor) - x) >> d) == 0u))))
-          for (u32 p = wp; p < hi; ++p, word >>= 1) x = moved(x, word & 1u, floor, d);
-      } else {
-        sample = x;
-        for (u32 p = wp; p < hi; ++p, word >>= 1) {
-          while (p >= next && sg + 1u < ns) { ++sg; next = sb[sg + 1]; k = sg / nt; floor = slotFloor(k); d = slotDelay(k); x = slotInit(k); }
-          if (p == wp) sample = x;
-          x = moved(x, word & 1u, floor, d);
-        }
-      }
-      sm[wk >> 1] |= sample << ((wk & 1u) * 16u);
-    }
-    if (gp + 256u <= p1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      *reinterpret_cast<uint4*>(samples + gp / kSample) = make_uint4(sm[0], sm[1], sm[2], sm[3]);
-#else
-      for (u32 wk = 0; wk < 8; ++wk) samples[gp / kSample + wk] = (unsigned short)(sm[wk >> 1] >> ((wk & 1u) * 16u));
-#endif
-    } else {
-      for (u32 wk = 0; wk < 8 && gp + wk * 32u < p1; ++wk) samples[gp / kSample + wk] = (unsigned short)(sm[wk >> 1] >> ((wk & 1u) * 16u));
-    }
-  }
 }
 
 // pass 7: the elements of a chunk in coding order with exact predictors.  q: table row k = slot k.
@@ -566,8 +541,8 @@ BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32*
   }
 }
 BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32 task, u32 chunk, u32 nc, u32 nt,
-                         const u32* base, const u32* sb, const u32* sbits, const unsigned short* samples,
-                         u32* q, u32 stride, unsigned short* out) {
+                         const u32* base, const u32* sb, const u32* sbits, const SlotMap* snaps, const SlotMap* smap,
+                         const unsigned short* sstart, u32* q, u32 stride, unsigned short* out, u32* err) {
   const u32 k_lo = type == kTGaps ? 8u : type == kTInts ? 12u : 0u;
   const u32 k_hi = type == kTRoot ? 8u : type == kTInts ? 15u : 12u;
   for (u32 k = k_lo; k < k_hi; ++k) {
@@ -575,7 +550,13 @@ BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 st
     const u32 floor = slotFloor(k), d = slotDelay(k);
     const u32 a0 = P & ~(kSample - 1u);
     u32 a, x;
-    if (a0 > s0) { a = a0; x = samples[a0 / kSample]; } else { a = s0; x = slotInit(k); }
+    if (a0 > s0) {                                 // the bracket as it stood at a0, resolved with its slot-chunk's true start value
+      const u32 jc = a0 / kSlotChunk;
+      const SlotMap sn = snaps[a0 / kSample];
+      const u32 off = (u32)sstart[jc] - (smap[jc].lo_x0 & 0xFFFFu);
+      if (off > 31u && sn.mask) *err |= kErrChain;
+      a = a0; x = sn.lo_x0 + popc(sn.mask & ((1u << (off > 31u ? 31u : off)) - 1u));
+    } else { a = s0; x = slotInit(k); }
     forBits(sbits, a, P, [&](u32, u32 b) { x = moved(x, b, floor, d); });
     q[k * stride] = x;
   }

@@ -99,8 +99,8 @@ bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& ta
   }
   // passes 4-6
   const u32 nsc = (total + kSlotChunk - 1) / kSlotChunk;
-  std::vector<SlotMap> smap(nsc);
-  for (u32 j = 0; j < nsc; ++j) smap[j] = laneBracket(sbits.data(), sb.data(), ns, nt, total, j, &err);
+  std::vector<SlotMap> smap(nsc), snaps(total / kSample + 4);
+  for (u32 j = 0; j < nsc; ++j) smap[j] = laneBracket(sbits.data(), sb.data(), ns, nt, total, j, snaps.data(), &err);
   if (err) return false;
   if (std::getenv("BWTC_HIP_DEBUG")) {
     u32 open_end = 0, far = 0;
@@ -120,16 +120,14 @@ bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& ta
     for (u32 g = 0; g < ng; ++g) laneChainFill(smap.data(), nsc, gsize, g, tg.data(), sstart.data(), &err);
   }
   if (err) return false;
-  std::vector<unsigned short> samples(total / kSample + 2, 0);
-  for (u32 j = 0; j < nsc; ++j) laneSamples(sbits.data(), sb.data(), ns, nt, total, j, sstart.data(), samples.data());
   // pass 7
   u32 q[kSlotStride];
   for (u32 c = 0; c < nc; ++c) {
     const u32 t = chunks[c].task_first & 0x7FFFFFFFu;
     laneEmit(packed, chunks[c].begin, chunks[c].end, tasks[t].type, cstate[c], t, c, nc, nt, base.data(), sb.data(), sbits.data(),
-             samples.data(), q, 1, out);
+             snaps.data(), smap.data(), sstart.data(), q, 1, out, &err);
   }
-  return true;
+  return err == 0;
 }
 
 }  // namespace gm
