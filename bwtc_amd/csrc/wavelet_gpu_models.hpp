@@ -232,69 +232,69 @@ BWTC_GM_HD u64 laneMapT(const u32* packed, u32 begin, u32 end) {
   m |= (u64)i0 << 32; m |= (u64)i1 << 34; m |= (u64)i2 << 36;
   return m;
 }
-// The same map from the chunk's TAIL, read backwards until it decides:
+// The same map from the chunk's TAIL alone, where that is enough (nearly always):
 //   main      four advancing elements fix the state whatever it was -- a change of bit value among
 //             them does, and so do four equal bits (FSM.hpp:42-67 saturates after four steps);
 //   gaps      the state is (last bit, bit before it) of the gap-coded elements;
-//   integers  two equal bits in a row fix the saturating counter at 0 or 2, and the bits after the
-//             LATEST such pair alternate, which only moves it between the end and the middle.
-// The backward walk stops as soon as every machine the chunk's type touches is decided -- after 4
-// elements for a root, a few more for an inner node (two gap-coded ones), the distance to the last
-// repeated bit for an integer level.  Only a chunk that never decides (fewer than four elements,
-// fewer than two gaps, strictly alternating integer bits) takes the forward walk with all images.
+//   integers  two equal bits in a row fix the saturating counter; what follows is replayed.
+// Falls back to the full walk when the tail does not decide (short chunks, an INNER chunk with
+// fewer than two gap-coded elements in its last 32, integer bits that alternate over 64 elements).
 BWTC_GM_HD u64 laneMap(const u32* packed, u32 begin, u32 end, u32 type) {
   const u32 n = end - begin;
-  const bool adv = type == kTRoot || type == kTInner;
-  const bool gaps = type == kTGaps || type == kTInner;
-  u32 seen = 0;                                    // elements read so far (from the end)
-  u32 last4 = 0;                                   // main: bit e = the (e+1)-th last element's bit, e < 4
-  u32 gk = 0, g1 = 0, g2 = 0;                      // gaps: flagged elements met (capped at 2), last and last-but-one bit
-  u32 prev = 0, after = 0, pair_bit = 0;           // integers: the element read before (= the one after), elements after the pair
-  bool pair = false;
-  bool done = n == 0;
-  u32 i = end;
-  while (!done && i > begin) {
-    const u32 wi = (i - 1u) >> 4;
-    const u32 word = packed[wi];
-    const u32 lo = wi << 4 > begin ? wi << 4 : begin;
-    while (i > lo) {
-      --i;
-      const u32 v = (word >> ((i & 15u) * 2u)) & 3u, bit = v & 1u, flag = v >> 1;
-      if (seen < 4u) last4 |= bit << seen;
-      if ((type == kTGaps || flag) && gk < 2u) { if (gk == 0) g1 = bit; else g2 = bit; ++gk; }
-      if (type == kTInts && !pair) {
-        if (seen > 0 && bit == prev) { pair = true; pair_bit = prev; after = seen - 1u; }   // elements i, i+1 are equal; `after` follow them
-        prev = bit;
+  bool quick = n >= 4;
+  u64 m = 0;
+  if (quick) {
+    const u32 want = type == kTInts ? 64u : type == kTInner ? 32u : 4u;
+    const u32 tail = n < want ? n : want;          // elements end - tail .. end - 1
+    u32 bits = 0, flags = 0;                       // bit e = element end - 1 - e (the LAST element is bit 0), e < 32
+    u64 bits64 = 0;                                // the same for all 64 (integers)
+    {
+      // the last 64 elements lie in at most five packed words: loaded together, then unpacked
+      const u32 w_hi = (end - 1u) >> 4, w_lo = (end - tail) >> 4;
+      u32 wd[5];
+      for (u32 k = 0; k < 5; ++k) wd[k] = w_hi >= k && w_hi - k >= w_lo ? packed[w_hi - k] : 0u;
+      for (u32 e = 0; e < tail; ++e) {
+        const u32 i = end - 1u - e, k = w_hi - (i >> 4);
+        const u32 word = k == 0 ? wd[0] : k == 1 ? wd[1] : k == 2 ? wd[2] : k == 3 ? wd[3] : wd[4];
+        const u32 v = (word >> ((i & 15u) * 2u)) & 3u;
+        if (e < 32u) { bits |= (v & 1u) << e; flags |= (v >> 1) << e; }
+        bits64 |= (u64)(v & 1u) << e;
       }
-      ++seen;
-      const bool main_ok = !adv || seen >= 4u, gaps_ok = !gaps || gk >= 2u, ints_ok = type != kTInts || pair;
-      if (main_ok && gaps_ok && ints_ok) { done = true; break; }
+    }
+    if (type == kTRoot || type == kTInner) {
+      const u32 b4 = bits & 1u;
+      const u32 x = (bits ^ (0u - b4)) & 15u;      // set where one of the last four bits differs from the last one
+      const u32 r = x & 2u ? 1u : x & 4u ? 2u : x & 8u ? 3u : 4u;
+      const u32 st = r == 4u ? (b4 ? 7u : 0u) : (b4 ? 3u + r : 4u - r);
+      m |= (u64)(st * 0x249249u);                  // the same three bits eight times
+    } else {
+      m |= kMapIdentity & 0xFFFFFFull;
+    }
+    if (type == kTGaps) {
+      m |= (u64)((((bits & 1u) << 1) | ((bits >> 1) & 1u)) * 0x55u) << 24;
+    } else if (type == kTInner) {
+      const u32 f = flags & ((tail >= 32u) ? 0xFFFFFFFFu : ((1u << tail) - 1u));
+      if (popc(f) >= 2u) {
+        const u32 e1 = (u32)__builtin_ctz(f), e2 = (u32)__builtin_ctz(f & (f - 1u));
+        m |= (u64)(((((bits >> e1) & 1u) << 1) | ((bits >> e2) & 1u)) * 0x55u) << 24;
+      } else quick = false;
+    } else {
+      m |= kMapIdentity & (0xFFull << 24);
+    }
+    if (type == kTInts) {
+      const u64 eq = ~(bits64 ^ (bits64 >> 1)) & (tail >= 64u ? ~0ull >> 1 : ((1ull << (tail - 1u)) - 1ull));   // bit e: elements e and e+1 (from the end) are equal
+      if (eq) {
+        const u32 e = (u32)__builtin_ctzll(eq);    // the latest such pair: element end - 1 - e is its second bit
+        u32 st = (bits64 >> e) & 1u ? 2u : 0u;
+        for (u32 k = e; k-- > 0;) st = next3(st, (u32)(bits64 >> k) & 1u);
+        m |= (u64)(st * 0x15u) << 32;
+      } else quick = false;
+    } else {
+      m |= kMapIdentity & (0x3Full << 32);
     }
   }
-  const bool main_ok = !adv || seen >= 4u, gaps_ok = !gaps || gk >= 2u, ints_ok = type != kTInts || pair;
-  if (!(main_ok && gaps_ok && ints_ok)) {
-    u64 m = 0;
-    BWTC_GM_BY_TYPE(type, m = laneMapT<TYPE>(packed, begin, end));
-    return m;
-  }
-  u64 m = 0;
-  if (adv) {
-    const u32 b4 = last4 & 1u;
-    const u32 x = (last4 ^ (0u - b4)) & 15u;      // set where one of the last four bits differs from the last one
-    const u32 r = x & 2u ? 1u : x & 4u ? 2u : x & 8u ? 3u : 4u;
-    const u32 st = r == 4u ? (b4 ? 7u : 0u) : (b4 ? 3u + r : 4u - r);
-    m |= (u64)(st * 0x249249u);                    // the same three bits eight times
-  } else {
-    m |= kMapIdentity & 0xFFFFFFull;
-  }
-  if (gaps) m |= (u64)(((g1 << 1) | g2) * 0x55u) << 24;
-  else m |= kMapIdentity & (0xFFull << 24);
-  if (type == kTInts) {
-    const u32 st = (after & 1u) ? 1u : (pair_bit ? 2u : 0u);
-    m |= (u64)(st * 0x15u) << 32;
-  } else {
-    m |= kMapIdentity & (0x3Full << 32);
-  }
+  if (quick) return m;
+  BWTC_GM_BY_TYPE(type, m = laneMapT<TYPE>(packed, begin, end));
   return m;
 }
 
