@@ -321,6 +321,7 @@ def main():
     elapsed = farm.timed(timed_step, args.steps, 0, None)
     m1, c1, b1 = ctx.wavelet_host_clock()
     f1 = ctx.wavelet_host_progress()[1]
+    block_latency = ctx.wavelet_latency()                # begun -> record finished, mean over the stream so far
     gpu_s, collect_s = clock["gpu_s"], clock["collect_s"]            # of the timed region only
     t0 = time.perf_counter()
     drain()
@@ -492,7 +493,8 @@ def main():
             "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,
-            "depth_needed": int(-(-single_ms // max(step_ms, 1e-3))) if coder == "B" else 1,
+            "block_latency_ms": round(1e3 * block_latency, 1) if coder == "B" else 0.0,
+            "depth_needed": int(-(-(1e3 * block_latency if block_latency else single_ms) // max(step_ms, 1e-3))) if coder == "B" else 1,
             "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,
             "host_model_s_per_block": round((m1 - m0) / blocks_done, 3) if coder == "B" else 0.0,
             "host_coder_s_per_block": round((c1 - c0) / blocks_done, 3) if coder == "B" else 0.0,

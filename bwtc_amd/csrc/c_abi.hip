@@ -417,6 +417,14 @@ int bwtc_hip_wavelet_host_progress(bwtc_hip_ctx* ctx, uint64_t* queued, uint64_t
   return 0;
 }
 
+int bwtc_hip_wavelet_latency(bwtc_hip_ctx* ctx, double* mean_seconds) {
+  if (!ctx || !mean_seconds) return -1;
+  const HostPipeline* p = ctx->eng.pipeline;
+  const uint64_t n = p ? p->clock.finished.load() : 0;
+  *mean_seconds = n ? p->clock.latency_ns.load() * 1e-9 / (double)n : 0.0;
+  return 0;
+}
+
 int bwtc_hip_wavelet_encode_device_begin(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                          const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
                                          uint32_t threads, uint8_t* out, uint64_t out_cap,

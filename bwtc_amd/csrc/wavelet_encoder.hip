@@ -249,6 +249,7 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
   std::shared_ptr<DeviceWaveletJob> jobp(new DeviceWaveletJob());
   DeviceWaveletJob& job = *jobp;
   job.rank = e.next_ticket;
+  job.t_begun = std::chrono::steady_clock::now();
   job.user_out = out;
   job.user_cap = out_cap;
   job.block_size = size;

@@ -93,6 +93,8 @@ void HostPipeline::finishNow(WaveletJob& job) {
 void HostPipeline::finish(WaveletJob& job) {
   --clock.unfinished;
   finishNow(job);
+  if (job.t_begun.time_since_epoch().count())
+    clock.latency_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(job.t_finished - job.t_begun).count());
   ++clock.finished;
 }
 

@@ -33,6 +33,7 @@ namespace bwtc_hip {
 // host time spent in the two stages (summed over threads), for BWTC_HIP_DEBUG
 struct StageClock {
   std::atomic<uint64_t> model_ns{0}, coder_ns{0}, blocks{0}, finished{0};
+  std::atomic<uint64_t> latency_ns{0};             // begun -> record finished, summed over the finished blocks
   std::atomic<int> unfinished{0};      // blocks begun and not yet finished by the workers
 };
 
@@ -226,6 +227,7 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   uint8_t* user_out = nullptr;
   uint64_t user_cap = 0;
   std::chrono::steady_clock::time_point t_queued, t_modelled, t_finished;   // BWTC_HIP_DEBUG timeline
+  std::chrono::steady_clock::time_point t_begun;    // when the block's device half started (set by whoever made the job)
 };
 
 }  // namespace bwtc_hip

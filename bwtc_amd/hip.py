@@ -35,7 +35,7 @@ EXPORTS = [
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
     "bwtc_hip_memcpy_to_host", "bwtc_hip_host_alloc", "bwtc_hip_host_free",
-    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_wavelet_latency", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
@@ -86,6 +86,7 @@ def load():
     L.bwtc_hip_copy_wait.argtypes = [_vp]
     L.bwtc_hip_wavelet_host_clock.argtypes = [_vp, _vp, _vp, _vp]
     L.bwtc_hip_wavelet_host_progress.argtypes = [_vp, _vp, _vp]
+    L.bwtc_hip_wavelet_latency.argtypes = [_vp, _vp]
     L.bwtc_hip_numa_node.argtypes = [_vp]
     L.bwtc_hip_host_cpu_slice.argtypes = [ctypes.c_int, _u32, _u32, _vp, _u32]
     L.bwtc_hip_set_worker_cpus.argtypes = [_vp, _vp, _u32]
@@ -243,6 +244,12 @@ class Context:
         _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
                "bwtc_hip_wavelet_host_clock")
         return m.value, c.value, b.value
+
+    def wavelet_latency(self):
+        """Mean seconds a block has been under way (device half started -> record finished)."""
+        v = ctypes.c_double(0)
+        _check(self.lib.bwtc_hip_wavelet_latency(self.handle, ctypes.byref(v)), "bwtc_hip_wavelet_latency")
+        return v.value
 
     def numa_node(self):
         """NUMA node of the context's GPU, -1 when the system does not say."""

@@ -239,6 +239,10 @@ int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double
  * threads have finished (*finished): what a caller needs to tell the rate the host half sustains
  * from the rate at which blocks are begun. */
 int bwtc_hip_wavelet_host_progress(bwtc_hip_ctx* ctx, uint64_t* queued, uint64_t* finished);
+/* Mean time a block has been under way so far: from the start of its device half (_begin / _prepare)
+ * to its finished record.  Blocks under way needed = that time / the time per block of the caller's
+ * loop; a context keeps the limit it was created with (BWTC_HIP_WAVELET_DEPTH). */
+int bwtc_hip_wavelet_latency(bwtc_hip_ctx* ctx, double* mean_seconds);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 /* A new wavelet stream with the main probability model of coder letter `coder`
  * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,
