@@ -138,6 +138,19 @@ class PinnedPool {
   bool running_ = false, quit_ = false;
 };
 
+// The model passes of one block between their two parts (wavelet_gpu_models.hip): where its tables
+// and intermediates live in the context's workspace.
+struct GmPass {
+  bool ready = false;
+  const u32* d_packed = nullptr;
+  u32 n_coded = 0, nt = 0, nc = 0, ns = 0, nsc = 0, ntiles = 0, gsize = 0, ng = 0;
+  u64 n_base = 0;
+  void *d_tasks = nullptr, *d_chunks = nullptr, *d_order = nullptr, *d_excl = nullptr, *d_tagg = nullptr, *d_tstate = nullptr,
+       *d_cmap = nullptr, *d_cstate = nullptr, *d_base = nullptr, *d_partial = nullptr, *d_sb = nullptr, *d_sbits = nullptr,
+       *d_smap = nullptr, *d_sstart = nullptr, *d_gmap = nullptr, *d_gL = nullptr, *d_tg = nullptr, *d_snaps = nullptr,
+       *d_tail = nullptr;
+};
+
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
 struct WaveletSectionStats;
 struct DeviceWaveletJob : WaveletJob {
@@ -146,6 +159,8 @@ struct DeviceWaveletJob : WaveletJob {
   PinnedBytes w_owner;                 // device-modelled blocks: the w-elements (2 bytes per coded element)
   u32* h_tail = nullptr;               //   {state after the block, error flags, elements counted} (in w_owner, behind the elements)
   u32 gm_state_in = 0;                 //   the carried state the device passes were given
+  GmPass gm;                           // farmed streams: the passes' first part is done, the rest waits for the state (_queue)
+  bool failed = false;                 // the host-callback join could not be made (out of memory): _end reports it
   // between wavelet_encode_prepare and wavelet_encode_queue
   bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
   bool host_route = false;             // coded by encodeSections at queue time instead
@@ -239,6 +254,7 @@ struct BwtEngine {
   int reserve_run_arrays();
   std::shared_ptr<DeviceWaveletJob> half_job;   // scanned + planned, its streams still to be made
   std::shared_ptr<DeviceWaveletJob> copy_job;   // streams made, copy to the host in flight, not queued yet (_begin flow)
+  std::weak_ptr<DeviceWaveletJob> gm_pending;   // _prepare / _queue flow: the job whose model passes wait in the workspace for their state
   bool deferred_queue = false;        // _begin is in use: a begun block joins the stream one or two calls later
   bool async_streams_copy = false;    // set by _begin around its _prepare
   HostPipeline* pipeline = nullptr;   // worker threads, lane engines, coder tasks ('B'; made by the first block)
@@ -339,6 +355,11 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
 // the passes and the copy of the w-elements to h_w, of {state after, error flags, count} to h_tail.
 int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
                           const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail);
+// the same in two parts: what does not depend on the carried state, and the rest (early_state != null:
+// the state after the block is read back, with a short wait, before the long passes are queued)
+int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
+                           const std::vector<u32>& coded_pos, GmPass* g);
+int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_w, u32* h_tail, u32* early_state);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,
 // 112-157, 159-163) for a device-resident transformed block, in two halves so that blocks

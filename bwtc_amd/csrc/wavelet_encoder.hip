@@ -35,7 +35,9 @@ namespace bwtc_hip {
 // the same; a block just joins the host pipeline one call later.
 
 // second part of a block whose first part is done: streams (or the host route), buffers
-static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool async_copy = false) {
+static int wavelet_finish_device_half(BwtEngine& e, const std::shared_ptr<DeviceWaveletJob>& jobp, bool async_copy = false,
+                                      bool farm_prepare = false) {
+  DeviceWaveletJob& job = *jobp;
   if (!job.half) return 0;
   job.half = false;
   if (!job.plan_future.valid()) return 0;                 // empty block: nothing to plan or code
@@ -60,6 +62,9 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
     // the block before the previous one joined while the scanner ran.  (_prepare / _queue callers
     // learn the state at _queue time: their models stay on the worker threads.)
     const bool on_gpu = e.device_models && e.wavelet_model == 'B' && e.deferred_queue;
+    // A stream farmed over contexts (_prepare / _queue) learns the state at _queue time: the passes'
+    // first part (tables, chunk maps, the tiles' state maps) is done now, the rest then.
+    const bool on_gpu_later = e.device_models && e.wavelet_model == 'B' && !e.deferred_queue && farm_prepare;
     if (on_gpu)
       for (std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator o = e.jobs.begin(); o != e.jobs.end() && o->first < job.rank; ++o)
         if (!o->second->queued) { const int rq = wavelet_encode_queue(e, o->first, e.wavelet_state, &e.wavelet_state); if (rq) return rq; }
@@ -73,6 +78,21 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
     if (!e.pipeline) {
       e.pipeline = new HostPipeline(job.host_threads, e.huge_group_elements, e.max_inflight);
       if (!e.worker_cpus.empty()) e.pipeline->setWorkerCpus(e.worker_cpus);
+    }
+    if (on_gpu_later && e.wt_coded) {
+      // (another prepared block's passes may still wait in the workspace: its turn is lost, its models
+      // go to the worker threads)
+      if (std::shared_ptr<DeviceWaveletJob> other = e.gm_pending.lock()) if (!other->queued) other->gm.ready = false;
+      const bool w_recycled = e.w_pool.take(&job.w_owner);
+      const u64 w_bytes = ((u64)e.wt_coded * 2 + 63) / 64 * 64;
+      const size_t had = job.w_owner.size();
+      if (!job.w_owner.reserve(w_bytes + 64)) return -2;
+      if (!w_recycled || job.w_owner.size() != had) e.w_pool.noteAllocated();
+      job.h_tail = reinterpret_cast<u32*>(job.w_owner.data() + w_bytes);
+      job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = job.h_tail[3] = 0xFFFFFFFFu;
+      rc = wavelet_models_prepare(e, d_packed, (u32)e.wt_coded, job.plan, job.coded_pos, &job.gm);
+      if (rc) return rc;
+      e.gm_pending = jobp;
     }
     if (on_gpu && e.wt_coded) {
       const bool w_recycled = e.w_pool.take(&job.w_owner);
@@ -96,8 +116,8 @@ static int wavelet_finish_device_half(BwtEngine& e, DeviceWaveletJob& job, bool 
         std::fprintf(stderr, "wavelet: models of %llu coded elements queued on the device %.2f ms after the streams\n",
                      (unsigned long long)e.wt_coded, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
     }
-    job.fused = !job.w && e.pipeline->fusedNow(e.wavelet_model);
-    if (!job.fused && !job.w) {
+    job.fused = !job.w && !job.gm.ready && e.pipeline->fusedNow(e.wavelet_model);
+    if (!job.fused && !job.w && !job.gm.ready) {
       if (!e.prob_free.empty()) { job.prob.swap(*e.prob_free.back()); e.prob_free.pop_back(); }
       if (!job.prob.reserve(e.wt_coded + 8)) return -2;
     }
@@ -141,7 +161,7 @@ static int wavelet_finish_pending_half(BwtEngine& e, bool async_copy) {
   if (!e.half_job) return 0;
   std::shared_ptr<DeviceWaveletJob> jobp;
   jobp.swap(e.half_job);
-  const int rc = wavelet_finish_device_half(e, *jobp, async_copy);
+  const int rc = wavelet_finish_device_half(e, jobp, async_copy);
   if (rc == 0 && async_copy && jobp->copying) e.copy_job = jobp;
   return rc;
 }
@@ -190,7 +210,7 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   if (job.queued) return -1;
   if (job.half) {                                    // its streams are not made yet: now
     if (e.half_job == jobp) e.half_job.reset();
-    const int rc = wavelet_finish_device_half(e, job);
+    const int rc = wavelet_finish_device_half(e, jobp);
     if (rc) return rc;
   }
   if (job.copying) {                                 // its streams are on their way to the host
@@ -199,6 +219,39 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
     if (e.codes_wait() != hipSuccess) return -3;
   }
   job.queued = true;
+  if (job.gm.ready && job.streams_ready && e.wavelet_model == 'B') {
+    // farmed stream, models on the device: the rest of the passes with the state that has just
+    // arrived; the state after the block comes back after the (short) state scan, the block joins
+    // the host pipeline from a host callback when its w-elements have landed
+    u32 after = state_in;
+    int rc = wavelet_models_run(e, job.gm, state_in, reinterpret_cast<uint16_t*>(job.w_owner.data()), job.h_tail, &after);
+    job.gm.ready = false;
+    if (rc) return rc;
+    job.w = reinterpret_cast<const uint16_t*>(job.w_owner.data());
+    job.gm_state_in = state_in;
+    job.w_end_state = after;
+    *state_out = after;
+    struct Join { std::shared_ptr<DeviceWaveletJob> job; HostPipeline* pipe; u32 state_in; };
+    Join* j = new Join{jobp, e.pipeline, state_in};
+    const hipError_t hrc = hipLaunchHostFunc(e.d2h_stream, [](void* p) {
+      std::unique_ptr<Join> j(static_cast<Join*>(p));
+      DeviceWaveletJob& job = *j->job;
+      const u32 n_coded = job.coded_pos.empty() ? 0u : job.coded_pos.back();
+      const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[3] == 0 && job.h_tail[0] == job.w_end_state &&
+                      !std::getenv("BWTC_HIP_TEST_MODELS_FALLBACK");
+      if (!ok) {                                      // flagged: the worker threads model it from the packed streams
+        job.w = nullptr;
+        if (!job.prob.reserve(static_cast<size_t>(n_coded) + 8)) { job.failed = true; HostPipeline::finishNow(job); return; }
+      }
+      (void)j->pipe->queue(j->job, j->state_in, 'B');
+    }, j);
+    if (hrc != hipSuccess) { delete j; return -3; }
+    return 0;
+  }
+  if (job.streams_ready && !job.w && !job.fused && job.prob.size() < static_cast<size_t>(job.coded_pos.empty() ? 0 : job.coded_pos.back()) + 8) {
+    // a block whose device passes lost their turn (see wavelet_finish_device_half): host models after all
+    if (!job.prob.reserve(static_cast<size_t>(job.coded_pos.empty() ? 0 : job.coded_pos.back()) + 8)) return -2;
+  }
   if (job.host_route) {
     // shapes the stream kernels do not take: the library's own tree builder, here and now
     u32 st = state_in;
@@ -303,6 +356,15 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
   e.half_job = jobp;
   *ticket = e.next_ticket++;
   e.jobs[*ticket] = jobp;
+  if (!e.deferred_queue && e.device_models && e.wavelet_model == 'B' && !e.wavelet_on_host) {
+    // _prepare / _queue flow with the models on the device: the streams of THIS block are made now
+    // (its plan is waited for: a few milliseconds of GPU idle, once per block and context), so that
+    // _queue -- which callers serialise over all contexts of a stream -- only has the state-dependent
+    // passes to launch
+    e.half_job.reset();
+    rc = wavelet_finish_device_half(e, jobp, true, true);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -338,7 +400,7 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
     e.prob_free.back()->swap(job.prob);
   }
   *out_bytes = job.record.size();
-  const int rc = job.record.size() <= job.user_cap ? 0 : -1;
+  const int rc = job.failed ? -2 : job.record.size() <= job.user_cap ? 0 : -1;
   if (e.pipeline) {                                   // freed by a worker, not by the thread that feeds the GPU
     std::shared_ptr<WaveletJob> last(std::move(jobp));
     e.pipeline->dispose(std::move(last));

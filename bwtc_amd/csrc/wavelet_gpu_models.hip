@@ -208,12 +208,14 @@ int BwtEngine::reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes) {
   return 0;
 }
 
-// d_packed: the block's packed streams (n_coded elements) in HBM.  Queues the passes on the
-// engine's stream and the copy of the w-elements (and of {state after the block, error flags}) to
-// h_w / h_tail on the d2h stream; nothing is waited for.  state_in = the main machine's state
-// before the block.
-int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
-                          const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail) {
+// The passes in two parts, so that a stream farmed over several contexts can do everything that does
+// not depend on the blocks before this one early (wavelet_models_prepare: tables, chunk maps, the
+// tiles' state maps) and the rest once the carried state is known (wavelet_models_run).
+// d_packed: the block's packed streams (n_coded elements) in HBM.  Nothing is waited for, except:
+// early_state != null -> the state after the block is read back right after the state scan (a wait
+// of some tens of microseconds) and returned, before the long passes are queued.
+int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
+                           const std::vector<u32>& coded_pos, GmPass* g) {
   BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   std::vector<gm::Task> tasks;
@@ -221,9 +223,13 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   gm::buildTasks(plan, coded_pos.data(), &tasks, &chunks);
   const u32 nt = (u32)tasks.size(), nc = (u32)chunks.size();
   if (nt == 0 || nc == 0 || n_coded == 0) return -1;
-  const u32 ns = gm::kSlots * nt;
-  const u32 nsc = ceil_div(n_coded, gm::kSlotChunk);
-  const u64 n_base = (u64)gm::kSlots * nc + 1;
+  g->d_packed = d_packed; g->n_coded = n_coded; g->nt = nt; g->nc = nc;
+  g->ns = gm::kSlots * nt;
+  g->nsc = ceil_div(n_coded, gm::kSlotChunk);
+  g->n_base = (u64)gm::kSlots * nc + 1;
+  g->ntiles = ceil_div(nc, kGmStateTPB * kGmStateE);
+  g->gsize = gm::chainGroupSize(g->nsc);
+  g->ng = ceil_div(g->nsc, g->gsize);
 
   u64 at = 0;
   auto take = [&](u64 bytes) { const u64 o = at; at = gm_align(at + bytes); return o; };
@@ -231,18 +237,16 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
   const u64 o_chunks = take((u64)nc * sizeof(gm::Chunk));
   const u64 o_order = take((u64)nc * 4);
   const u64 tables_end = at;
-  const u32 ntiles = ceil_div(nc, kGmStateTPB * kGmStateE);
-  const u64 o_excl = take((u64)ntiles * kGmStateTPB * 8), o_tagg = take((u64)ntiles * 8), o_tstate = take((u64)ntiles * 4);
+  const u64 o_excl = take((u64)g->ntiles * kGmStateTPB * 8), o_tagg = take((u64)g->ntiles * 8), o_tstate = take((u64)g->ntiles * 4);
   const u64 o_cmap = take((u64)nc * 8);
   const u64 o_cstate = take((u64)nc * 4);
-  const u64 o_base = take(n_base * 4);
-  const u64 o_partial = take(((u64)ceil_div(n_base, kScanTile) + 1) * 4);
-  const u64 o_sb = take(((u64)ns + 1) * 4);
+  const u64 o_base = take(g->n_base * 4);
+  const u64 o_partial = take(((u64)ceil_div(g->n_base, kScanTile) + 1) * 4);
+  const u64 o_sb = take(((u64)g->ns + 1) * 4);
   const u64 o_sbits = take(((u64)n_coded / 32 + 16) * 4);
-  const u64 o_smap = take((u64)nsc * sizeof(gm::SlotMap));
-  const u64 o_sstart = take(((u64)nsc + 1) * 2);
-  const u32 gsize = gm::chainGroupSize(nsc), ng = ceil_div(nsc, gsize);
-  const u64 o_gmap = take((u64)ng * 64), o_gL = take((u64)ng * 2), o_tg = take((u64)ng * 2);
+  const u64 o_smap = take((u64)g->nsc * sizeof(gm::SlotMap));
+  const u64 o_sstart = take(((u64)g->nsc + 1) * 2);
+  const u64 o_gmap = take((u64)g->ng * 64), o_gL = take((u64)g->ng * 2), o_tg = take((u64)g->ng * 2);
   const u64 o_snaps = take(((u64)n_coded / gm::kSample + 4) * sizeof(gm::SlotMap));
   const u64 o_tail = take(16);
   int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
@@ -259,46 +263,63 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
     for (u32 c = 0; c < nc; ++c) order[first[tasks[chunks[c].task_first & 0x7FFFFFFFu].type]++] = c;
   }
   BWTC_HIP_TRY(hipMemcpyAsync(base, e.h_gm, tables_end, hipMemcpyHostToDevice, st));
-  const gm::Task* d_tasks = reinterpret_cast<const gm::Task*>(base + o_tasks);
-  const gm::Chunk* d_chunks = reinterpret_cast<const gm::Chunk*>(base + o_chunks);
-  const u32* d_order = reinterpret_cast<const u32*>(base + o_order);
-  u64* d_excl = reinterpret_cast<u64*>(base + o_excl);
-  u64* d_tagg = reinterpret_cast<u64*>(base + o_tagg);
-  u32* d_tstate = reinterpret_cast<u32*>(base + o_tstate);
-  u64* d_cmap = reinterpret_cast<u64*>(base + o_cmap);
-  u32* d_cstate = reinterpret_cast<u32*>(base + o_cstate);
-  u32* d_base = reinterpret_cast<u32*>(base + o_base);
-  u32* d_sb = reinterpret_cast<u32*>(base + o_sb);
-  u32* d_sbits = reinterpret_cast<u32*>(base + o_sbits);
-  gm::SlotMap* d_smap = reinterpret_cast<gm::SlotMap*>(base + o_smap);
-  unsigned short* d_sstart = reinterpret_cast<unsigned short*>(base + o_sstart);
-  gm::SlotMap* d_snaps = reinterpret_cast<gm::SlotMap*>(base + o_snaps);
-  u32* d_tail = reinterpret_cast<u32*>(base + o_tail);              // [0] state after the block, [1] error flags
-  unsigned short* d_w = static_cast<unsigned short*>(e.d_gm_w);
+  g->d_tasks = base + o_tasks; g->d_chunks = base + o_chunks; g->d_order = base + o_order;
+  g->d_excl = base + o_excl; g->d_tagg = base + o_tagg; g->d_tstate = base + o_tstate;
+  g->d_cmap = base + o_cmap; g->d_cstate = base + o_cstate; g->d_base = base + o_base; g->d_partial = base + o_partial;
+  g->d_sb = base + o_sb; g->d_sbits = base + o_sbits; g->d_smap = base + o_smap; g->d_sstart = base + o_sstart;
+  g->d_gmap = base + o_gmap; g->d_gL = base + o_gL; g->d_tg = base + o_tg; g->d_snaps = base + o_snaps; g->d_tail = base + o_tail;
 
-  BWTC_HIP_TRY(hipMemsetAsync(d_tail, 0, 16, st));
-  BWTC_HIP_TRY(hipMemsetAsync(d_sbits, 0, ((u64)n_coded / 32 + 16) * 4, st));
-  BWTC_HIP_TRY(hipMemsetAsync(d_base + n_base - 1, 0, 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(g->d_tail, 0, 16, st));
+  BWTC_HIP_TRY(hipMemsetAsync(g->d_sbits, 0, ((u64)n_coded / 32 + 16) * 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(static_cast<u32*>(g->d_base) + g->n_base - 1, 0, 4, st));
+  hipLaunchKernelGGL(k_gm_map, dim3(ceil_div(nc, kGmTPB)), dim3(kGmTPB), 0, st, d_packed, (const gm::Chunk*)g->d_chunks,
+                     (const gm::Task*)g->d_tasks, (const u32*)g->d_order, nc, (u64*)g->d_cmap);
+  hipLaunchKernelGGL(k_gm_state_tile, dim3(g->ntiles), dim3(kGmStateTPB), 0, st, (const gm::Chunk*)g->d_chunks, (const u64*)g->d_cmap,
+                     nc, (u64*)g->d_excl, (u64*)g->d_tagg);
+  g->ready = true;
+  return 0;
+}
+
+int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_w, u32* h_tail, u32* early_state) {
+  BwtEngine::ScanScope scan_scope(e);
+  hipStream_t st = e.stream;
+  if (!g.ready) return -1;
+  const u32 nc = g.nc, nt = g.nt, ns = g.ns, nsc = g.nsc, n_coded = g.n_coded;
+  const gm::Task* d_tasks = static_cast<const gm::Task*>(g.d_tasks);
+  const gm::Chunk* d_chunks = static_cast<const gm::Chunk*>(g.d_chunks);
+  const u32* d_order = static_cast<const u32*>(g.d_order);
+  u32* d_cstate = static_cast<u32*>(g.d_cstate);
+  u32* d_base = static_cast<u32*>(g.d_base);
+  u32* d_sb = static_cast<u32*>(g.d_sb);
+  u32* d_sbits = static_cast<u32*>(g.d_sbits);
+  gm::SlotMap* d_smap = static_cast<gm::SlotMap*>(g.d_smap);
+  unsigned short* d_sstart = static_cast<unsigned short*>(g.d_sstart);
+  gm::SlotMap* d_snaps = static_cast<gm::SlotMap*>(g.d_snaps);
+  u32* d_tail = static_cast<u32*>(g.d_tail);                        // [0] state after the block, [1] error flags, [2] elements counted, [3] scan error
+  unsigned short* d_w = static_cast<unsigned short*>(e.d_gm_w);
   const dim3 gc(ceil_div(nc, kGmTPB)), gs(ceil_div(nsc, kGmTPB)), tpb(kGmTPB);
-  hipLaunchKernelGGL(k_gm_map, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_order, nc, d_cmap);
-  hipLaunchKernelGGL(k_gm_state_tile, dim3(ntiles), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, d_excl, d_tagg);
-  hipLaunchKernelGGL(k_gm_state_top, dim3(1), dim3(64), 0, st, d_tagg, ntiles, state_in, d_tstate, d_tail);
-  hipLaunchKernelGGL(k_gm_state_apply, dim3(ntiles), dim3(kGmStateTPB), 0, st, d_chunks, d_cmap, nc, d_excl, d_tstate, d_cstate);
-  hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_order, nc, d_base);
-  exclusive_scan_u32(d_base, n_base, reinterpret_cast<u32*>(base + o_partial), st);
+  hipLaunchKernelGGL(k_gm_state_top, dim3(1), dim3(64), 0, st, (const u64*)g.d_tagg, g.ntiles, state_in, (u32*)g.d_tstate, d_tail);
+  if (early_state) {
+    BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 2, d_tail, 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(e.wait());
+    *early_state = e.h_small[2];
+  }
+  hipLaunchKernelGGL(k_gm_state_apply, dim3(g.ntiles), dim3(kGmStateTPB), 0, st, d_chunks, (const u64*)g.d_cmap, nc, (const u64*)g.d_excl,
+                     (const u32*)g.d_tstate, d_cstate);
+  hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_order, nc, d_base);
+  exclusive_scan_u32(d_base, g.n_base, static_cast<u32*>(g.d_partial), st);
   hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
-  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
+  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
   hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_snaps, d_tail + 1);
-  unsigned short* d_gmap = reinterpret_cast<unsigned short*>(base + o_gmap);
-  unsigned short* d_gL = reinterpret_cast<unsigned short*>(base + o_gL);
-  unsigned short* d_tg = reinterpret_cast<unsigned short*>(base + o_tg);
-  hipLaunchKernelGGL(k_gm_chain_group, dim3(ng), dim3(64), 0, st, d_smap, nsc, gsize, d_gmap, d_gL);
-  hipLaunchKernelGGL(k_gm_chain_top, dim3(1), dim3(1024), 0, st, d_gmap, d_gL, ng, d_tg, d_tail + 1);
-  hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(ng, 64)), dim3(64), 0, st, d_smap, nsc, gsize, ng, d_tg, d_sstart, d_tail + 1);
-  hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_snaps, d_smap,
+  hipLaunchKernelGGL(k_gm_chain_group, dim3(g.ng), dim3(64), 0, st, d_smap, nsc, g.gsize, (unsigned short*)g.d_gmap, (unsigned short*)g.d_gL);
+  hipLaunchKernelGGL(k_gm_chain_top, dim3(1), dim3(1024), 0, st, (const unsigned short*)g.d_gmap, (const unsigned short*)g.d_gL, g.ng,
+                     (unsigned short*)g.d_tg, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(g.ng, 64)), dim3(64), 0, st, d_smap, nsc, g.gsize, g.ng, (const unsigned short*)g.d_tg,
+                     d_sstart, d_tail + 1);
+  hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_snaps, d_smap,
                      d_sstart, d_order, nc, nt, d_w, d_tail + 1);
   // total of the scan = every element counted once (else the tables do not describe the streams)
-  BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + n_base - 1, 4, hipMemcpyDeviceToDevice, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 2, d_base + g.n_base - 1, 4, hipMemcpyDeviceToDevice, st));
   if (e.scan_chain.err) BWTC_HIP_TRY(hipMemcpyAsync(d_tail + 3, e.scan_chain.err, 4, hipMemcpyDeviceToDevice, st));   // a timed-out scan
   BWTC_HIP_TRY(e.ensure_d2h_stream());
   BWTC_HIP_TRY(hipEventRecord(e.ev_models, st));
@@ -311,6 +332,14 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
     std::fprintf(stderr, "models on the device: %u coded elements, %u tasks, %u chunks, %u slot-chunks, state in %u\n",
                  n_coded, nt, nc, nsc, state_in);
   return 0;
+}
+
+int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
+                          const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail) {
+  GmPass g;
+  const int rc = wavelet_models_prepare(e, d_packed, n_coded, plan, coded_pos, &g);
+  if (rc) return rc;
+  return wavelet_models_run(e, g, state_in, h_w, h_tail, nullptr);
 }
 
 }  // namespace bwtc_hip

@@ -109,11 +109,11 @@ int main(int argc, char** argv) {
           std::fclose(f);
         }
       }
-      // ... and only where the adaptive models run on the worker threads (BWTC_HIP_MODELS=host, or a
-      // stream farmed over several contexts): with the models on the GPU -- the default -- a block is
-      // under way for 0.6 s and holds 1.2 GB of page-locked memory, 16 blocks are what it takes.
+      // ... and only where the adaptive models run on the worker threads (BWTC_HIP_MODELS=host): with
+      // the models on the GPU -- the default, also for a stream farmed over several contexts -- a block
+      // is under way for 0.6 s and holds 1.2 GB of page-locked memory, 16 blocks are what it takes.
       const char* mv = std::getenv("BWTC_HIP_MODELS");
-      const bool host_models = (mv && std::strcmp(mv, "host") == 0) || n_ctx > 1 || enc != 'B';
+      const bool host_models = (mv && std::strcmp(mv, "host") == 0) || enc != 'B';
       const bool deep = host_models && block_bytes >= 64e6 && stream_bytes / block_bytes >= 256.0 * n_ctx;
       pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : 16;
     }

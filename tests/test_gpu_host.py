@@ -96,6 +96,15 @@ def test_cli_block_farm_over_two_contexts_gives_the_sequential_stream(tmp_path, 
         assert one.read_bytes() == want, enc
         assert (tmp_path / ("two.%s.bwtc" % enc)).read_bytes() == want, enc
         assert (tmp_path / ("three.%s.bwtc" % enc)).read_bytes() == want, enc
+    # the 'B' models of a farmed stream run on the device (the state-dependent passes at _queue time,
+    # the block joins the host pipeline from a stream callback): the same stream with the models on the
+    # worker threads, and when every block's device result is declared flagged (host fallback)
+    for extra in ({"BWTC_HIP_MODELS": "host"}, {"BWTC_HIP_TEST_MODELS_FALLBACK": "1"}):
+        dst = tmp_path / "two.B.alt.bwtc"
+        r = subprocess.run([exe, "-m", "1", "-e", "B", "--devices", "0,0", str(src), str(dst)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stderr
+        assert dst.read_bytes() == (tmp_path / "two.B.bwtc").read_bytes(), extra
     out = tmp_path / "farm.out"
     r = subprocess.run([unexe, str(tmp_path / "two.B.bwtc"), str(out)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
