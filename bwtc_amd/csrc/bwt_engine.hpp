@@ -21,6 +21,7 @@
 #include "scan.hpp"
 #include "wavelet_host.hpp"
 #include "wavelet_pipeline.hpp"
+#include <sys/mman.h>
 #include <condition_variable>
 #include <future>
 #include <map>
@@ -41,9 +42,50 @@ struct RrEmit;
 // block's own buffer.  Recycled between blocks (locking pages is slow), contents lost on growth.
 // Where the system will not lock that many pages (96 blocks under way hold 12 GB per context) the
 // bytes are ordinary memory: the copy is then staged by the runtime, slower but the same bytes.
+struct PinnedGauge {                                // bytes of host staging held by this process, now and at most
+  std::atomic<uint64_t> now{0}, peak{0};
+  void add(uint64_t n) {
+    const uint64_t v = now.fetch_add(n) + n;
+    uint64_t p = peak.load();
+    while (p < v && !peak.compare_exchange_weak(p, v)) {}
+  }
+  void sub(uint64_t n) { now.fetch_sub(n); }
+  static PinnedGauge& get() { static PinnedGauge g; return g; }
+};
+
+// Page-locked host memory, the fast way: transparent huge pages, touched by the calling thread (on its
+// own NUMA node, outside the driver), then registered -- 50 ms per 1.2 GB where hipHostMalloc takes
+// 200 ms, most of it under the driver's lock, and 130 ms more to free (scripts/dev/pin_bench.cpp; the
+// copies run at the same 57 GB/s).  *kind: 2 registered, 1 hipHostMalloc, 0 nothing could be locked.
+inline void* lockedHostAlloc(size_t n, int* kind) {
+  const size_t huge = (size_t)2 << 20;
+  void* q = nullptr;
+  if (n >= huge && !std::getenv("BWTC_HIP_NO_HUGE_PAGES")) {
+    const size_t bytes = (n + huge - 1) / huge * huge;
+    if (posix_memalign(&q, huge, bytes) == 0) {
+      (void)madvise(q, bytes, MADV_HUGEPAGE);
+      for (size_t i = 0; i < bytes; i += 4096) static_cast<volatile char*>(q)[i] = 0;
+      if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) { *kind = 2; return q; }
+      (void)hipGetLastError();
+      std::free(q);
+      q = nullptr;
+    }
+  }
+  if (hipHostMalloc(&q, n ? n : 1, hipHostMallocDefault) == hipSuccess) { *kind = 1; return q; }
+  (void)hipGetLastError();                         // not an error of the caller's stream
+  *kind = 0;
+  return nullptr;
+}
+inline void lockedHostFree(void* p, int kind) {
+  if (!p) return;
+  if (kind == 2) { (void)hipHostUnregister(p); std::free(p); }
+  else if (kind == 1) (void)hipHostFree(p);
+  else std::free(p);
+}
+
 class PinnedBytes {
  public:
-  PinnedBytes() : p_(nullptr), n_(0), locked_(true) {}
+  PinnedBytes() : p_(nullptr), n_(0), locked_(0) {}
   ~PinnedBytes() { release(); }
   PinnedBytes(const PinnedBytes&) = delete;
   PinnedBytes& operator=(const PinnedBytes&) = delete;
@@ -51,30 +93,27 @@ class PinnedBytes {
   bool reserve(size_t n) {
     if (n <= n_) return true;
     release();
-    void* q = nullptr;
-    if (hipHostMalloc(&q, n + n / 8, hipHostMallocDefault) == hipSuccess) {
-      locked_ = true;
-    } else {
-      (void)hipGetLastError();                     // not an error of the caller's stream
+    void* q = lockedHostAlloc(n + n / 8, &locked_);
+    if (!q) {
       if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "PinnedBytes: %zu bytes could not be page-locked, using ordinary memory\n", n + n / 8);
       q = std::malloc(n + n / 8);
       if (!q) return false;
-      locked_ = false;
     }
     p_ = static_cast<uint8_t*>(q);
     n_ = n + n / 8;
+    PinnedGauge::get().add(n_);
     return true;
   }
   uint8_t* data() { return p_; }
   size_t size() const { return n_; }
  private:
   void release() {
-    if (p_) { if (locked_) (void)hipHostFree(p_); else std::free(p_); }
+    if (p_) { lockedHostFree(p_, locked_); PinnedGauge::get().sub(n_); }
     p_ = nullptr; n_ = 0;
   }
   uint8_t* p_;
   size_t n_;
-  bool locked_;
+  int locked_;                                   // see lockedHostAlloc
 };
 
 // Page-locked buffers of one size class, recycled between blocks.  Locking a gigabyte of pages
@@ -149,6 +188,8 @@ struct GmPass {
        *d_cmap = nullptr, *d_cstate = nullptr, *d_base = nullptr, *d_partial = nullptr, *d_sb = nullptr, *d_sbits = nullptr,
        *d_smap = nullptr, *d_sstart = nullptr, *d_gmap = nullptr, *d_gL = nullptr, *d_tg = nullptr, *d_snaps = nullptr,
        *d_tail = nullptr;
+  u32 ends[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // the carried state after the block, by the state it starts in
+  bool ends_ready = false;
 };
 
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
@@ -355,10 +396,12 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
 // the passes and the copy of the w-elements to h_w, of {state after, error flags, count} to h_tail.
 int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
                           const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail);
-// the same in two parts: what does not depend on the carried state, and the rest (early_state != null:
-// the state after the block is read back, with a short wait, before the long passes are queued)
+// the same in two parts: what does not depend on the carried state (read_ends: and, after a wait for the
+// device, the state after the block for each of the eight states it can start in), and the rest
+// (early_state != null: the state after the block is returned before the long passes are queued -- from
+// that table, else read back with a short wait)
 int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
-                           const std::vector<u32>& coded_pos, GmPass* g);
+                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends = false);
 int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_w, u32* h_tail, u32* early_state);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,

@@ -42,6 +42,10 @@ static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int
   return 0;
 }
 
+// how every buffer handed out by bwtc_hip_host_alloc was locked (see lockedHostAlloc)
+static std::mutex& host_allocs_mu() { static std::mutex m; return m; }
+static std::map<void*, int>& host_allocs() { static std::map<void*, int> m; return m; }
+
 extern "C" {
 
 int bwtc_hip_device_count(void) {
@@ -121,12 +125,24 @@ int bwtc_hip_memcpy_to_host(bwtc_hip_ctx* ctx, void* dst, const void* d_src, uin
 
 void* bwtc_hip_host_alloc(bwtc_hip_ctx* ctx, uint64_t bytes) {
   if (!ctx || hipSetDevice(ctx->eng.device) != hipSuccess) return nullptr;
-  void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  int kind = 0;
+  void* p = bwtc_hip::lockedHostAlloc(bytes ? bytes : 1, &kind);
+  if (!p) return nullptr;
+  std::lock_guard<std::mutex> g(host_allocs_mu());
+  host_allocs()[p] = kind;
   return p;
 }
 void bwtc_hip_host_free(bwtc_hip_ctx* ctx, void* p) {
-  if (ctx && p && hipSetDevice(ctx->eng.device) == hipSuccess) (void)hipHostFree(p);
+  if (!ctx || !p || hipSetDevice(ctx->eng.device) != hipSuccess) return;
+  int kind = 1;
+  {
+    std::lock_guard<std::mutex> g(host_allocs_mu());
+    std::map<void*, int>::iterator it = host_allocs().find(p);
+    if (it == host_allocs().end()) return;          // not one of ours
+    kind = it->second;
+    host_allocs().erase(it);
+  }
+  bwtc_hip::lockedHostFree(p, kind);
 }
 int bwtc_hip_memcpy_to_device_async(bwtc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
   if (!ctx || (!d_dst && bytes) || (!src && bytes)) return -1;
@@ -422,6 +438,12 @@ int bwtc_hip_wavelet_latency(bwtc_hip_ctx* ctx, double* mean_seconds) {
   const HostPipeline* p = ctx->eng.pipeline;
   const uint64_t n = p ? p->clock.finished.load() : 0;
   *mean_seconds = n ? p->clock.latency_ns.load() * 1e-9 / (double)n : 0.0;
+  return 0;
+}
+
+int bwtc_hip_host_staging_bytes(uint64_t* now, uint64_t* peak) {
+  if (now) *now = bwtc_hip::PinnedGauge::get().now.load();
+  if (peak) *peak = bwtc_hip::PinnedGauge::get().peak.load();
   return 0;
 }
 

@@ -88,9 +88,13 @@ static int wavelet_finish_device_half(BwtEngine& e, const std::shared_ptr<Device
       const size_t had = job.w_owner.size();
       if (!job.w_owner.reserve(w_bytes + 64)) return -2;
       if (!w_recycled || job.w_owner.size() != had) e.w_pool.noteAllocated();
+      if (e.max_inflight > 2) {                       // as below: the next blocks' buffers are made off this thread
+        e.w_pool.allocateAhead(e.device, (size_t)(w_bytes + w_bytes / 64 + 64), e.max_inflight + 1);
+        e.codes_pool.allocateAhead(e.device, job.codes_owner.size(), e.max_inflight + 1);
+      }
       job.h_tail = reinterpret_cast<u32*>(job.w_owner.data() + w_bytes);
       job.h_tail[0] = job.h_tail[1] = job.h_tail[2] = job.h_tail[3] = 0xFFFFFFFFu;
-      rc = wavelet_models_prepare(e, d_packed, (u32)e.wt_coded, job.plan, job.coded_pos, &job.gm);
+      rc = wavelet_models_prepare(e, d_packed, (u32)e.wt_coded, job.plan, job.coded_pos, &job.gm, true);
       if (rc) return rc;
       e.gm_pending = jobp;
     }
@@ -221,8 +225,9 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
   job.queued = true;
   if (job.gm.ready && job.streams_ready && e.wavelet_model == 'B') {
     // farmed stream, models on the device: the rest of the passes with the state that has just
-    // arrived; the state after the block comes back after the (short) state scan, the block joins
-    // the host pipeline from a host callback when its w-elements have landed
+    // arrived; the state after the block is looked up (_prepare left it for every state the block can
+    // start in: nothing here waits for the device), the block joins the host pipeline from a host
+    // callback when its w-elements have landed
     u32 after = state_in;
     int rc = wavelet_models_run(e, job.gm, state_in, reinterpret_cast<uint16_t*>(job.w_owner.data()), job.h_tail, &after);
     job.gm.ready = false;

@@ -20,6 +20,7 @@ namespace gm = bwtc::wavelet::gm;
 
 constexpr int kGmTPB = 256;
 constexpr int kGmStateTPB = 1024;
+constexpr int kGmSmallEnds = 960;                   // words of the engine's small page-locked mirror used here
 constexpr int kGmStateE = 8;
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_map(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
@@ -66,6 +67,14 @@ __global__ void k_gm_state_top(const u64* __restrict__ tagg, u32 ntiles, u32 sta
   u32 st = gm::packState(state_in & 7u, 2, 1);
   for (u32 t = 0; t < ntiles; ++t) { tstate[t] = st; st = gm::mapApply(tagg[t], st); }
   *state_out = st & 7u;
+}
+// ends[i] = the carried state after the block when it starts in state i: known before the state is
+// (a stream farmed over contexts hands the state on without waiting for this block's passes)
+__global__ void k_gm_state_ends(const u64* __restrict__ tagg, u32 ntiles, u32* __restrict__ ends) {
+  if (blockIdx.x || threadIdx.x >= 8) return;
+  u32 st = gm::packState(threadIdx.x, 2, 1);
+  for (u32 t = 0; t < ntiles; ++t) st = gm::mapApply(tagg[t], st);
+  ends[threadIdx.x] = st & 7u;
 }
 __global__ __launch_bounds__(kGmStateTPB) void k_gm_state_apply(const gm::Chunk* __restrict__ chunks, const u64* __restrict__ cmap,
                                                                 u32 nc, const u64* __restrict__ excl, const u32* __restrict__ tstate,
@@ -215,7 +224,7 @@ int BwtEngine::reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes) {
 // early_state != null -> the state after the block is read back right after the state scan (a wait
 // of some tens of microseconds) and returned, before the long passes are queued.
 int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
-                           const std::vector<u32>& coded_pos, GmPass* g) {
+                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends) {
   BwtEngine::ScanScope scan_scope(e);
   hipStream_t st = e.stream;
   std::vector<gm::Task> tasks;
@@ -248,7 +257,7 @@ int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const
   const u64 o_sstart = take(((u64)g->nsc + 1) * 2);
   const u64 o_gmap = take((u64)g->ng * 64), o_gL = take((u64)g->ng * 2), o_tg = take((u64)g->ng * 2);
   const u64 o_snaps = take(((u64)n_coded / gm::kSample + 4) * sizeof(gm::SlotMap));
-  const u64 o_tail = take(16);
+  const u64 o_tail = take(16 + 32);                   // + the eight possible states after the block
   int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
   if (rc) return rc;
   u8* base = static_cast<u8*>(e.d_gm);
@@ -276,6 +285,16 @@ int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const
                      (const gm::Task*)g->d_tasks, (const u32*)g->d_order, nc, (u64*)g->d_cmap);
   hipLaunchKernelGGL(k_gm_state_tile, dim3(g->ntiles), dim3(kGmStateTPB), 0, st, (const gm::Chunk*)g->d_chunks, (const u64*)g->d_cmap,
                      nc, (u64*)g->d_excl, (u64*)g->d_tagg);
+  if (read_ends) {
+    // (the caller hands the state from context to context: it waits here, once, for its OWN device half
+    // instead of making the stream's other contexts wait at _queue)
+    u32* d_ends = static_cast<u32*>(g->d_tail) + 4;
+    hipLaunchKernelGGL(k_gm_state_ends, dim3(1), dim3(64), 0, st, (const u64*)g->d_tagg, g->ntiles, d_ends);
+    BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + kGmSmallEnds, d_ends, 32, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(e.wait());
+    for (int i = 0; i < 8; ++i) g->ends[i] = e.h_small[kGmSmallEnds + i];
+    g->ends_ready = true;
+  }
   g->ready = true;
   return 0;
 }
@@ -300,9 +319,13 @@ int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_
   const dim3 gc(ceil_div(nc, kGmTPB)), gs(ceil_div(nsc, kGmTPB)), tpb(kGmTPB);
   hipLaunchKernelGGL(k_gm_state_top, dim3(1), dim3(64), 0, st, (const u64*)g.d_tagg, g.ntiles, state_in, (u32*)g.d_tstate, d_tail);
   if (early_state) {
-    BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + 2, d_tail, 4, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(e.wait());
-    *early_state = e.h_small[2];
+    if (g.ends_ready) {
+      *early_state = g.ends[state_in & 7u];
+    } else {
+      BWTC_HIP_TRY(hipMemcpyAsync(e.h_small + kGmSmallEnds, d_tail, 4, hipMemcpyDeviceToHost, st));
+      BWTC_HIP_TRY(e.wait());
+      *early_state = e.h_small[kGmSmallEnds];
+    }
   }
   hipLaunchKernelGGL(k_gm_state_apply, dim3(g.ntiles), dim3(kGmStateTPB), 0, st, d_chunks, (const u64*)g.d_cmap, nc, (const u64*)g.d_excl,
                      (const u32*)g.d_tstate, d_cstate);

@@ -55,6 +55,7 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   fused_sections_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   long_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   w_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
+  w_long_chains_.on_block_coded = [this](WaveletJob& j) { finish(j); };
   // Device-modelled blocks leave only the range coders to the host.  A lane of the 16-lane engine
   // advances ITS chain five times slower than the scalar loop (9 ns against 1.7 per element), so
   // the block's longest section(s) get a scalar task each (they set the block's latency; queue()
@@ -64,6 +65,15 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   // threads and 51 ms of GPU per block: 2 engines 91 ms per block, 4 just short, 6 and 8 keep up)
   max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P * 3 + 7) / 8)) : 0u;
   if (std::getenv("BWTC_HIP_W_ENGINES") && std::atoi(std::getenv("BWTC_HIP_W_ENGINES")) == 0) max_w_engines_ = 0;
+  // The long sections of two blocks stepped alternately by one thread (runChainPairW): 1.25 ns per
+  // element instead of 1.65-1.9 on the GPU box's EPYC on random elements (scripts/dev/rc_fma_bench.cpp).
+  // (opt-in, BWTC_HIP_W_PAIR_ENGINES=n: in the pipeline, on real streams, the pairs saved nothing --
+  // 0.79 core-seconds per text block either way -- and every block was under way for 1.3 s instead of 0.7)
+  max_w_pair_engines_ = envNumber("BWTC_HIP_W_PAIR_ENGINES", 0);
+  // BWTC_HIP_W_LANES=32: an engine steps two vectors of sixteen chains alternately.  Measured no faster per
+  // core (0.87 core-seconds per text block with six engines against 0.82): the vector step is bound by
+  // its instruction count (transposes, the byte events), not by its dependency chain.
+  w_lanes_ = envNumber("BWTC_HIP_W_LANES", 16);
   w_long_chain_ = static_cast<uint64_t>(envNumber("BWTC_HIP_W_LONG_MI", 8)) << 20;
   if (std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS")) w_long_chain_ = std::strtoull(std::getenv("BWTC_HIP_LONG_CHAIN_ELEMENTS"), nullptr, 10);   // tests
 }
@@ -162,6 +172,10 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
       size_t n_long = 0;
       while (n_long < job.coder->sectionTasks() && job.coder->sectionElements(n_long) >= cut) ++n_long;
       std::vector<std::function<void()> > own;
+      if (max_w_pair_engines_ && n_long) {
+        if (w_long_chains_.add(jobp, 0, n_long, max_w_pair_engines_))
+          pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(w_long_chains_, 2, &clock.coder_ns); });
+      } else
       for (size_t k = 0; k < n_long; ++k) {
         own.push_back([this, jobp, k] {
           WaveletJob& j = *jobp;
@@ -175,7 +189,7 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
       }
       if (!own.empty()) pool_.submit(job.rank, own);
       if (w_chains_.add(jobp, n_long, job.coder->sectionTasks(), max_w_engines_))
-        pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(w_chains_, 16, &clock.coder_ns); });
+        pool_.submit(0, [this] { bwtc::wavelet::runCoderLanes(w_chains_, static_cast<int>(w_lanes_), &clock.coder_ns); });
       return job.w_end_state;
     }
     const uint64_t longest = std::max<uint64_t>(1, job.coder->largestSectionElements());

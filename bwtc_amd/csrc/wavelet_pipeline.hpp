@@ -285,6 +285,9 @@ class HostPipeline {
   BlockChainSource chains_;                          // sections for the 16-lane coder engines
   BlockChainSource long_chains_;                     // very long sections: scalar engines, two chains at a time
   BlockChainSource w_chains_;                        // device-modelled blocks: their shorter sections, for the 16-lane engines
+  BlockChainSource w_long_chains_;                   //   their longest sections, for scalar engines that step two chains alternately
+  unsigned max_w_pair_engines_;                      //   at most this many of those (0: every long section has a scalar task of its own)
+  unsigned w_lanes_;                                 //   chains an engine holds (16: one vector, 32: two stepped alternately)
   unsigned max_w_engines_;                           //   at most this many of them (0: no lanes, every chain scalar)
   uint64_t w_long_chain_;                            //   sections this long keep a scalar task of their own
   BlockSectionSource fused_sections_;                // fused model + coder engines

@@ -151,13 +151,16 @@ const uint64_t kScalarOnly = 512;        // chains shorter than this never enter
 const int kMinLanes = 4;                 // fewer busy lanes and an empty source: finish them scalar, two by two
 const uint64_t kMaxWords = 512;          // 16-element words per vector run (bounds the output room reserved per lane)
 
+const int kGroups = 2;                   // vectors an engine steps alternately (their dependency chains overlap)
+const int kAll = kLanes * kGroups;
+
 struct Lanes {
-  alignas(64) uint32_t lo[kLanes], size[kLanes];
-  const uint8_t* codes[kLanes];
-  const uint16_t* prob[kLanes];
-  uint64_t i[kLanes];
-  uint8_t* out[kLanes];
-  uint32_t advance[kLanes];              // 16 for a busy lane, 0 for an idle one (it keeps re-reading the zero page)
+  alignas(64) uint32_t lo[kAll], size[kAll];
+  const uint8_t* codes[kAll];
+  const uint16_t* prob[kAll];
+  uint64_t i[kAll];
+  uint8_t* out[kAll];
+  uint32_t advance[kAll];                // 16 for a busy lane, 0 for an idle one (it keeps re-reading the zero page)
 };
 
 alignas(64) const uint16_t kZeroProb[32] = {0};
@@ -194,60 +197,79 @@ BWTC_AVX512 inline void transpose16(__m512i r[16]) {
 // carries the interval.
 // WMODE: the lanes' elements are w-words (bit << 15 | probability of the coded bit, wavelet_gpu_models.hpp)
 // read through L.prob; the probability of a one and the bit are taken from them.
-template <bool WMODE>
+// G = 2: two vectors of sixteen chains are stepped alternately.  A step is a chain of dependent
+// instructions from the interval to the interval (two multiplies, the byte test, the masked shift),
+// some 45 cycles of which a single vector keeps the core's pipes busy for a third; the second
+// vector's steps fill them.
+template <bool WMODE, int G>
 BWTC_AVX512 void runWords(Lanes& L, uint64_t words, uint32_t busy_mask) {
-  __m512i lo = _mm512_load_si512(L.lo), size = _mm512_load_si512(L.size);
+  __m512i lo[G], size[G];
+  __mmask16 kBusy[G];
+  for (int g = 0; g < G; ++g) {
+    lo[g] = _mm512_load_si512(L.lo + g * kLanes);
+    size[g] = _mm512_load_si512(L.size + g * kLanes);
+    kBusy[g] = static_cast<__mmask16>(busy_mask >> (g * kLanes));
+  }
   const __m512i one = _mm512_set1_epi32(1), c4095 = _mm512_set1_epi32(4095), c2048 = _mm512_set1_epi32(2048);
   const __m512i top = _mm512_set1_epi32(static_cast<int>(0xFF000000u)), c510 = _mm512_set1_epi32(510);
-  const __m512i lane_id = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
-  const __mmask16 kBusy = static_cast<__mmask16>(busy_mask);
+  const __m512i lane0 = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
   const __m512i c32768 = _mm512_set1_epi32(32768), c32767 = _mm512_set1_epi32(32767), c4096 = _mm512_set1_epi32(4096);
-  alignas(64) uint32_t cw[kLanes] = {0};
-  alignas(64) uint32_t ev[16 * kLanes * 4 + 64];       // at most four bytes per lane and step
+  alignas(64) uint32_t cw[kAll] = {0};
+  alignas(64) uint32_t ev[G][16 * kLanes * 4 + 64];    // at most four bytes per lane and step
+  alignas(64) __m512i P[G][16];
   for (uint64_t w = 0; w < words; ++w) {
-    __m512i P[16];
-    for (int l = 0; l < kLanes; ++l) {
-      P[l] = _mm512_cvtepu16_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(L.prob[l] + L.i[l])));
-      if (!WMODE) std::memcpy(&cw[l], L.codes[l] + (L.i[l] >> 2), 4);
-      L.i[l] += L.advance[l];
+    for (int g = 0; g < G; ++g) {
+      for (int l = 0; l < kLanes; ++l) {
+        const int a = g * kLanes + l;
+        P[g][l] = _mm512_cvtepu16_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(L.prob[a] + L.i[a])));
+        if (!WMODE) std::memcpy(&cw[a], L.codes[a] + (L.i[a] >> 2), 4);
+        L.i[a] += L.advance[a];
+      }
+      transpose16(P[g]);
     }
-    transpose16(P);
-    __m512i W = _mm512_load_si512(cw);
-    uint32_t n = 0;
+    __m512i W[G];
+    uint32_t n[G];
+    for (int g = 0; g < G; ++g) { W[g] = _mm512_load_si512(cw + g * kLanes); n[g] = 0; }
     for (int t = 0; t < 16; ++t) {
-      __m512i p = P[t];
-      __mmask16 kBit;
-      if (WMODE) {
-        kBit = _mm512_test_epi32_mask(p, c32768);
-        const __m512i m = _mm512_and_si512(p, c32767);
-        p = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(c4096, m), m);       // probability of a one
-      } else {
-        kBit = _mm512_test_epi32_mask(W, one);
-        W = _mm512_srli_epi32(W, 2);
-      }
-      const __m512i hi = _mm512_srli_epi32(size, 12), lw = _mm512_and_si512(size, c4095);
-      const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, p),
-                                          _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, p), c2048), 12));
-      const __m512i t1 = _mm512_add_epi32(tt, one);
-      lo = _mm512_mask_add_epi32(lo, static_cast<__mmask16>(~kBit), lo, t1);          // zero bit: lo += t + 1
-      size = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(size, t1), _mm512_sub_epi32(tt, one));
-      // byte output: lanes whose interval ends share their top byte
-      __m512i hiend = _mm512_add_epi32(_mm512_add_epi32(lo, size), one);
-      __mmask16 m = _mm512_mask_testn_epi32_mask(kBusy, _mm512_xor_si512(lo, hiend), top);
-      for (;;) {
-        _mm512_storeu_si512(ev + n, _mm512_maskz_compress_epi32(m, _mm512_or_si512(_mm512_srli_epi32(lo, 24), lane_id)));
-        n += static_cast<uint32_t>(__builtin_popcount(m));
-        lo = _mm512_mask_slli_epi32(lo, m, lo, 8);
-        size = _mm512_mask_add_epi32(size, m, _mm512_slli_epi32(size, 8), c510);
-        hiend = _mm512_add_epi32(_mm512_add_epi32(lo, size), one);
-        m = _mm512_mask_testn_epi32_mask(m, _mm512_xor_si512(lo, hiend), top);
-        if (__builtin_expect(m == 0, 1)) break;
+#pragma GCC unroll 2
+      for (int g = 0; g < G; ++g) {
+        __m512i p = P[g][t];
+        __mmask16 kBit;
+        if (WMODE) {
+          kBit = _mm512_test_epi32_mask(p, c32768);
+          const __m512i m = _mm512_and_si512(p, c32767);
+          p = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(c4096, m), m);       // probability of a one
+        } else {
+          kBit = _mm512_test_epi32_mask(W[g], one);
+          W[g] = _mm512_srli_epi32(W[g], 2);
+        }
+        const __m512i hi = _mm512_srli_epi32(size[g], 12), lw = _mm512_and_si512(size[g], c4095);
+        const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, p),
+                                            _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, p), c2048), 12));
+        const __m512i t1 = _mm512_add_epi32(tt, one);
+        lo[g] = _mm512_mask_add_epi32(lo[g], static_cast<__mmask16>(~kBit), lo[g], t1);          // zero bit: lo += t + 1
+        size[g] = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(size[g], t1), _mm512_sub_epi32(tt, one));
+        // byte output: lanes whose interval ends share their top byte
+        __m512i hiend = _mm512_add_epi32(_mm512_add_epi32(lo[g], size[g]), one);
+        __mmask16 m = _mm512_mask_testn_epi32_mask(kBusy[g], _mm512_xor_si512(lo[g], hiend), top);
+        for (;;) {
+          _mm512_storeu_si512(ev[g] + n[g], _mm512_maskz_compress_epi32(m, _mm512_or_si512(_mm512_srli_epi32(lo[g], 24), lane0)));
+          n[g] += static_cast<uint32_t>(__builtin_popcount(m));
+          lo[g] = _mm512_mask_slli_epi32(lo[g], m, lo[g], 8);
+          size[g] = _mm512_mask_add_epi32(size[g], m, _mm512_slli_epi32(size[g], 8), c510);
+          hiend = _mm512_add_epi32(_mm512_add_epi32(lo[g], size[g]), one);
+          m = _mm512_mask_testn_epi32_mask(m, _mm512_xor_si512(lo[g], hiend), top);
+          if (__builtin_expect(m == 0, 1)) break;
+        }
       }
     }
-    for (uint32_t k = 0; k < n; ++k) { const uint32_t e = ev[k]; *L.out[e >> 8]++ = static_cast<uint8_t>(e); }
+    for (int g = 0; g < G; ++g)
+      for (uint32_t k = 0; k < n[g]; ++k) { const uint32_t e = ev[g][k]; *L.out[g * kLanes + (e >> 8)]++ = static_cast<uint8_t>(e); }
   }
-  _mm512_store_si512(L.lo, lo);
-  _mm512_store_si512(L.size, size);
+  for (int g = 0; g < G; ++g) {
+    _mm512_store_si512(L.lo + g * kLanes, lo[g]);
+    _mm512_store_si512(L.size + g * kLanes, size[g]);
+  }
 }
 
 }  // namespace
@@ -274,12 +296,13 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
   };
   // max_lanes < kMinLanes: never a vector -- the engine steps two chains alternately (the mode for
   // a block's one or two very long chains, which a lane would hold for seconds)
-  const int lanes = std::max(1, std::min(max_lanes, kLanes));
+  const int lanes = std::max(1, std::min(max_lanes, kAll));
+  const bool two = lanes > kLanes;                     // more than a vector's worth: two vectors stepped alternately
   Lanes L;
-  CoderChain chain[kLanes];
-  ChainDesc desc[kLanes];
-  bool busy[kLanes];
-  for (int l = 0; l < kLanes; ++l) busy[l] = false;
+  CoderChain chain[kAll];
+  ChainDesc desc[kAll];
+  bool busy[kAll];
+  for (int l = 0; l < kAll; ++l) busy[l] = false;
   bool sourceDry = false;
   bool wmode = false;                                  // this engine's chains come as w-words (a source hands out one kind)
   auto scalar = [&](int l, uint64_t until) {
@@ -318,8 +341,8 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
       // not worth a vector: two chains stepped alternately (or the last one alone), in slices so
       // that new work -- another block's chains -- is picked up soon
       const uint64_t kSlice = static_cast<uint64_t>(1) << 22;
-      int ids[kLanes], n = 0;
-      for (int l = 0; l < kLanes; ++l) if (busy[l]) ids[n++] = l;
+      int ids[kAll], n = 0;
+      for (int l = 0; l < kAll; ++l) if (busy[l]) ids[n++] = l;
       if (n >= 2) {
         const int a = ids[0], b = ids[1];
         if (desc[a].w && desc[b].w) runChainPairW(chain[a], desc[a].w, chain[b], desc[b].w, kSlice);
@@ -337,9 +360,9 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
     }
     uint64_t words = kMaxWords;
     uint32_t mask = 0;
-    for (int l = 0; l < kLanes; ++l) if (busy[l]) { words = std::min(words, (chain[l].e - chain[l].i) >> 4); mask |= 1u << l; }
+    for (int l = 0; l < kAll; ++l) if (busy[l]) { words = std::min(words, (chain[l].e - chain[l].i) >> 4); mask |= 1u << l; }
     if (words > 0) {
-      for (int l = 0; l < kLanes; ++l) {
+      for (int l = 0; l < kAll; ++l) {
         if (busy[l]) {
           CoderChain& c = chain[l];
           L.lo[l] = c.lo; L.size[l] = c.size; L.codes[l] = desc[l].codes; L.prob[l] = wmode ? desc[l].w : desc[l].prob; L.i[l] = c.i;
@@ -349,15 +372,16 @@ void runCoderLanes(ChainSource& src, int max_lanes, std::atomic<uint64_t>* busy_
           L.out[l] = nullptr; L.advance[l] = 0;
         }
       }
-      if (wmode) runWords<true>(L, words, mask); else runWords<false>(L, words, mask);
-      for (int l = 0; l < kLanes; ++l) {
+      if (two && (mask >> kLanes)) { if (wmode) runWords<true, 2>(L, words, mask); else runWords<false, 2>(L, words, mask); }
+      else { if (wmode) runWords<true, 1>(L, words, mask); else runWords<false, 1>(L, words, mask); }
+      for (int l = 0; l < kAll; ++l) {
         if (!busy[l]) continue;
         CoderChain& c = chain[l];
         c.lo = L.lo[l]; c.size = L.size[l]; c.i = L.i[l];
         c.used = static_cast<size_t>(L.out[l] - c.out->data());
       }
     }
-    for (int l = 0; l < kLanes; ++l)                     // lanes with less than a word left: scalar tail
+    for (int l = 0; l < kAll; ++l)                       // lanes with less than a word left: scalar tail
       if (busy[l] && chain[l].e - chain[l].i < 16) finishLane(l);
     sourceDry = false;
   }

@@ -35,7 +35,7 @@ EXPORTS = [
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
     "bwtc_hip_get_kernel_timers", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
     "bwtc_hip_memcpy_to_host", "bwtc_hip_host_alloc", "bwtc_hip_host_free",
-    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_wavelet_latency", "bwtc_hip_n_lf", "bwtc_hip_bwt",
+    "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_wavelet_latency", "bwtc_hip_host_staging_bytes", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
     "bwtc_hip_inverse_bwt_block_device", "bwtc_hip_compress_bound",
     "bwtc_hip_huffman_encode_device", "bwtc_hip_huffman_encode", "bwtc_hip_transform_and_encode",
@@ -87,6 +87,7 @@ def load():
     L.bwtc_hip_wavelet_host_clock.argtypes = [_vp, _vp, _vp, _vp]
     L.bwtc_hip_wavelet_host_progress.argtypes = [_vp, _vp, _vp]
     L.bwtc_hip_wavelet_latency.argtypes = [_vp, _vp]
+    L.bwtc_hip_host_staging_bytes.argtypes = [_vp, _vp]
     L.bwtc_hip_numa_node.argtypes = [_vp]
     L.bwtc_hip_host_cpu_slice.argtypes = [ctypes.c_int, _u32, _u32, _vp, _u32]
     L.bwtc_hip_set_worker_cpus.argtypes = [_vp, _vp, _u32]
@@ -507,6 +508,14 @@ def host_cpu_slice(numa_node, rank, ranks):
     if n < 0:
         raise BwtcHipError("bwtc_hip_host_cpu_slice failed with code %d" % n)
     return [int(c) for c in buf[:n]]
+
+
+def host_staging_bytes():
+    """(now, peak) bytes of host staging memory this process holds for blocks under way."""
+    L = load()
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    L.bwtc_hip_host_staging_bytes(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def synth_into(kind, seed, out):

@@ -23,6 +23,7 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -219,6 +220,10 @@ class BlockFarm {
         uploaded = false;
       }
       int rc;
+      const bool debug = std::getenv("BWTC_HIP_DEBUG") != nullptr;
+      const auto tA = std::chrono::steady_clock::now();
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count(); };
       if (!uploaded) {
         rc = bwtc_hip_memcpy_to_device_async(w.ctx, w.d_in[cur.dev], w.h_in[cur.buf], cur.size);
         if (rc) return fail(rc, "bwtc_hip_memcpy_to_device_async");
@@ -244,8 +249,10 @@ class BlockFarm {
       uint32 lf[256], freqs[256];
       std::memset(freqs, 0, sizeof freqs);
       const uint32 n_lf = bwtc_hip_n_lf(cur.size, m_sp);
+      const auto tB = std::chrono::steady_clock::now();
       rc = bwtc_hip_bwt_block_device(w.ctx, d_blk, d_blk, cur.size, lf, n_lf, freqs);
       if (rc) return fail(rc, "bwtc_hip_bwt_block_device");
+      const auto tC = std::chrono::steady_clock::now();
       if (m_coder == 'H') {
         uint64_t n = 0;
         rc = bwtc_hip_huffman_encode_device(w.ctx, d_blk, cur.size, lf, n_lf, freqs, static_cast<uint8_t*>(w.d_comp),
@@ -257,6 +264,7 @@ class BlockFarm {
         deliver(cur.index, cur.size, out);
       } else {
         while (w.pending.size() >= m_depth) if (!collectOldest(w)) return;
+        const auto tD = std::chrono::steady_clock::now();
         Pending p;
         p.index = cur.index; p.size = cur.size;
         const uint64_t cap = bwtc_hip_compress_bound(m_maxBlock);
@@ -267,17 +275,23 @@ class BlockFarm {
         rc = bwtc_hip_wavelet_encode_device_prepare(w.ctx, d_blk, cur.size, lf, n_lf, freqs, m_threadsPerContext,
                                                     p.out, cap, &p.ticket);
         if (rc) { std::free(p.out); return fail(rc, "bwtc_hip_wavelet_encode_device_prepare"); }
+        const auto tE = std::chrono::steady_clock::now();
+        std::chrono::steady_clock::time_point tF;
         {
           // the block's place in the stream: after block index - 1, whichever context holds that one
           std::unique_lock<std::mutex> g(m_mu);
           m_cv.wait(g, [&] { return m_nextQueue == cur.index || m_failed; });
           if (m_failed) return;
           uint32_t after = 0;
+          tF = std::chrono::steady_clock::now();
           rc = bwtc_hip_wavelet_encode_queue(w.ctx, p.ticket, m_state, &after);
           if (rc == 0) { m_state = after; ++m_nextQueue; }
         }
         m_cv.notify_all();
         if (rc) { std::free(p.out); return fail(rc, "bwtc_hip_wavelet_encode_queue"); }
+        if (debug)
+          std::fprintf(stderr, "farm: block %zu: upload %.1f ms, transform %.1f, collect %.1f, prepare %.1f, turn %.1f, queue %.1f\n",
+                       cur.index, ms(tA, tB), ms(tB, tC), ms(tC, tD), ms(tD, tE), ms(tE, tF), ms(tF, std::chrono::steady_clock::now()));
         w.pending.push_back(p);
       }
       if (haveNext) { cur = next; have = true; uploaded = true; } else have = false;

@@ -243,6 +243,11 @@ int bwtc_hip_wavelet_host_progress(bwtc_hip_ctx* ctx, uint64_t* queued, uint64_t
  * to its finished record.  Blocks under way needed = that time / the time per block of the caller's
  * loop; a context keeps the limit it was created with (BWTC_HIP_WAVELET_DEPTH). */
 int bwtc_hip_wavelet_latency(bwtc_hip_ctx* ctx, double* mean_seconds);
+/* Host staging memory (page-locked where the system allows) held by this process for blocks under
+ * way -- packed streams and w-elements of every context -- now and at its highest so far: what a
+ * deployment has to provide per rank for the depth it runs (no reference counterpart; the reference
+ * holds one block, Compressor.cpp:100-108). */
+int bwtc_hip_host_staging_bytes(uint64_t* now, uint64_t* peak);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 /* A new wavelet stream with the main probability model of coder letter `coder`
  * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,

@@ -6,8 +6,8 @@ out=gpurun_out/r3_farm_timing
 mkdir -p $out
 python - <<'P'
 import sys
-sys.path.insert(0, "tests")
-import synth
+sys.path.insert(0, ".")
+from bwtc_amd import synth
 with open("/tmp/farm_in.bin", "wb") as f:
     blocks = [synth.gen_text(268435456, 100 + i).tobytes() for i in range(4)]
     for r in range(4):
