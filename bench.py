@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0,
                     help="'B': blocks under way at once.  0 = what the product picks for a stream as long as the one "
                          "this run codes (compress.cpp: 128 / 96 blocks -- the fused lane engines -- only for streams "
-                         "of 256 blocks and more, when the host has AVX-512 and 40 / 24 GB per rank; else 16)")
+                         "of 256 blocks and more, when the host has AVX-512 and 40 / 24 GB per rank; else 20, 16 below 40 GB)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
@@ -213,12 +213,13 @@ def main():
     world_hint = max(1, int(os.environ.get("WORLD_SIZE", "1")))
     # The depth the product would pick for this stream (bwtc_amd/host/compress.cpp): the fused host
     # engines keep a text block under way for seconds, so the deep pipelines (128 / 96 blocks) are
-    # only for streams of 256 blocks and more; everything shorter runs 16 deep.
+    # only for streams of 256 blocks and more; everything else runs 20 deep (16 with less than 40 GB).
     mem_per_rank = mem_available_gb() / world_hint
-    stream_blocks = max(args.warmup, 16) + args.steps
-    # (deep pipelines are for the host-model routes; with the models on the GPU 16 blocks are enough)
+    stream_blocks = max(args.warmup, 20) + args.steps
+    # (deep pipelines are for the host-model routes; with the models on the GPU 13-14 blocks carry the
+    # rate and 20 absorb the spread of the host half)
     deep = stream_blocks >= 256 and has_avx512() and os.environ.get("BWTC_HIP_MODELS") == "host"
-    auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 16
+    auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 20 if mem_per_rank >= 40 else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()

@@ -111,11 +111,12 @@ int main(int argc, char** argv) {
       }
       // ... and only where the adaptive models run on the worker threads (BWTC_HIP_MODELS=host): with
       // the models on the GPU -- the default, also for a stream farmed over several contexts -- a block
-      // is under way for 0.6 s and holds 1.2 GB of page-locked memory, 16 blocks are what it takes.
+      // is under way for 0.7 s and holds 1.3 GB of page-locked memory; 13-14 blocks are what the rate
+      // takes, 20 leave room for the spread of the host half (16: an occasional 2-3 ms wait per block).
       const char* mv = std::getenv("BWTC_HIP_MODELS");
       const bool host_models = (mv && std::strcmp(mv, "host") == 0) || enc != 'B';
       const bool deep = host_models && block_bytes >= 64e6 && stream_bytes / block_bytes >= 256.0 * n_ctx;
-      pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : 16;
+      pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : gb >= 40.0 ? 20 : 16;
     }
     if (pipeline > 256) pipeline = 256;
     char buf[16];
