@@ -493,65 +493,76 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ 
   }
 }
 
-// One workgroup of 16 waves: exclusive sum of aggA, aggB; exclusive max of aggC; totals ->
-// counts[0..1].  Every wave owns a contiguous chunk and walks it 64 entries at a time
-// (coalesced), first to get the chunk totals, then again with the carried prefix.
+// Exclusive sum of aggA, aggB; exclusive max of aggC; totals -> counts[0..1].  A workgroup of 16
+// waves owns 4096 consecutive entries, a wave 256 of them (four coalesced rows of 64, their twelve
+// loads in flight together).  PHASE 0 leaves every workgroup's totals in part[]; PHASE 1 adds up the
+// parts before it and scans its entries with that carried in.  (One workgroup walking all 131 072
+// tile aggregates of a 256 MiB block took 107-168 us, three times per block, with the GPU idle beside it.)
+constexpr u32 kRrScanChunk = 4096;
+template <int PHASE>
 __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ aggA,
                                                             u32* __restrict__ aggB,
                                                             u32* __restrict__ aggC, u32 ntiles,
+                                                            u32* __restrict__ part,
                                                             u32* __restrict__ counts) {
   __shared__ u32 s_tot[3][16];
+  __shared__ u32 s_base[3];
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x / kWave;
-  const u32 per = ((ntiles + 15u) / 16u + 63u) / 64u * 64u;   // chunk length, multiple of 64
-  const u32 b = wave * per;
-  const u32 e = min(b + per, ntiles);
-  u32 sa = 0, sb = 0, sc = 0;
-  // four rows of 64 entries per trip, their twelve loads in flight together (this one workgroup
-  // walks 131 072 tile aggregates for a 256 MiB block: one row per trip was 128 latencies in a row)
-  for (u32 i0 = b + lane; i0 < e; i0 += 4u * kWave) {
-    u32 a[4], bb[4], c[4];
+  const u32 b = blockIdx.x * kRrScanChunk + wave * 256u;
+  const u32 e = min(b + 256u, ntiles);
+  u32 va[4], vb[4], vc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = i0 + (u32)r * kWave;
-      const bool ok = i < e;
-      a[r] = ok ? aggA[i] : 0u; bb[r] = ok ? aggB[i] : 0u; c[r] = ok ? aggC[i] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { sa += a[r]; sb += bb[r]; sc = max(sc, c[r]); }
+  for (int r = 0; r < 4; ++r) {
+    const u32 i = b + (u32)r * kWave + lane;
+    const bool ok = i < e;
+    va[r] = ok ? aggA[i] : 0u; vb[r] = ok ? aggB[i] : 0u; vc[r] = ok ? aggC[i] : 0u;
   }
+  u32 sa = 0, sb = 0, sc = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { sa += va[r]; sb += vb[r]; sc = max(sc, vc[r]); }
   sa = wave_scan_add(sa, lane); sb = wave_scan_add(sb, lane); sc = wave_scan_max(sc, lane);
   if (lane == kWave - 1) { s_tot[0][wave] = sa; s_tot[1][wave] = sb; s_tot[2][wave] = sc; }
+  if (PHASE == 1 && wave == 0) {
+    // what the workgroups before this one hold (at most a few hundred parts), and the totals
+    u32 pa = 0, pb = 0, pc = 0, ta = 0, tb = 0;
+    for (u32 g = lane; g < gridDim.x; g += kWave) {
+      const u32 x = part[3u * g], y = part[3u * g + 1u], z = part[3u * g + 2u];
+      ta += x; tb += y;
+      if (g < blockIdx.x) { pa += x; pb += y; pc = max(pc, z); }
+    }
+    pa = wave_scan_add(pa, lane); pb = wave_scan_add(pb, lane); pc = wave_scan_max(pc, lane);
+    ta = wave_scan_add(ta, lane); tb = wave_scan_add(tb, lane);
+    if (lane == kWave - 1) {
+      s_base[0] = pa; s_base[1] = pb; s_base[2] = pc;
+      if (blockIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
+    }
+  }
   __syncthreads();
-  u32 ca = 0, cb = 0, cc = 0, ta = 0, tb = 0;
-  for (u32 w = 0; w < 16; ++w) {
-    if (w < wave) { ca += s_tot[0][w]; cb += s_tot[1][w]; cc = max(cc, s_tot[2][w]); }
-    ta += s_tot[0][w]; tb += s_tot[1][w];
-  }
-  for (u32 i0 = b; i0 < e; i0 += 4u * kWave) {
-    u32 va[4], vb[4], vc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = i0 + (u32)r * kWave + lane;
-      const bool ok = i < e;
-      va[r] = ok ? aggA[i] : 0u; vb[r] = ok ? aggB[i] : 0u; vc[r] = ok ? aggC[i] : 0u;
+  if (PHASE == 0) {
+    if (threadIdx.x == 0) {
+      u32 ta = 0, tb = 0, tc = 0;
+      for (u32 w = 0; w < 16; ++w) { ta += s_tot[0][w]; tb += s_tot[1][w]; tc = max(tc, s_tot[2][w]); }
+      part[3u * blockIdx.x] = ta; part[3u * blockIdx.x + 1u] = tb; part[3u * blockIdx.x + 2u] = tc;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = i0 + (u32)r * kWave + lane;
-      const u32 ia = wave_scan_add(va[r], lane), ib = wave_scan_add(vb[r], lane), ic = wave_scan_max(vc[r], lane);
-      const u32 pc = __shfl_up(ic, 1, kWave);
-      if (i < e) {
-        aggA[i] = ca + ia - va[r];
-        aggB[i] = cb + ib - vb[r];
-        aggC[i] = max(cc, lane ? pc : 0u);
-      }
-      ca += __shfl(ia, kWave - 1, kWave);
-      cb += __shfl(ib, kWave - 1, kWave);
-      cc = max(cc, __shfl(ic, kWave - 1, kWave));
-    }
+    return;
   }
-  if (threadIdx.x == 0) { counts[0] = ta; counts[1] = tb; }
+  u32 ca = s_base[0], cb = s_base[1], cc = s_base[2];
+  for (u32 w = 0; w < wave; ++w) { ca += s_tot[0][w]; cb += s_tot[1][w]; cc = max(cc, s_tot[2][w]); }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const u32 i = b + (u32)r * kWave + lane;
+    const u32 ia = wave_scan_add(va[r], lane), ib = wave_scan_add(vb[r], lane), ic = wave_scan_max(vc[r], lane);
+    const u32 pc = __shfl_up(ic, 1, kWave);
+    if (i < e) {
+      aggA[i] = ca + ia - va[r];
+      aggB[i] = cb + ib - vb[r];
+      aggC[i] = max(cc, lane ? pc : 0u);
+    }
+    ca += __shfl(ia, kWave - 1, kWave);
+    cb += __shfl(ib, kWave - 1, kWave);
+    cc = max(cc, __shfl(ic, kWave - 1, kWave));
+  }
 }
 
 // PAIRS: instead of scattering rank[s] = nr from here (one random 4-byte write per element,
@@ -894,7 +905,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_small, off_ent, off_comp, off_sweep, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -923,6 +934,7 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_aggA = take(rr_tiles * 4);
   a.off_aggB = take(rr_tiles * 4);
   a.off_aggC = take(rr_tiles * 4);
+  a.off_agg_part = take((rr_tiles / 4096 + 2) * 12);
   a.off_small = take(1024 * 4);
   a.off_ent = take(2u << 20);
   a.off_comp = take(huffman_compress_bound(cap));
@@ -969,6 +981,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_aggA = reinterpret_cast<u32*>(base + a.off_aggA);
   d_aggB = reinterpret_cast<u32*>(base + a.off_aggB);
   d_aggC = reinterpret_cast<u32*>(base + a.off_aggC);
+  d_agg_part = reinterpret_cast<u32*>(base + a.off_agg_part);
   d_small = reinterpret_cast<u32*>(base + a.off_small);
   d_ent = base + a.off_ent;
   d_comp = base + a.off_comp;
@@ -1214,7 +1227,11 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
                                 short_len, kmask, d_aggA, d_aggB, d_aggC);
   else hipLaunchKernelGGL((k_rerank_reduce<K, INIT, false>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
                           short_len, kmask, d_aggA, d_aggB, d_aggC);
-  hipLaunchKernelGGL(k_rerank_scan_tiles, dim3(1), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, counts);
+  {
+    const u32 parts = ceil_div(tiles, kRrScanChunk);
+    hipLaunchKernelGGL(k_rerank_scan_tiles<0>, dim3(parts), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, d_agg_part, counts);
+    hipLaunchKernelGGL(k_rerank_scan_tiles<1>, dim3(parts), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, d_agg_part, counts);
+  }
   // how much stays active decides the route, so the counts are read before the apply kernel
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(wait());

@@ -53,21 +53,34 @@ struct PinnedGauge {                                // bytes of host staging hel
   static PinnedGauge& get() { static PinnedGauge g; return g; }
 };
 
-// Page-locked host memory, the fast way: transparent huge pages, touched by the calling thread (on its
-// own NUMA node, outside the driver), then registered -- 50 ms per 1.2 GB where hipHostMalloc takes
-// 200 ms, most of it under the driver's lock, and 130 ms more to free (scripts/dev/pin_bench.cpp; the
-// copies run at the same 57 GB/s).  *kind: 2 registered, 1 hipHostMalloc, 0 nothing could be locked.
+// Page-locked host memory, the fast way: an anonymous mapping of transparent huge pages, touched by the
+// calling thread (on its own NUMA node, outside the driver), then registered -- 50 ms per 1.2 GB where
+// hipHostMalloc takes 200 ms, most of it under the driver's lock, and 130 ms more to free
+// (scripts/dev/pin_bench.cpp; the copies run at the same 57 GB/s).  Only for buffers of 32 MiB and more
+// (the w-elements and staging buffers of full-size blocks): a mapping of its own, never memory carved
+// from the allocator's heap, so nothing else ever lives in, next to or after a registered range.
+// *kind: 2 registered mapping, 1 hipHostMalloc, 0 nothing could be locked.
+constexpr size_t kLockedHugePage = (size_t)2 << 20;
+constexpr size_t kLockedMapFrom = (size_t)32 << 20;
+inline size_t lockedMapBytes(size_t n) { return (n + kLockedHugePage - 1) / kLockedHugePage * kLockedHugePage; }
 inline void* lockedHostAlloc(size_t n, int* kind) {
-  const size_t huge = (size_t)2 << 20;
   void* q = nullptr;
-  if (n >= huge && !std::getenv("BWTC_HIP_NO_HUGE_PAGES")) {
-    const size_t bytes = (n + huge - 1) / huge * huge;
-    if (posix_memalign(&q, huge, bytes) == 0) {
+  if (n >= kLockedMapFrom && !std::getenv("BWTC_HIP_NO_HUGE_PAGES")) {
+    const size_t bytes = lockedMapBytes(n);
+    // over-map by one huge page and trim to a 2 MiB boundary
+    void* raw = mmap(nullptr, bytes + kLockedHugePage, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (raw != MAP_FAILED) {
+      const uintptr_t r = reinterpret_cast<uintptr_t>(raw);
+      const uintptr_t al = (r + kLockedHugePage - 1) / kLockedHugePage * kLockedHugePage;
+      if (al > r) (void)munmap(raw, al - r);
+      const size_t tail = (r + bytes + kLockedHugePage) - (al + bytes);
+      if (tail) (void)munmap(reinterpret_cast<void*>(al + bytes), tail);
+      q = reinterpret_cast<void*>(al);
       (void)madvise(q, bytes, MADV_HUGEPAGE);
       for (size_t i = 0; i < bytes; i += 4096) static_cast<volatile char*>(q)[i] = 0;
       if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) { *kind = 2; return q; }
       (void)hipGetLastError();
-      std::free(q);
+      (void)munmap(q, bytes);
       q = nullptr;
     }
   }
@@ -76,10 +89,13 @@ inline void* lockedHostAlloc(size_t n, int* kind) {
   *kind = 0;
   return nullptr;
 }
-inline void lockedHostFree(void* p, int kind) {
+// `n`: the size the buffer was asked for (kind 2 needs it to unmap)
+inline void lockedHostFree(void* p, int kind, size_t n) {
   if (!p) return;
-  if (kind == 2) { (void)hipHostUnregister(p); std::free(p); }
-  else if (kind == 1) (void)hipHostFree(p);
+  if (kind == 2) {
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return; }   // still known to the device: the mapping stays
+    (void)munmap(p, lockedMapBytes(n));
+  } else if (kind == 1) (void)hipHostFree(p);
   else std::free(p);
 }
 
@@ -108,7 +124,7 @@ class PinnedBytes {
   size_t size() const { return n_; }
  private:
   void release() {
-    if (p_) { lockedHostFree(p_, locked_); PinnedGauge::get().sub(n_); }
+    if (p_) { lockedHostFree(p_, locked_, n_); PinnedGauge::get().sub(n_); }
     p_ = nullptr; n_ = 0;
   }
   uint8_t* p_;
@@ -256,6 +272,7 @@ struct BwtEngine {
   u32* d_aggA = nullptr;   // rerank tile aggregates
   u32* d_aggB = nullptr;
   u32* d_aggC = nullptr;
+  u32* d_agg_part = nullptr;   // totals per 4096 tile aggregates (k_rerank_scan_tiles)
   u32* d_sweep = nullptr;  // chained radix sort: histograms, bases, tickets (SweepWs::small_words)
   bool use_sweep = false;  // BWTC_HIP_SORT=sweep selects the chained single-read passes (measured
                            // slower on MI355X than the XCD-contiguous three-kernel passes)

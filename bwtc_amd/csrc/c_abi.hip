@@ -44,7 +44,7 @@ static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int
 
 // how every buffer handed out by bwtc_hip_host_alloc was locked (see lockedHostAlloc)
 static std::mutex& host_allocs_mu() { static std::mutex m; return m; }
-static std::map<void*, int>& host_allocs() { static std::map<void*, int> m; return m; }
+static std::map<void*, std::pair<int, uint64_t> >& host_allocs() { static std::map<void*, std::pair<int, uint64_t> > m; return m; }
 
 extern "C" {
 
@@ -129,20 +129,20 @@ void* bwtc_hip_host_alloc(bwtc_hip_ctx* ctx, uint64_t bytes) {
   void* p = bwtc_hip::lockedHostAlloc(bytes ? bytes : 1, &kind);
   if (!p) return nullptr;
   std::lock_guard<std::mutex> g(host_allocs_mu());
-  host_allocs()[p] = kind;
+  host_allocs()[p] = std::make_pair(kind, bytes ? bytes : 1);
   return p;
 }
 void bwtc_hip_host_free(bwtc_hip_ctx* ctx, void* p) {
   if (!ctx || !p || hipSetDevice(ctx->eng.device) != hipSuccess) return;
-  int kind = 1;
+  std::pair<int, uint64_t> how;
   {
     std::lock_guard<std::mutex> g(host_allocs_mu());
-    std::map<void*, int>::iterator it = host_allocs().find(p);
+    std::map<void*, std::pair<int, uint64_t> >::iterator it = host_allocs().find(p);
     if (it == host_allocs().end()) return;          // not one of ours
-    kind = it->second;
+    how = it->second;
     host_allocs().erase(it);
   }
-  bwtc_hip::lockedHostFree(p, kind);
+  bwtc_hip::lockedHostFree(p, how.first, static_cast<size_t>(how.second));
 }
 int bwtc_hip_memcpy_to_device_async(bwtc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
   if (!ctx || (!d_dst && bytes) || (!src && bytes)) return -1;

@@ -34,3 +34,37 @@ def varied_blocks(count, max_size, seed):
         d = np.ascontiguousarray(d, dtype=np.uint8)
         if d.size:
             yield case, kind, d
+
+
+def _synth():
+    from bwtc_amd import synth
+    return synth
+
+
+def structured(rng, n):
+    """Inputs that stress the suffix sorter: long repeats, periods, tiny alphabets, Fibonacci words."""
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        d = np.full(n, int(rng.integers(0, 256)))
+    elif kind == 1:
+        p = rng.integers(0, 256, int(rng.integers(1, 40)))
+        d = np.tile(p, n // p.size + 1)[:n].copy()
+        d[rng.random(n) < float(rng.uniform(0, 0.002))] = int(rng.integers(0, 256))
+    elif kind == 2:
+        a, b = [0], [0, 1]
+        while len(b) < n:
+            a, b = b, b + a
+        d = np.array(b[:n]) + int(rng.integers(0, 200))
+    elif kind == 3:
+        d = rng.integers(0, int(rng.integers(2, 5)), n)
+    elif kind == 4:
+        base = rng.integers(0, 256, max(1, n // int(rng.integers(2, 50))))
+        d = np.concatenate([base] * (n // base.size + 1))[:n].copy()
+        k = int(rng.integers(0, 20))
+        if k:
+            d[rng.integers(0, n, k)] = rng.integers(0, 256, k)
+    elif kind == 5:
+        d = _synth().gen_text(n, int(rng.integers(1, 1 << 30)))
+    else:
+        d = _synth().gen_dna(n, int(rng.integers(1, 1 << 30)))
+    return kind, np.ascontiguousarray(d, dtype=np.uint8)

@@ -218,6 +218,44 @@ def test_wavelet_B_overlapped_blocks_equal_the_sequential_stream(hip_ctx, oracle
     assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes()
 
 
+def test_wavelet_B_short_structured_streams_through_the_pipeline(hip_ctx, oracle):
+    """Twenty-four short streams (all-equal bytes, periods with defects, Fibonacci words, tiny
+    alphabets, repeats, text, DNA; tests/blockgen.py) cut into blocks of random size, up to twelve
+    under way at once through _begin/_end: block sizes from a few hundred bytes up change the route
+    from block to block (host tree builder / device streams, models on the device), buffers are
+    recycled across sizes, and the carried state runs through all of it.  Each stream byte-equal to
+    the oracle's sequential encoder.  (The fixed-seed part of scripts/fuzz_gpu_parity.py.)"""
+    import blockgen
+    rng = np.random.default_rng(424242)
+    for case in range(24):
+        total = int(rng.integers(1000, 3 << 20))
+        kind, d = blockgen.structured(rng, total)
+        bs = int(rng.integers(max(200, total // 40), max(400, total)))
+        hip_ctx.wavelet_reset()
+        pending, records = [], []
+
+        def collect():
+            t, out, n = pending.pop(0)
+            m = hip_ctx.wavelet_encode_end(t)
+            records.append(_packed(n) + _packed(1) + b"\x00" + out[:m].tobytes())
+        for off in range(0, d.size, bs):
+            blk = d[off:off + bs]
+            if len(pending) >= 12:
+                collect()
+            d_in = hip_ctx.dmalloc(blk.size + 16)
+            try:
+                hip_ctx.to_device(d_in, blk)
+                lf, freqs = hip_ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+                out = np.zeros(hip_ctx.compress_bound(blk.size), np.uint8)
+                pending.append((hip_ctx.wavelet_encode_device_begin(d_in, blk.size, lf, freqs, out, threads=4), out, blk.size))
+            finally:
+                hip_ctx.dfree(d_in)
+        while pending:
+            collect()
+        stream = b"B" + b"".join(records) + b"\x00"
+        assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes(), (case, kind, total, bs)
+
+
 def test_wavelet_B_pipeline_limits_and_misuse(oracle):
     """Depth limit and ticket handling of _begin/_end: an unknown ticket is refused, a finished
     but uncollected oldest block makes a further _begin return -6 instead of waiting forever,
