@@ -256,6 +256,52 @@ def test_wavelet_B_short_structured_streams_through_the_pipeline(hip_ctx, oracle
         assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes(), (case, kind, total, bs)
 
 
+@pytest.mark.parametrize("models", ["device", "host"])
+def test_wavelet_B_prepare_queue_flow_on_one_context(models, oracle, monkeypatch):
+    """bwtc_hip_wavelet_encode_device_prepare / _queue as a caller that farms a stream uses them
+    (bwtc_hip_farm.hpp), here on one context: the carried state goes in at _queue and comes back
+    at once (the device passes of a prepared block leave it for all eight start states).  Two
+    blocks prepared before the first is queued: the earlier one loses its turn in the device
+    workspace and is modelled by the worker threads -- same stream.  Byte-equal to the oracle's
+    sequential encoder, with the models on the device and on the host."""
+    from bwtc_amd import hip
+    if models == "host":
+        monkeypatch.setenv("BWTC_HIP_MODELS", "host")
+    d = np.concatenate([synth.gen_text(3 << 20, 21), synth.gen_dna(1 << 20, 5), synth.gen_text(1 << 20, 22)])
+    bs = 1 << 20
+    ctx = hip.Context(device=0, max_block_size=bs + 1024)
+    try:
+        blocks = [d[o:o + bs] for o in range(0, d.size, bs)]
+        prepared = []
+
+        def prepare(blk):
+            d_in = ctx.dmalloc(blk.size + 16)
+            try:
+                ctx.to_device(d_in, blk)
+                lf, freqs = ctx.bwt_block_device(d_in, d_in, blk.size, 8)
+                out = np.zeros(ctx.compress_bound(blk.size), np.uint8)
+                prepared.append((ctx.wavelet_encode_device_prepare(d_in, blk.size, lf, freqs, out, threads=4), out, blk.size))
+            finally:
+                ctx.dfree(d_in)
+        state, joined, stream = 4, 0, b"B"                # FSM8's state in a new stream
+        order = [2, 1, 1, 1]                              # blocks prepared before the next _queue calls
+        at = 0
+        for burst in order:
+            for _ in range(burst):
+                prepare(blocks[at]); at += 1
+            while joined < len(prepared):
+                state = ctx.wavelet_encode_queue(prepared[joined][0], state)
+                joined += 1
+        assert at == len(blocks)
+        for t, out, n in prepared:
+            m = ctx.wavelet_encode_end(t)
+            stream += _packed(n) + _packed(1) + b"\x00" + out[:m].tobytes()
+        stream += b"\x00"
+        assert stream == oracle.oracle_compress_B(d, bs, 8).tobytes()
+    finally:
+        ctx.close()
+
+
 def test_wavelet_B_pipeline_limits_and_misuse(oracle):
     """Depth limit and ticket handling of _begin/_end: an unknown ticket is refused, a finished
     but uncollected oldest block makes a further _begin return -6 instead of waiting forever,
