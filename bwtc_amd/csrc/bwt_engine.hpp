@@ -217,7 +217,6 @@ struct DeviceWaveletJob : WaveletJob {
   u32* h_tail = nullptr;               //   {state after the block, error flags, elements counted} (in w_owner, behind the elements)
   u32 gm_state_in = 0;                 //   the carried state the device passes were given
   GmPass gm;                           // farmed streams: the passes' first part is done, the rest waits for the state (_queue)
-  bool failed = false;                 // the host-callback join could not be made (out of memory): _end reports it
   // between wavelet_encode_prepare and wavelet_encode_queue
   bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
   bool host_route = false;             // coded by encodeSections at queue time instead

@@ -206,7 +206,24 @@ int wavelet_encode_begin(BwtEngine& e, const u8* d_bwt, u32 size, const u32* lf,
 // Second half of _begin: the block joins its stream.  state_in = the main model's carried state
 // after the previous block of the stream (whichever context coded that one), *state_out = the
 // state after this block.
+static int wavelet_encode_queue_unguarded(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out);
+
+// A block whose entry into the stream failed half way is marked failed and done: _end then reports the
+// error instead of waiting for a record that nobody is making.
 int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out) {
+  const int rc = wavelet_encode_queue_unguarded(e, ticket, state_in, state_out);
+  if (rc) {
+    std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.find(ticket);
+    if (it != e.jobs.end() && it->second->queued) {
+      DeviceWaveletJob& job = *it->second;
+      std::lock_guard<std::mutex> g(job.mu);
+      if (!job.done) { job.failed = true; job.done = true; job.cv.notify_all(); }
+    }
+  }
+  return rc;
+}
+
+static int wavelet_encode_queue_unguarded(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out) {
   std::map<u64, std::shared_ptr<DeviceWaveletJob> >::iterator it = e.jobs.find(ticket);
   if (it == e.jobs.end() || !state_out) return -1;
   std::shared_ptr<DeviceWaveletJob> jobp = it->second;
@@ -248,7 +265,10 @@ int wavelet_encode_queue(BwtEngine& e, u64 ticket, u32 state_in, u32* state_out)
         job.w = nullptr;
         if (!job.prob.reserve(static_cast<size_t>(n_coded) + 8)) { job.failed = true; HostPipeline::finishNow(job); return; }
       }
-      (void)j->pipe->queue(j->job, j->state_in, 'B');
+      // (the state handed on came from the device's state maps: a host half that ends elsewhere means
+      // the stream after this block is wrong -- reported at _end, never passed over)
+      const u32 handed_on = job.w_end_state;
+      (void)j->pipe->queue(j->job, j->state_in, 'B', &handed_on);
     }, j);
     if (hrc != hipSuccess) { delete j; return -3; }
     return 0;

@@ -145,7 +145,7 @@ void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
   pool_.submit(jobp->rank, next);
 }
 
-uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t fsm8_state, char model) {
+uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t fsm8_state, char model, const uint32_t* expect_end) {
   WaveletJob& job = *jobp;
   if (job.w) {
     // The models ran on the device: what is left are the sections' range-coder chains, each on its
@@ -212,6 +212,7 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
   }
   job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes, fsm8_state, model));
   const uint32_t next_state = job.coder->endState();
+  if (expect_end && *expect_end != next_state) job.failed = true;
   job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());
   job.t_queued = std::chrono::steady_clock::now();
   job.models_left = job.coder->modelTasks();

@@ -218,6 +218,8 @@ struct WaveletJob : std::enable_shared_from_this<WaveletJob> {
   const uint16_t* w = nullptr;                       // modelled on the device: bit << 15 | probability of the coded bit,
                                                      //   per coded element (wavelet_gpu_models.hpp); no model tasks then
   uint32_t w_end_state = 4;                          //   and the carried state after the block
+  bool failed = false;                 // the block could not be coded as its stream needs (out of memory at the join,
+                                       // a host half that ends in another state than the one handed on): _end reports it
   std::mutex mu;
   std::condition_variable cv;
   size_t models_left = 0, sections_left = 0;
@@ -256,7 +258,9 @@ class HostPipeline {
   // job: record (header part), plan, coded_pos, codes, prob (room for the coded elements), rank and
   // user_out/user_cap set.  Builds the block's coder from the carried model state and queues its
   // work; returns the state to carry into the next block.
-  uint32_t queue(const std::shared_ptr<WaveletJob>& job, uint32_t fsm8_state, char model);
+  // expect_end (optional): the state the caller has already handed to the next block; a block whose
+  // models end elsewhere is marked failed before any of its tasks runs
+  uint32_t queue(const std::shared_ptr<WaveletJob>& job, uint32_t fsm8_state, char model, const uint32_t* expect_end = nullptr);
   static void wait(WaveletJob& job);
   // a block without coded elements (or coded elsewhere): closes the record right away
   static void finishNow(WaveletJob& job);
