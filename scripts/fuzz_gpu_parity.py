@@ -8,7 +8,9 @@ sweeps are the fixed-seed subset of this).  Three phases, each against the oracl
   4. the GPU inverse transform of the product's own transform (gives the input back);
   5. `compress` -> `uncompress` round trips of the command-line tools (host decoders + GPU inverse),
      both coders, and the 'B' / 'H' stream against the oracle's whole-stream encoder.
-usage: fuzz_gpu_parity.py [seconds per phase] [seed] [phases, e.g. 23]      exit code 1 if anything differed."""
+usage: fuzz_gpu_parity.py [seconds per phase] [seed] [phases, e.g. 23]      exit code 1 if anything differed.
+FUZZ_BIG=1: phase 2 with streams of 32-96 MB in blocks of 9-33 MB (the page-locked buffers of such blocks are
+registered mappings, recycled across sizes)."""
 import os
 import sys
 import time
@@ -40,7 +42,8 @@ def main():
     phases = sys.argv[3] if len(sys.argv) > 3 else "12345"
     oracle_lib.build()
     rng = np.random.default_rng(seed)
-    ctx = hip.Context(device=0, max_block_size=(8 << 20) + 1024)
+    big = os.environ.get("FUZZ_BIG") == "1"
+    ctx = hip.Context(device=0, max_block_size=((40 if big else 8) << 20) + 1024)
     bad = 0
     print("seed", seed, flush=True)
 
@@ -65,9 +68,9 @@ def main():
     # ---- 2: multi-block 'B' streams through the overlapped pipeline ---------------------------------
     t0, n2 = time.time(), 0
     while "2" in phases and time.time() - t0 < budget:
-        total = int(rng.integers(1000, 6 << 20))
+        total = int(rng.integers(32 << 20, 96 << 20)) if big else int(rng.integers(1000, 6 << 20))
         kind, d = blockgen.structured(rng, total)
-        bs = int(rng.integers(max(200, total // 40), max(400, total)))
+        bs = int(rng.integers(9 << 20, 33 << 20)) if big else int(rng.integers(max(200, total // 40), max(400, total)))
         print("stream", n2, "kind", kind, "total", total, "block", bs, flush=True)
         ctx.wavelet_reset()
         pending, records = [], []
