@@ -455,6 +455,9 @@ void wavelet_pipeline_release(BwtEngine& e) {
     std::fprintf(stderr, "wavelet pipeline: %llu blocks; host time in models %.3f s, in range coders %.3f s (summed over threads)\n",
                  (unsigned long long)e.pipeline->clock.blocks.load(), e.pipeline->clock.model_ns.load() * 1e-9,
                  e.pipeline->clock.coder_ns.load() * 1e-9);
+  if (e.pipeline && std::getenv("BWTC_HIP_DEBUG") && e.pipeline->clock.scalar_ns.load())
+    std::fprintf(stderr, "wavelet pipeline: %.3f s of the range coders' time in the scalar tasks of the longest sections, the rest in the lane engines\n",
+                 e.pipeline->clock.scalar_ns.load() * 1e-9);
   delete e.pipeline;                              // joins the workers (engines retire when nothing is queued)
   e.pipeline = nullptr;
   e.codes_pool.clear();

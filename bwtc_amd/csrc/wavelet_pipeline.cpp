@@ -181,7 +181,9 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
           WaveletJob& j = *jobp;
           const auto t0 = std::chrono::steady_clock::now();
           j.coder->codeSectionW(k, j.w, &j.outs);
-          clock.coder_ns += since(t0);
+          const uint64_t dt = since(t0);
+          clock.coder_ns += dt;
+          clock.scalar_ns += dt;
           bool fin;
           { std::lock_guard<std::mutex> g(j.mu); fin = --j.sections_left == 0; }
           if (fin) finish(j);

@@ -33,6 +33,7 @@ namespace bwtc_hip {
 // host time spent in the two stages (summed over threads), for BWTC_HIP_DEBUG
 struct StageClock {
   std::atomic<uint64_t> model_ns{0}, coder_ns{0}, blocks{0}, finished{0};
+  std::atomic<uint64_t> scalar_ns{0};               // the part of coder_ns spent in the scalar tasks of device-modelled blocks
   std::atomic<uint64_t> latency_ns{0};             // begun -> record finished, summed over the finished blocks
   std::atomic<int> unfinished{0};      // blocks begun and not yet finished by the workers
 };
