@@ -231,6 +231,11 @@ def main():
     # buffers they share stay on the NUMA node of the rank's GPU, on CPUs no other rank uses.
     numa_node = ctx.numa_node()
     my_cpus = farm.cpu_slice(numa_node) if os.environ.get("BWTC_BENCH_AFFINITY", "1") != "0" else []
+    if os.environ.get("BWTC_BENCH_CPULIST"):             # experiments: an explicit list, e.g. "64-79,192"
+        my_cpus = []
+        for part in os.environ["BWTC_BENCH_CPULIST"].split(","):
+            a, _, b = part.partition("-")
+            my_cpus += list(range(int(a), int(b or a) + 1))
     if my_cpus:
         ctx.set_worker_cpus(my_cpus)
         os.sched_setaffinity(0, my_cpus)
