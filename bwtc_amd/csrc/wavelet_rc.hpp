@@ -23,7 +23,12 @@ struct CoderChain {
   uint64_t i, e;
   std::vector<uint8_t>* out;
   size_t used;
-  void start(uint64_t b, uint64_t end, std::vector<uint8_t>* o) { lo = 0; size = 0xFFFFFFFEu; i = b; e = end; out = o; used = o->size(); }
+  void start(uint64_t b, uint64_t end, std::vector<uint8_t>* o) {
+    lo = 0; size = 0xFFFFFFFEu; i = b; e = end; out = o; used = o->size();
+    // room for a byte per seven elements at once (a text block's sections take one per ten): the 27 MB of
+    // the longest section were otherwise reached through a dozen reallocations, each copying what was there
+    if (end - b >= (1u << 16)) o->reserve(used + (end - b) / 7 + 4096);
+  }
   uint8_t* room(uint64_t elements) {                                   // at most four bytes leave the coder per bit
     if (out->size() - used < 4 * elements + 8) out->resize(used + 4 * elements + 8 + out->size() / 2);
     return out->data() + used;
