@@ -206,7 +206,14 @@ int bwtc_hip_wavelet_encode_end(bwtc_hip_ctx* ctx, uint64_t ticket, uint64_t* ou
  * first block of a stream; the reference's WaveletEncoder carries it inside its m_probModel,
  * probmodels/FSM.hpp:196-205), *state_out the state after this block, to be passed to the _queue
  * of the next block on whichever context holds it.  _queue calls of a stream are made in block
- * order; each returns at once.  _begin = _prepare + _queue with the context's own state. */
+ * order; each returns at once.  _begin = _prepare + _queue with the context's own state.
+ * With the adaptive models on the device (the default for 'B') _prepare returns when its device
+ * half is done -- it leaves the state after the block for each of the eight states the block can
+ * start in, so that _queue has nothing to wait for -- and _queue launches the passes that depend
+ * on the state; the block joins the context's worker threads when its elements have reached the
+ * host.  A block prepared while another prepared block of the same context has not been queued
+ * yet takes that one's place in the device workspace: the earlier block's models then run on the
+ * worker threads (same bytes). */
 int bwtc_hip_wavelet_encode_device_prepare(bwtc_hip_ctx* ctx, const uint8_t* d_bwt, uint32_t size,
                                            const uint32_t* lf, uint32_t n_lf, const uint32_t* freqs,
                                            uint32_t threads, uint8_t* out, uint64_t out_cap,
