@@ -44,9 +44,23 @@ static __global__ __launch_bounds__(1024) void k_scan_single(u32* __restrict__ d
   if (total_out && threadIdx.x == 0) *total_out = total;
 }
 
+// RAW: `partial` holds the tiles' totals as k_scan_reduce left them, and every workgroup adds up the
+// ones before its own (at most kScanRawTiles words from the L2) instead of a one-workgroup scan between
+// the two launches: the radix sorter's offset tables are 2048 tiles, scanned 33 times per block, and
+// that launch was 6 us of one workgroup with the GPU idle around it.
+constexpr u32 kScanRawTiles = 4096;
+template <bool RAW>
 static __global__ __launch_bounds__(kScanTPB) void k_scan_apply(u32* __restrict__ data,
                                                          const u32* __restrict__ partial, u64 n) {
   __shared__ u32 scratch[kScanTPB / kWave + 1];
+  u32 before = 0;
+  if (RAW) {
+    u32 acc = 0;
+    for (u32 i = threadIdx.x; i < blockIdx.x; i += kScanTPB) acc += partial[i];
+    block_scan_excl_add<kScanTPB>(acc, scratch, &before);          // every thread gets the total
+  } else {
+    before = partial[blockIdx.x];
+  }
   const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanE;
   u32 v[kScanE];
   const bool full = base + kScanE <= n;
@@ -65,7 +79,7 @@ static __global__ __launch_bounds__(kScanTPB) void k_scan_apply(u32* __restrict_
 #pragma unroll
   for (int i = 0; i < kScanE; ++i) s += v[i];
   u32 total;
-  u32 off = block_scan_excl_add<kScanTPB>(s, scratch, &total) + partial[blockIdx.x];
+  u32 off = block_scan_excl_add<kScanTPB>(s, scratch, &total) + before;
 #pragma unroll
   for (int i = 0; i < kScanE; ++i) { u32 t = v[i]; v[i] = off; off += t; }
   if (full) {
@@ -200,8 +214,12 @@ static inline void exclusive_scan_u32(u32* data, u64 n, u32* partial, hipStream_
     return;
   }
   hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(kScanTPB), 0, st, data, partial, n);
+  if (tiles <= kScanRawTiles) {
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3(tiles), dim3(kScanTPB), 0, st, data, partial, n);
+    return;
+  }
   hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, partial, tiles, (u32*)nullptr);
-  hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanTPB), 0, st, data, partial, n);
+  hipLaunchKernelGGL(k_scan_apply<false>, dim3(tiles), dim3(kScanTPB), 0, st, data, partial, n);
 }
 
 }  // namespace bwtc_hip
