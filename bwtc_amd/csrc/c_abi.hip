@@ -347,6 +347,8 @@ static unsigned usable_cpus() {
   return n;
 }
 
+uint32_t bwtc_hip_host_usable_cpus(void) { return usable_cpus(); }
+
 static unsigned pick_threads(uint32_t threads) {
   if (threads) return threads;
   // all of them: the thread that feeds the GPU sleeps while it waits (BwtEngine::wait), and what

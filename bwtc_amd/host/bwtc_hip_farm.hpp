@@ -38,25 +38,30 @@ namespace bwtc {
 
 class BlockFarm {
  public:
+  enum { kStaging = 4 };                 // page-locked input buffers per worker
   // coder: 'H' or a wavelet letter.  depth = blocks one context keeps between the device half and
   // the collected record ('B'); host threads are split evenly between the contexts.
   BlockFarm(const std::vector<int>& devices, uint32 maxBlock, char coder, uint32 startingPoints, unsigned depth = 12)
       : m_maxBlock(maxBlock), m_coder(coder), m_sp(startingPoints), m_depth(depth ? depth : 1), m_submitted(0),
         m_inputDone(false), m_nextQueue(0), m_state(4), m_nextWrite(0), m_failed(false) {
     if (devices.empty()) { std::fprintf(stderr, "bwtc-hip: block farm without devices\n"); std::exit(1); }
-    unsigned cpus = std::thread::hardware_concurrency();
-    if (cpus == 0) cpus = 1;
+    // (what the process may keep busy -- the cgroup's quota counts, not only the hardware threads: a
+    // farm that started 64 workers per context inside a 16-CPU quota was throttled as a whole)
+    const unsigned cpus = std::max(1u, (unsigned)bwtc_hip_host_usable_cpus());
     m_threadsPerContext = std::max(1u, std::min(64u, cpus / (unsigned)devices.size()));
     for (size_t d = 0; d < devices.size(); ++d) {
       std::unique_ptr<Worker> w(new Worker());
       w->device = devices[d];
       hipFatal(bwtc_hip_create(devices[d], maxBlock, &w->ctx), "bwtc_hip_create");
       if (coder != 'H') hipFatal(bwtc_hip_wavelet_start(w->ctx, coder), "bwtc_hip_wavelet_start");
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < kStaging; ++b) {
         w->h_in[b] = static_cast<byte*>(bwtc_hip_host_alloc(w->ctx, (uint64)maxBlock + 64));
-        w->d_in[b] = bwtc_hip_malloc(w->ctx, (uint64)maxBlock + 64);
-        if (!w->h_in[b] || !w->d_in[b]) hipFatal(-2, "farm staging buffers");
+        if (!w->h_in[b]) hipFatal(-2, "farm staging buffers");
         w->h_free[b] = true;
+      }
+      for (int b = 0; b < 2; ++b) {
+        w->d_in[b] = bwtc_hip_malloc(w->ctx, (uint64)maxBlock + 64);
+        if (!w->d_in[b]) hipFatal(-2, "farm device buffers");
       }
       if (coder == 'H') {
         w->d_comp = bwtc_hip_malloc(w->ctx, bwtc_hip_compress_bound(maxBlock));
@@ -91,7 +96,8 @@ class BlockFarm {
     for (size_t d = 0; d < m_workers.size(); ++d) if (m_workers[d]->thread.joinable()) m_workers[d]->thread.join();
     for (size_t d = 0; d < m_workers.size(); ++d) {
       Worker& w = *m_workers[d];
-      for (int b = 0; b < 2; ++b) { bwtc_hip_free(w.ctx, w.d_in[b]); bwtc_hip_host_free(w.ctx, w.h_in[b]); }
+      for (int b = 0; b < 2; ++b) bwtc_hip_free(w.ctx, w.d_in[b]);
+      for (int b = 0; b < kStaging; ++b) bwtc_hip_host_free(w.ctx, w.h_in[b]);
       for (size_t i = 0; i < w.outFree.size(); ++i) std::free(w.outFree[i]);
       for (size_t i = 0; i < w.pending.size(); ++i) std::free(w.pending[i].out);
       if (w.d_comp) bwtc_hip_free(w.ctx, w.d_comp);
@@ -102,13 +108,18 @@ class BlockFarm {
   size_t devices() const { return m_workers.size(); }
 
   // ---- reader side ---------------------------------------------------------------------------
-  // Page-locked buffer (maxBlock bytes) for the next block; waits while the target worker's two
-  // staging buffers are still in use.
+  // Page-locked buffer (maxBlock bytes) for the next block; waits while all of the target worker's
+  // staging buffers are still in use.  (Four of them: with two, reading a block -- 60 ms for 256 MiB
+  // from the page cache -- and the worker's 75 ms per block took turns instead of overlapping.)
   byte* nextInput() {
     Worker& w = *m_workers[m_submitted % m_workers.size()];
     std::unique_lock<std::mutex> g(m_mu);
-    m_cv.wait(g, [&] { return w.h_free[0] || w.h_free[1] || m_failed; });
-    m_fill = w.h_free[0] ? 0 : 1;
+    int free_one = -1;
+    m_cv.wait(g, [&] {
+      for (int b = 0; b < kStaging && free_one < 0; ++b) if (w.h_free[b]) free_one = b;
+      return free_one >= 0 || m_failed;
+    });
+    m_fill = free_one < 0 ? 0 : free_one;
     return w.h_in[m_fill];
   }
   // the buffer from nextInput() holds `size` bytes: block number = order of submission
@@ -158,9 +169,9 @@ class BlockFarm {
   struct Worker {
     int device = 0;
     bwtc_hip_ctx* ctx = nullptr;
-    byte* h_in[2] = {nullptr, nullptr};
+    byte* h_in[kStaging] = {nullptr, nullptr, nullptr, nullptr};
     void* d_in[2] = {nullptr, nullptr};
-    bool h_free[2] = {true, true};
+    bool h_free[kStaging] = {true, true, true, true};
     void* d_comp = nullptr;
     std::deque<Job> jobs;                 // assigned, not yet taken (guarded by the farm's mutex)
     std::deque<Pending> pending;          // 'B': queued on the context, record not collected yet (worker's own)
@@ -316,30 +327,30 @@ class BlockFarm {
   bool m_failed;
 };
 
-// Compressor.cpp:65-118 over a BlockFarm: the caller's thread reads and writes, in block order.
+// Compressor.cpp:65-118 over a BlockFarm: a reader thread fills the staging buffers in block order,
+// the caller's thread writes the records in block order (one thread doing both spent 60 ms reading and
+// 15 ms writing per 256 MiB block, one after the other: more than a GPU needs for the block).
 inline size_t Compressor::compressFarmed(const std::vector<int>& devices, uint32 startingPoints, unsigned depth) {
   size_t compressedSize = writeGlobalHeader();
   const size_t bs = bwtBlockSize();
   BlockFarm farm(devices, (uint32)bs, m_options.entropyCoder, startingPoints, depth ? depth : 12);
+  std::thread reader([&] {
+    for (;;) {
+      byte* buf = farm.nextInput();
+      const size_t got = m_in->readBlock(buf, bs);
+      if (got == 0) break;
+      farm.submit((uint32)got);
+    }
+    farm.finishInput();
+  });
   std::vector<byte> record;
   uint32 blockSize = 0;
-  for (;;) {
-    byte* buf = farm.nextInput();
-    const size_t got = m_in->readBlock(buf, bs);
-    if (got == 0) break;
-    farm.submit((uint32)got);
-    while (farm.nextRecord(&record, &blockSize, false)) {         // whatever is ready, in order
-      compressedSize += writeBlockPrefix(blockSize);
-      m_out->writeBlock(record.data(), record.data() + record.size());
-      compressedSize += record.size();
-    }
-  }
-  farm.finishInput();
   while (farm.nextRecord(&record, &blockSize, true)) {
     compressedSize += writeBlockPrefix(blockSize);
     m_out->writeBlock(record.data(), record.data() + record.size());
     compressedSize += record.size();
   }
+  reader.join();
   m_out->writeByte(0); ++compressedSize;                          // writeEmptyHeader, Compressor.cpp:115
   m_out->flush();
   return compressedSize;

@@ -255,6 +255,10 @@ int bwtc_hip_wavelet_latency(bwtc_hip_ctx* ctx, double* mean_seconds);
  * deployment has to provide per rank for the depth it runs (no reference counterpart; the reference
  * holds one block, Compressor.cpp:100-108). */
 int bwtc_hip_host_staging_bytes(uint64_t* now, uint64_t* peak);
+/* CPUs this process may keep busy: the hardware threads, cut down to the cgroup's CPU quota -- what
+ * `threads` = 0 means in the calls above.  A caller that runs several contexts splits this number
+ * between them (the reference is single-threaded, Compressor.cpp:67-70). */
+uint32_t bwtc_hip_host_usable_cpus(void);
 void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx);
 /* A new wavelet stream with the main probability model of coder letter `coder`
  * (WaveletEncoder(char), WaveletCoders.hpp:52; giveProbabilityModel,
