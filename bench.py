@@ -497,6 +497,7 @@ def main():
             "stream_blocks_for_rate": stream_for_rate,
             "host_mem_per_rank_gb": round(mem_per_rank, 1),
             "host_staging_peak_gb_rank0": round(hip.host_staging_bytes()[1] / 1e9, 2),
+            "host_rss_peak_gb_rank0": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6, 1),
             "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,

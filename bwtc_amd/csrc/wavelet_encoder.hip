@@ -334,6 +334,7 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
   job.host_threads = threads;
   // header: WaveletEncoder::writeBlockHeader, WaveletCoders.cpp:173-219
   std::vector<uint8_t>& rec = job.record;
+  if (e.pipeline) e.pipeline->takeSpareRecord(&rec);   // a collected block's record: its pages are there already
   rec.assign(6, 0);
   bwtc::writeBWTBlockHeader(lf, n_lf, rec);
   job.host_stats.reset(new WaveletSectionStats());

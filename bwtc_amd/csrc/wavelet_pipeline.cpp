@@ -152,7 +152,7 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
     // own (a chain alone advances at its full speed, and the block's longest one is its latency),
     // as many tasks as the block's elements are multiples of its longest chain, at least two.
     job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.w_end_state, bwtc::wavelet::StreamCoder::Modelled()));
-    job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());
+    freshOutputs(job, job.plan.sections.size());
     job.t_queued = job.t_modelled = std::chrono::steady_clock::now();
     job.models_left = 0;
     job.sections_left = job.coder->sectionTasks();
@@ -215,7 +215,7 @@ uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t f
   job.coder.reset(new bwtc::wavelet::StreamCoder(job.plan, job.coded_pos.data(), job.codes, fsm8_state, model));
   const uint32_t next_state = job.coder->endState();
   if (expect_end && *expect_end != next_state) job.failed = true;
-  job.outs.assign(job.plan.sections.size(), bwtc::wavelet::SectionOutput());
+  freshOutputs(job, job.plan.sections.size());
   job.t_queued = std::chrono::steady_clock::now();
   job.models_left = job.coder->modelTasks();
   job.sections_left = job.coder->sectionTasks();

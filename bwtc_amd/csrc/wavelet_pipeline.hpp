@@ -7,6 +7,7 @@
 // and is known before its coding starts, so the bytes are those of a strictly sequential
 // encoder.
 #pragma once
+#include <malloc.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -272,7 +273,31 @@ class HostPipeline {
   // caller's thread -- the one that feeds the GPU -- several milliseconds per block.
   void dispose(std::shared_ptr<WaveletJob>&& job) {
     std::shared_ptr<WaveletJob> j(std::move(job));
-    pool_.submit(~static_cast<uint64_t>(0), [j]() mutable { j.reset(); });
+    pool_.submit(~static_cast<uint64_t>(0), [this, j]() mutable {
+      keepSpares(*j);
+      j.reset();
+      // what the blocks' smaller tables leave behind in the allocator's arenas (freed by other threads
+      // than the ones that allocated them) goes back to the system now and then: a long stream at full
+      // rate otherwise sat on 30-70 GB of freed memory beside the 36 GB it uses
+      if ((++disposed_ & 31u) == 0) (void)malloc_trim(0);
+    });
+  }
+  // The record and the sections' outputs of a collected block -- 100 MB of touched pages for a 256 MiB
+  // text block -- go to the next block that needs them instead of back to the allocator (which gave
+  // every block fresh pages to fault in, and whose per-thread arenas grew the process to 60-95 GB
+  // over a long stream where 36 GB are in use).
+  void keepSpares(WaveletJob& job) {
+    std::lock_guard<std::mutex> g(spare_mu_);
+    if (spare_outs_.size() < kSpares && !job.outs.empty()) { spare_outs_.emplace_back(); spare_outs_.back().swap(job.outs); }
+    if (spare_records_.size() < kSpares && job.record.capacity() > 4096) { spare_records_.emplace_back(); spare_records_.back().swap(job.record); }
+  }
+  void takeSpareOutputs(std::vector<bwtc::wavelet::SectionOutput>* outs) {
+    std::lock_guard<std::mutex> g(spare_mu_);
+    if (!spare_outs_.empty()) { outs->swap(spare_outs_.back()); spare_outs_.pop_back(); }
+  }
+  void takeSpareRecord(std::vector<uint8_t>* record) {
+    std::lock_guard<std::mutex> g(spare_mu_);
+    if (!spare_records_.empty()) { record->swap(spare_records_.back()); spare_records_.pop_back(); }
   }
   // Route of the next block of a 'B' stream: true = the fused engines (the job then needs no
   // probability array).  Even a pipeline built for them sends a block the two-stage way (parallel
@@ -284,6 +309,17 @@ class HostPipeline {
   static constexpr unsigned kFusedBacklog = 6;
   StageClock clock;
  private:
+  enum { kSpares = 40 };
+  std::atomic<uint32_t> disposed_{0};
+  std::mutex spare_mu_;
+  std::vector<std::vector<bwtc::wavelet::SectionOutput> > spare_outs_;
+  std::vector<std::vector<uint8_t> > spare_records_;
+  // n sections' outputs, empty, with whatever room a spare set brings along
+  void freshOutputs(WaveletJob& job, size_t n) {
+    if (job.outs.empty()) takeSpareOutputs(&job.outs);
+    job.outs.resize(n);
+    for (size_t s = 0; s < n; ++s) job.outs[s].bytes.clear();
+  }
   void submitSections(const std::shared_ptr<WaveletJob>& job);
   void finish(WaveletJob& job);
   BlockGroupSource groups_;                          // before the pool: the workers are joined first
