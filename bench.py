@@ -42,6 +42,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _rss_gb():
+    """[resident memory of this process now, its high-water mark so far], GB."""
+    try:
+        f = dict(l.split(":", 1) for l in open("/proc/self/status") if l.startswith(("VmRSS", "VmHWM")))
+        return [round(int(f[k].split()[0]) * 1024 / 1e9, 1) for k in ("VmRSS", "VmHWM")]
+    except Exception:
+        return None
+
+
 def usable_cpus():
     """CPUs this job may keep busy: affinity mask, cut down to the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -287,6 +296,7 @@ def main():
         clock["gpu_s"] += time.perf_counter() - t
         issued[0] += 1
 
+    rss0 = _rss_gb()
     # ---- untimed: H2D alone, one block alone, pipeline fill ---------------------------------
     t0 = time.perf_counter()
     upload(0)
@@ -313,18 +323,24 @@ def main():
         step()
     fill_blocks += settle
     fill_ms = 1e3 * (time.perf_counter() - t0)
+    rss = {"before_first_block": rss0, "after_fill": _rss_gb()}
     ctx.reset_kernel_timers()
     clock["gpu_s"] = clock["collect_s"] = 0.0
     m0, c0, b0 = ctx.wavelet_host_clock()
     f0 = ctx.wavelet_host_progress()[1]
     dev_ms = []
 
+    trace_rss = os.environ.get("BWTC_BENCH_RSS_TRACE") == "1"
+
     def timed_step():
         step()
         dev_ms.append(ctx.stats().ms_total)
+        if trace_rss and len(dev_ms) % 25 == 0:
+            print("step %d: rss/hwm %s" % (len(dev_ms), _rss_gb()), file=sys.stderr, flush=True)
 
     # ---- timed: K steps, each begins one block and (B) collects one ------------------------------
     elapsed = farm.timed(timed_step, args.steps, 0, None)
+    rss["after_timed_region"] = _rss_gb()
     m1, c1, b1 = ctx.wavelet_host_clock()
     f1 = ctx.wavelet_host_progress()[1]
     block_latency = ctx.wavelet_latency()                # begun -> record finished, mean over the stream so far
@@ -332,6 +348,7 @@ def main():
     t0 = time.perf_counter()
     drain()
     drain_ms = 1e3 * (time.perf_counter() - t0)
+    rss["after_drain"] = _rss_gb()
     comp_bytes = comp[0]
     # records the host workers finished inside the timed region: the rate the host half really
     # sustained (the records COLLECTED there may all have been finished during the fill)
@@ -498,6 +515,7 @@ def main():
             "host_mem_per_rank_gb": round(mem_per_rank, 1),
             "host_staging_peak_gb_rank0": round(hip.host_staging_bytes()[1] / 1e9, 2),
             "host_rss_peak_gb_rank0": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6, 1),
+            "host_rss_gb_rank0": rss,
             "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,

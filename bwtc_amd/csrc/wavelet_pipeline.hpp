@@ -273,8 +273,12 @@ class HostPipeline {
   // caller's thread -- the one that feeds the GPU -- several milliseconds per block.
   void dispose(std::shared_ptr<WaveletJob>&& job) {
     std::shared_ptr<WaveletJob> j(std::move(job));
-    pool_.submit(~static_cast<uint64_t>(0), [this, j]() mutable {
-      keepSpares(*j);
+    // The record and the outputs change hands here and now (a few swaps), and what is left of the block
+    // is freed by the next worker that looks for work: as a task of the lowest priority -- as this was
+    // at first -- it waited while the workers were busy, that is for as long as the stream ran at full
+    // rate, and every collected block stayed allocated (110 MB per block, 60 GB after 700 blocks).
+    keepSpares(*j);
+    pool_.submit(0, [this, j]() mutable {
       j.reset();
       // what the blocks' smaller tables leave behind in the allocator's arenas (freed by other threads
       // than the ones that allocated them) goes back to the system now and then: a long stream at full

@@ -10,6 +10,12 @@ from bwtc_amd import hip, synth
 def rss_gb():
     return int(open("/proc/self/statm").read().split()[1]) * 4096 / 1e9
 
+
+def hwm_gb():
+    for l in open("/proc/self/status"):
+        if l.startswith("VmHWM"):
+            return int(l.split()[1]) * 1024 / 1e9
+
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 size = (int(sys.argv[2]) if len(sys.argv) > 2 else 64) << 20
 depth = int(os.environ.get("PROBE_DEPTH", "8"))
@@ -35,7 +41,7 @@ for i in range(blocks):
     lf, freqs = ctx.bwt_block_device(d_in[i % 2], d_out, size, 8)
     pending.append(ctx.wavelet_encode_device_begin(d_out, size, lf, freqs, ring[i % (depth + 1)], 16))
     if i % 50 == 49:
-        print("block %d: RSS %.2f GB, staging now/peak %.2f / %.2f GB, %.1f s" % ((i + 1, rss_gb()) + tuple(x / 1e9 for x in hip.host_staging_bytes()) + (time.time() - t0,)), flush=True)
+        print("block %d: RSS %.2f GB (high-water %.2f), staging now/peak %.2f / %.2f GB, %.1f s" % ((i + 1, rss_gb(), hwm_gb()) + tuple(x / 1e9 for x in hip.host_staging_bytes()) + (time.time() - t0,)), flush=True)
 while pending:
     ctx.wavelet_encode_end(pending.pop(0))
 print("end: RSS %.2f GB" % rss_gb(), flush=True)
