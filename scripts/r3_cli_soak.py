@@ -35,4 +35,4 @@ err = comp.stderr.read().decode()
 wall = time.time() - t0
 gb = reps * 4 * 268435456 / 1e9
 print("%s: %d blocks, %.1f GB in %.1f s = %.2f GB/s; resident memory each second (GB): %s; rc %d %s" %
-      (" ".join(extra) or "one context, default loop", reps * 4, gb, wall, gb / wall, samples, comp.returncode, err.strip().splitlines()[-1] if err.strip() else ""))
+      (" ".join(extra) or "no --devices (the CLI picks: farm with one context for a pipe)", reps * 4, gb, wall, gb / wall, samples, comp.returncode, err.strip().splitlines()[-1] if err.strip() else ""))
