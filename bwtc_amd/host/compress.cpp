@@ -93,20 +93,13 @@ int main(int argc, char** argv) {
   }
   if (!from_stdin && in_name.empty()) { std::fprintf(stderr, "no input\n"); return 1; }
 
-  // One device, a long stream (or one of unknown length, from a pipe): the block farm with one context --
-  // a reader thread and page-locked staging, the upload of a block under the kernels of the block before
-  // it (160 blocks of 256 MiB from a pipe: 3.4 GB/s against 2.6 for the loop below, which reads,
-  // uploads and transforms one after the other).  Short streams keep the loop: the farm's start-up
-  // costs them more than it gains (32 blocks: 4.2 s against 3.7).  BWTC_HIP_CLI_FARM=0 / 1 decides otherwise.
+  // One device and a stream from a pipe: the block farm with one context -- a reader thread and page-locked
+  // staging, the upload of a block under the kernels of the block before it (160 blocks of 256 MiB from a
+  // pipe: 12.6-13.3 s against 16.3 s for the loop below, which reads, uploads and transforms one after
+  // the other).  Files keep the loop: read from the page cache it is the faster of the two (96 blocks:
+  // 8.1 s against 8.8), and short streams pay for the farm's start-up.  BWTC_HIP_CLI_FARM=0 / 1 decides otherwise.
   if (devices.empty()) {
-    double blocks = 0.0;
-    if (!from_stdin) {
-      if (FILE* f = std::fopen(in_name.c_str(), "rb")) {
-        if (fseeko(f, 0, SEEK_END) == 0) blocks = (double)ftello(f) / (mem * 0.185 * 1e6);
-        std::fclose(f);
-      }
-    }
-    bool farm = from_stdin || blocks >= 64.0;
+    bool farm = from_stdin;
     if (const char* f = std::getenv("BWTC_HIP_CLI_FARM")) farm = f[0] == '1';
     if (farm) devices.push_back(device);
   }
