@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_emit(const u32* __restrict__ pack
                                                     const u32* __restrict__ order, u32 nc, u32 nt, unsigned short* __restrict__ out,
                                                     u32* __restrict__ err) {
   __shared__ u32 q[gm::kSlotStride][kGmTPB];
+  __shared__ u32 stage[32][kGmTPB];                  // a lane's line of output (64 elements) on its way out
   const u32 gid = blockIdx.x * kGmTPB + threadIdx.x;
   if (gid >= nc) return;
   const u32 c = order[gid];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_emit(const u32* __restrict__ pack
   const u32 t = ch.task_first & 0x7FFFFFFFu;
   u32 e = 0;
   gm::laneEmit(packed, ch.begin, ch.end, tasks[t].type, cstate[c], t, c, nc, nt, base, sb, sbits, snaps, smap, sstart,
-               &q[0][threadIdx.x], kGmTPB, out, &e);
+               &q[0][threadIdx.x], kGmTPB, out, &e, &stage[0][threadIdx.x]);
   if (e) atomicOr(err, e);
 }
 

@@ -498,21 +498,27 @@ BWTC_GM_HD u32 emitStep(u32 v, Machines& m, u32* q, u32 stride) {
   q[slot * stride] = moved(pr, bit, TYPE == kTInts ? 100u : 2u, (TYPE == kTGaps || TYPE == kTInts) ? 5u : slotDelay(slot));
   return (bit << 15) | (bit ? pr : 4096u - pr);
 }
+// `stage` (stride `stride` between its 32 words): room for the 64 elements = 128 bytes = one line of
+// output that a piece of 64 elements makes.  A piece that lies wholly inside the chunk is collected there
+// and leaves with eight 16-byte stores back to back: written 32 bytes at a time, sixteen elements' worth
+// of work apart, the lines of 130 000 lanes were open at once -- half of the L2 -- and part of them left
+// it half-written (1.6 x the bytes written, and fetched again to be completed).
 template <u32 TYPE>
-BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32* q, u32 stride, unsigned short* out) {
+BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32* q, u32 stride, unsigned short* out, u32* stage) {
   Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
   if (begin >= end) return;
   const u32 q0 = begin >> 6, q1 = (end - 1u) >> 6;
   Piece cur = loadPiece(packed, q0);
   for (u32 qi = q0; qi <= q1; ++qi) {
     const Piece nxt = loadPiece(packed, qi < q1 ? qi + 1u : qi);
+    const bool whole = (qi << 6) >= begin && (qi << 6) + 64u <= end;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
     for (u32 k = 0; k < 4; ++k) {
       const u32 wb = (qi << 6) + k * 16u;
       u32 word = pieceWord(cur, k);
-      if (wb >= begin && wb + 16u <= end) {                      // sixteen elements: 32 bytes of output, two 16-byte stores
+      if (wb >= begin && wb + 16u <= end) {                      // sixteen elements: 32 bytes of output
         u32 o[8];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -522,6 +528,24 @@ BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32*
           const u32 b = emitStep<TYPE>((word >> 2) & 3u, m, q, stride);
           word >>= 4;
           o[e] = a | (b << 16);
+        }
+        if (whole) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+          for (u32 e = 0; e < 8; ++e) stage[(k * 8u + e) * stride] = o[e];
+          if (k == 3u) {
+            u32* dst = reinterpret_cast<u32*>(out + (qi << 6));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (u32 v = 0; v < 8; ++v)
+              reinterpret_cast<uint4*>(dst)[v] = make_uint4(stage[(4u * v) * stride], stage[(4u * v + 1u) * stride],
+                                                            stage[(4u * v + 2u) * stride], stage[(4u * v + 3u) * stride]);
+#else
+            for (u32 v = 0; v < 32; ++v) dst[v] = stage[v * stride];
+#endif
+          }
+          continue;
         }
         u32* dst = reinterpret_cast<u32*>(out + wb);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -542,7 +566,7 @@ BWTC_GM_HD void laneEmitT(const u32* packed, u32 begin, u32 end, u32 state, u32*
 }
 BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 state, u32 task, u32 chunk, u32 nc, u32 nt,
                          const u32* base, const u32* sb, const u32* sbits, const SlotMap* snaps, const SlotMap* smap,
-                         const unsigned short* sstart, u32* q, u32 stride, unsigned short* out, u32* err) {
+                         const unsigned short* sstart, u32* q, u32 stride, unsigned short* out, u32* err, u32* stage) {
   const u32 k_lo = type == kTGaps ? 8u : type == kTInts ? 12u : 0u;
   const u32 k_hi = type == kTRoot ? 8u : type == kTInts ? 15u : 12u;
   for (u32 k = k_lo; k < k_hi; ++k) {
@@ -560,7 +584,7 @@ BWTC_GM_HD void laneEmit(const u32* packed, u32 begin, u32 end, u32 type, u32 st
     forBits(sbits, a, P, [&](u32, u32 b) { x = moved(x, b, floor, d); });
     q[k * stride] = x;
   }
-  BWTC_GM_BY_TYPE(type, laneEmitT<TYPE>(packed, begin, end, state, q, stride, out));
+  BWTC_GM_BY_TYPE(type, laneEmitT<TYPE>(packed, begin, end, state, q, stride, out, stage));
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------

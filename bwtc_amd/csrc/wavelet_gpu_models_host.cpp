@@ -121,11 +121,11 @@ bool modelsOnHostLanes(const u32* packed, u32 total, const std::vector<Task>& ta
   }
   if (err) return false;
   // pass 7
-  u32 q[kSlotStride];
+  u32 q[kSlotStride], stage[32];
   for (u32 c = 0; c < nc; ++c) {
     const u32 t = chunks[c].task_first & 0x7FFFFFFFu;
     laneEmit(packed, chunks[c].begin, chunks[c].end, tasks[t].type, cstate[c], t, c, nc, nt, base.data(), sb.data(), sbits.data(),
-             snaps.data(), smap.data(), sstart.data(), q, 1, out, &err);
+             snaps.data(), smap.data(), sstart.data(), q, 1, out, &err, stage);
   }
   return err == 0;
 }
