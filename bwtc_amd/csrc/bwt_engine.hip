@@ -300,25 +300,39 @@ __device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v)
 }
 
 // keys of G grams of g characters, b bits per gram code; slots in descending suffix order as in k_make_keys
+//
+// Long keys (lk.w != nullptr, see LongKey): the item also gets a second key word w = the NEXT lk.G2
+// grams (characters G g .. (G + G2) g of the suffix), and the dense code of its predecessor character
+// T[i-1] rides in spare bits of the key, so that the one long sort orders the suffixes by (G + G2) g
+// characters and the ranking behind it can emit the transform's bytes without going back to T.
+struct LongKey {
+  u32* w; int G2;                // make: where the second words go, grams per word
+  int hi_shift;                  // key bits [hi_shift, hi_shift + 13): the upper bits of the suffix number
+  int chr_shift; u32 chr_mask;   // key bits of the predecessor character's dense code
+};
 __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T, const u8* __restrict__ lut,
                                                         const uint4* __restrict__ gtable,
                                                         u64* __restrict__ keys, u32* __restrict__ idx, u32 n,
                                                         int g, int G, int b, u32 sigma, u32 top,
-                                                        u8* __restrict__ plane, int idx_hi) {
+                                                        u8* __restrict__ plane, int idx_hi, LongKey lk) {
   constexpr u32 kTile = 1024;
   __shared__ u8 s_lut[256];
-  __shared__ u8 s_code[kTile + 128];
-  __shared__ u32 s_g[kTile + 64];
+  __shared__ u8 s_code[kTile + 136];
+  __shared__ u32 s_g[kTile + 128];
   __shared__ u64 s_key[kTile];
+  __shared__ u32 s_w[kTile];
   s_lut[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
   const u32 J0 = blockIdx.x * kTile;
   if (J0 >= n) return;
   const u32 cntw = min(kTile, n - J0);
   const u32 i_base = n - J0 - cntw;
-  const u32 span = cntw + (u32)((G - 1) * g);        // gram starts this tile looks at (G g <= 64)
-  stage_codes(T, s_lut, s_code, i_base, span + (u32)g);
+  const int Gall = G + (lk.w ? lk.G2 : 0);
+  const u32 span = cntw + (u32)((Gall - 1) * g);     // gram starts this tile looks at (Gall g <= 96)
+  const u32 pre = (lk.w && i_base > 0) ? 1u : 0u;    // long keys: one character before the tile's first suffix
+  stage_codes(T, s_lut, s_code, i_base - pre, span + (u32)g + pre);
   __syncthreads();
+  const u8* s_c = s_code + pre;                       // s_c[t] = code of T[i_base + t]
   {
     // span <= 1024 + 60: at most five gram starts per thread, strided, so that the five table
     // lookups (the kernel's only latency) are in flight together
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     for (int e = 0; e < 5; ++e) {
       const u32 t = threadIdx.x + 256u * e;
       v[e] = 0;
-      if (t < span) for (int c = 0; c < g; ++c) v[e] = v[e] * sigma + s_code[t + c];
+      if (t < span) for (int c = 0; c < g; ++c) v[e] = v[e] * sigma + s_c[t + c];
     }
     u32 cd[5];
 #pragma unroll
@@ -342,16 +356,27 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     for (u32 s = 0; s < cnt; ++s) {
       u64 key = 0;
       for (int j = 0; j < G; ++j) key = (key << b) | (u64)s_g[o + s + (u32)(j * g)];
+      if (lk.w) {
+        u32 w = 0;
+        for (int j = G; j < Gall; ++j) w = (w << b) | s_g[o + s + (u32)(j * g)];
+        s_w[cntw - 1u - (o + s)] = w;
+        const u32 i = i_base + o + s;                  // its predecessor's code (suffix 0 has none)
+        key |= (u64)(i ? (u32)s_c[(int)(o + s) - 1] : 0u) << lk.chr_shift;
+      }
       s_key[cntw - 1u - (o + s)] = key;
     }
   }
   __syncthreads();
   for (u32 j = threadIdx.x; j < cntw; j += 256u) {
     u64 key = s_key[j];
-    if (idx_hi) key |= (u64)((n - 1u - (J0 + j)) >> 16) << 48;
+    if (idx_hi) key |= (u64)((n - 1u - (J0 + j)) >> 16) << (lk.w ? lk.hi_shift : 48);
     keys[J0 + j] = key;
     if (idx) idx[J0 + j] = n - 1u - (J0 + j);
-    if (plane) plane[J0 + j] = (u8)s_key[j];
+    if (lk.w) {
+      const u32 w = s_w[j];
+      lk.w[J0 + j] = w;
+      if (plane) plane[J0 + j] = (u8)w;               // the long sort's first pass is over w
+    } else if (plane) plane[J0 + j] = (u8)s_key[j];
   }
 }
 
@@ -402,17 +427,25 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loads, was eight memory latencies in a row per wave); the neighbours across an iteration's ends
 // are the adjacent iterations' end lanes, and only the two slots next to the whole chunk are
 // loaded on their own.
-template <typename K, bool INIT, bool SPLIT>
+// LONG (initial ranking after the long-key sort, radix_sort_long): a suffix's order key is (key & kmask,
+// w & wmask); the upper bits of its number sit at hi_shift, its predecessor character's code at chr_shift.
+struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; };
+
+template <typename K, bool INIT, bool SPLIT, bool LONG = false>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
                                          u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
-                                         RrMasks<K, INIT>& f) {
+                                         RrMasks<K, INIT>& f, RrLong lg = RrLong()) {
   // SPLIT (initial ranking of 64-bit keys only): a suffix number's upper bits sit in bits 48.. of
   // its key and idx[] holds 16-bit lower halves (the sort moved 10 bytes per item instead of 12)
   auto suffix_of = [&](K kraw, u32 word, u32 p) -> u32 {     // the 16-bit half out of its aligned word (two lanes per word)
-    if (sizeof(K) == 8 && SPLIT) return ((u32)((u64)kraw >> 48) << 16) | ((p & 1u) ? word >> 16 : word & 0xFFFFu);
+    if (sizeof(K) == 8 && SPLIT) {
+      const u32 hi = LONG ? ((u32)((u64)kraw >> lg.hi_shift) & 0x1FFFu) : (u32)((u64)kraw >> 48);
+      return (hi << 16) | ((p & 1u) ? word >> 16 : word & 0xFFFFu);
+    }
     return word;
   };
   K kc[kRrE];
+  u32 wc[LONG ? kRrE : 1] = {};
   {
     K kraw[kRrE];
     u32 word[kRrE];
@@ -422,23 +455,28 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
       const bool ok = p < m;
       kraw[e] = ok ? key[p] : (K)0;
       word[e] = ok ? idx[(sizeof(K) == 8 && SPLIT) ? p >> 1 : p] : 0u;
+      if (LONG) wc[LONG ? e : 0] = ok ? lg.w[p] & lg.wmask : 0u;
     }
 #pragma unroll
     for (int e = 0; e < kRrE; ++e) {
       const u32 p = wbase + e * kWave + lane;
       f.sfx[e] = p < m ? suffix_of(kraw[e], word[e], p) : 0u;
-      f.chr[e] = sizeof(K) == 8 ? (u32)((u64)kraw[e] >> 56) : 0u;
+      f.chr[e] = LONG ? ((u32)((u64)kraw[e] >> lg.chr_shift) & lg.chr_mask) : sizeof(K) == 8 ? (u32)((u64)kraw[e] >> 56) : 0u;
       kc[e] = kraw[e] & kmask;
     }
   }
   K before = (K)0, after = (K)0;          // slots wbase - 1 and wbase + chunk (where they exist)
-  u32 ibefore = 0u;
+  u32 ibefore = 0u, wbefore = 0u, wafter = 0u;
   if (lane == 0 && wbase > 0 && wbase < m) {
     const K braw = key[wbase - 1];
     before = braw & kmask;
+    if (LONG) wbefore = lg.w[wbase - 1] & lg.wmask;
     if (INIT) ibefore = suffix_of(braw, idx[(sizeof(K) == 8 && SPLIT) ? (wbase - 1) >> 1 : wbase - 1], wbase - 1);
   }
-  if (lane == kWave - 1 && wbase + (u32)kRrChunk < m) after = key[wbase + kRrChunk] & kmask;
+  if (lane == kWave - 1 && wbase + (u32)kRrChunk < m) {
+    after = key[wbase + kRrChunk] & kmask;
+    if (LONG) wafter = lg.w[wbase + kRrChunk] & lg.wmask;
+  }
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
     const u32 p = wbase + e * kWave + lane;
@@ -452,9 +490,20 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
     const K knext_first = e + 1 < kRrE ? lane_value(kc[e + 1 < kRrE ? e + 1 : e], 0) : after;
     if (lane == 0) { kp = (ok && p > 0) ? kprev_end : (K)0; if (INIT) ip = (ok && p > 0) ? iprev_end : 0u; }
     if (lane == kWave - 1) kn = (p + 1 < m) ? knext_first : (K)0;
-    bool h = ok && (p == 0 || kc[e] != kp);
+    bool wdiff_p = false, wdiff_n = false;           // LONG: the second key word differs from the neighbour's
+    if (LONG) {
+      const u32 wme = wc[LONG ? e : 0];
+      u32 wp = shfl_up1(wme), wn = shfl_down1(wme);
+      const u32 wprev_end = e > 0 ? lane_value(wc[LONG && e > 0 ? e - 1 : 0], kWave - 1) : wbefore;
+      const u32 wnext_first = e + 1 < kRrE ? lane_value(wc[LONG && e + 1 < kRrE ? e + 1 : 0], 0) : wafter;
+      if (lane == 0) wp = (ok && p > 0) ? wprev_end : 0u;
+      if (lane == kWave - 1) wn = (p + 1 < m) ? wnext_first : 0u;
+      wdiff_p = wme != wp;
+      wdiff_n = wme != wn;
+    }
+    bool h = ok && (p == 0 || kc[e] != kp || wdiff_p);
     if (INIT) h = h || (ok && p > 0 && (u64)ip + short_len >= (u64)n);
-    bool hn = (p + 1 >= m) || kn != kc[e];         // is p+1 a head (or past the end)?
+    bool hn = (p + 1 >= m) || kn != kc[e] || wdiff_n;         // is p+1 a head (or past the end)?
     if (INIT) hn = hn || ((u64)ic + short_len >= (u64)n);
     f.head[e] = __ballot(h);
     f.valid[e] = __ballot(ok);
@@ -464,19 +513,19 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
 
 __device__ __forceinline__ u32 top_bit(u64 v) { return 63u - (u32)__clzll((unsigned long long)v); }
 
-template <typename K, bool INIT, bool SPLIT = false>
+template <typename K, bool INIT, bool SPLIT = false, bool LONG = false>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_reduce(const K* __restrict__ key,
                                                           const u32* __restrict__ idx, u32 m,
                                                           u32 n, u32 short_len, K kmask,
                                                           u32* __restrict__ aggA,
                                                           u32* __restrict__ aggB,
-                                                          u32* __restrict__ aggC) {
+                                                          u32* __restrict__ aggC, RrLong lg = RrLong()) {
   __shared__ u32 s_tot[3][kRrWaves];
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT, SPLIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
+  rr_masks<K, INIT, SPLIT, LONG>(key, idx, m, n, short_len, kmask, wbase, lane, f, lg);
   u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
   for (int e = 0; e < kRrE; ++e) {
@@ -591,21 +640,41 @@ __global__ __launch_bounds__(1024) void k_rerank_scan_tiles(u32* __restrict__ ag
 struct RrEmit {
   u8* out; u32 out_n; u32* last_char; u32* pidx; const u8* T; u8* achr_out;
   u8* rec_plane; int rec_shift;      // MODE 2: digit (s >> rec_shift) & 255 of every record, for the window partition's first pass
+  const u8* inv_lut;                 // EMIT 3: dense code -> byte (the character rides in the long key as its code)
+  // LF powers noted as suffixes become final (the routes that never complete rank[]):
+  // LF[k] = slot of suffix n - k x, k = 1 .. lf_n - 1 (divsufsort.c:337-338,350,381,390); lf_inv = floor(2^32 / x)
+  u32* lf; u32 lf_n, lf_x, lf_inv;
 };
 
-template <typename K, bool INIT, int MODE, int EMIT, bool SPLIT = false>
+// Suffix s became final at `slot`: is it one of the sampled ones?
+__device__ __forceinline__ void lf_note(const RrEmit& em, u32 n, u32 s, u32 slot) {
+  if (em.lf_n <= 1u) return;
+  const u32 t = n - s;                                  // 1 .. n
+  u32 q = __umulhi(t, em.lf_inv);                       // floor(t / x) or one less
+  u32 r = t - q * em.lf_x;
+  if (r == em.lf_x) { r = 0u; ++q; }
+  if (r == 0u && q >= 1u && q < em.lf_n) em.lf[q] = slot;
+}
+
+//   3  (finisher route, after the long-key sort) nothing goes to rank[]: finished suffixes leave
+//      (out, SA, LF powers), the others are compacted into the list the finisher works on --
+//      suffix, slot, slot of the group's head, character.
+// EMIT 3: the character's dense code rides in the long key (RrLong::chr_shift); em.inv_lut turns it back.
+template <typename K, bool INIT, int MODE, int EMIT, bool SPLIT = false, bool LONG = false>
 __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
     const K* __restrict__ key, const u32* __restrict__ idx, const u32* __restrict__ aglob, u32 m,
     u32 n, u32 short_len, K kmask, const u32* __restrict__ aggA, const u32* __restrict__ aggB,
     const u32* __restrict__ aggC, u32* __restrict__ rank, u32* __restrict__ SA,
     u32* __restrict__ aidx_out, u32* __restrict__ aglob_out, u32* __restrict__ agrp_out,
-    u32* __restrict__ pair_s, u32* __restrict__ pair_r, RrEmit em) {
+    u32* __restrict__ pair_s, u32* __restrict__ pair_r, RrEmit em, RrLong lg = RrLong()) {
   __shared__ u32 s_tot[3][kRrWaves];
+  __shared__ u8 s_inv[EMIT == 3 ? 256 : 4];
+  if (EMIT == 3) s_inv[threadIdx.x] = em.inv_lut[threadIdx.x];     // kRrTPB == 256
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x / kWave;
   const u32 wbase = blockIdx.x * kRrTile + wave * kRrChunk;
   RrMasks<K, INIT> f;
-  rr_masks<K, INIT, SPLIT>(key, idx, m, n, short_len, kmask, wbase, lane, f);
+  rr_masks<K, INIT, SPLIT, LONG>(key, idx, m, n, short_len, kmask, wbase, lane, f, lg);
   {
     u32 nact = 0, nha = 0, last = 0;
 #pragma unroll
@@ -642,6 +711,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       qs[e] = q_run + (u32)__popcll(ac & lt);
       if (EMIT == 1) cs[e] = f.chr[e];
       if (EMIT == 2 && (!a || MODE != 2)) cs[e] = s ? em.T[s - 1u] : 0u;
+      if (EMIT == 3) cs[e] = s_inv[f.chr[e]];
     }
     q_run += (u32)__popcll(ac);
     g_run += (u32)__popcll(ac & hd);
@@ -658,13 +728,13 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
         pair_r[p] = a ? grp : 0xFFFFFFFFu;
         if (em.rec_plane) em.rec_plane[p] = (u8)(s >> em.rec_shift);
       } else if (MODE == 1) { pair_s[p] = s; pair_r[p] = nr; }
-      else rank[s] = nr;
+      else if (MODE == 0) rank[s] = nr;
       if (a) {
         const u32 q = qs[e];
         aglob_out[q] = g;
         if (MODE != 2) {
           aidx_out[q] = s;
-          agrp_out[q] = grp;
+          agrp_out[q] = MODE == 3 ? nr : grp;
           if (EMIT) em.achr_out[q] = (u8)c;
         }
       } else {
@@ -673,10 +743,256 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
           if (s == 0u) *em.pidx = g;
           if (g < em.out_n) em.out[g] = (u8)c;
           else *em.last_char = c;
+          if (MODE == 3) lf_note(em, n, s, g);
         }
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Finisher (after the long-key sort): the suffixes that are still tied at depth h form small
+// groups -- a few tens of millions of suffixes in groups of two to a few hundred for a text
+// block, where prefix doubling would first have to complete rank[] for ALL suffixes (an ISA
+// scatter of the whole block) before it could look at rank[s+h].  Here a group is settled by
+// comparing its members' next kFinChars characters directly: the list entry of a suffix is
+// (suffix, slot, slot of its group's head, predecessor character), groups are contiguous in the
+// list; a workgroup stages the characters of the groups it owns in LDS and every member counts
+// the members below it and equal to it.  A member without equals is final: out[slot], SA[slot],
+// the LF powers.  The others form the next list (their sub-group's head slot = old head + members
+// below), appended with one atomic per workgroup (the order of groups in the list is free).
+//
+// A workgroup looks at a window of kFinWin consecutive entries and owns the groups that START
+// in its first kFinStride entries and have at most kFinMaxGroup members (so they lie inside the
+// window).  Larger groups are nobody's: their entries go to the "hard" list, appended by the
+// workgroup whose stride range they lie in, and take the doubling rounds (bridge, below).
+// "Proper prefix sorts first": characters past the end of T compare as zero bytes, and of two
+// members that are equal under that rule and of which one reaches past the end, the shorter
+// (larger suffix number) is the smaller -- they are never equal.
+// ---------------------------------------------------------------------------------------
+constexpr int kFinTPB = 256;
+constexpr int kFinE = 8;
+constexpr int kFinWin = kFinTPB * kFinE;            // 2048 entries in LDS
+constexpr int kFinMaxGroup = 1024;
+constexpr int kFinStride = kFinWin - kFinMaxGroup;  // entries whose groups a workgroup owns
+constexpr u32 kFinChars = 16;                       // characters compared per pass
+constexpr u32 kFinNone = 0xFFFFFFFFu;
+
+struct FinList { u32* S; u32* P; u32* H; u8* C; };
+
+// sixteen characters T[pos .. pos+16) as two big-endian words; bytes at or past n read as zero
+__device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32 n, u64* c0, u64* c1) {
+  *c0 = 0; *c1 = 0;
+  if (pos >= n) return;
+  const u64* a = reinterpret_cast<const u64*>(T + (pos & ~7u));      // T is 256-byte aligned and padded
+  const u32 sh = (pos & 7u) * 8u;
+  const u64 w0 = a[0], w1 = a[1], w2 = a[2];
+  u64 lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;               // bytes pos .. pos+7, first byte lowest
+  u64 hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+  const u32 left = n - pos;                                          // real bytes from pos on
+  if (left < 16u) {
+    if (left <= 8u) { hi = 0; if (left < 8u) lo &= (1ull << (8u * left)) - 1ull; }
+    else hi &= (1ull << (8u * (left - 8u))) - 1ull;
+  }
+  *c0 = __builtin_bswap64(lo);
+  *c1 = __builtin_bswap64(hi);
+}
+
+__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n, u32 h,
+                                                    FinList next, u32* __restrict__ next_count,
+                                                    u32* __restrict__ hardS, u64* __restrict__ hardHP,
+                                                    u32* __restrict__ hard_count, u32* __restrict__ SA, RrEmit em) {
+  __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // 32 KiB; later the reorder staging
+  __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
+  __shared__ u32 s_H[kFinWin];
+  __shared__ unsigned short s_g[kFinWin + 2];                         // group size by start position; [kFinWin]: the group cut by the window's start
+  __shared__ u32 scr[kFinTPB / kWave + 1];
+  __shared__ u32 s_base;
+  u32* st_S = reinterpret_cast<u32*>(s_ch);                           // staging, by new position
+  u32* st_P = st_S + kFinWin;
+  u32* st_H = st_P + kFinWin;                                         // | final << 31
+  u8* st_C = reinterpret_cast<u8*>(st_H + kFinWin);
+  const u32 tid = threadIdx.x;
+  const u32 w0 = blockIdx.x * (u32)kFinStride;
+  const u32 lane = lane_id();
+
+  u32 S[kFinE], P[kFinE], H[kFinE], C[kFinE];
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
+    const bool ok = q < m;
+    S[e] = ok ? in.S[q] : 0u; P[e] = ok ? in.P[q] : 0u; H[e] = ok ? in.H[q] : kFinNone; C[e] = ok ? in.C[q] : 0u;
+    s_H[lp] = H[e];
+    s_g[lp] = 0xFFFFu;
+  }
+  if (tid < 2) s_g[kFinWin + tid] = 0xFFFFu;
+  __syncthreads();
+  // group sizes, from each group's last member
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
+    if (q < m) {
+      const bool last = (q + 1u == m) || (lp + 1u < (u32)kFinWin && s_H[lp + 1u] != H[e]);
+      const u32 off = P[e] - H[e];
+      if (last && off < (u32)kFinMaxGroup) {
+        const int a = (int)lp - (int)off;
+        s_g[a >= 0 ? a : kFinWin] = (unsigned short)(off + 1u);
+      }
+    }
+  }
+  __syncthreads();
+  int A[kFinE];                   // group start (window position), or -1: not this workgroup's to settle
+  u32 G[kFinE];
+  u32 hard_mask = 0;
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
+    A[e] = -1; G[e] = 0;
+    if (q < m) {
+      const int a = (int)lp - (int)(P[e] - H[e]);
+      const u32 g = (P[e] - H[e] < (u32)kFinMaxGroup) ? s_g[a >= 0 ? a : kFinWin] : 0xFFFFu;
+      if (g == 0xFFFFu) { if (lp < (u32)kFinStride) hard_mask |= 1u << e; }
+      else if (a >= 0 && a < kFinStride) { A[e] = a; G[e] = g; }
+    }
+  }
+  // characters of the members this workgroup settles
+  u64 c0[kFinE], c1[kFinE];
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) { c0[e] = 0; c1[e] = 0; if (A[e] >= 0) fin_chars(T, S[e] + h, n, &c0[e], &c1[e]); }
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    if (A[e] >= 0) {
+      const u32 lp = tid + (u32)e * kFinTPB;
+      const u32 touch = ((u64)S[e] + h + kFinChars > (u64)n) ? 0x80000000u : 0u;
+      s_ch[2u * lp] = c0[e]; s_ch[2u * lp + 1u] = c1[e];
+      s_S[lp] = S[e] | touch;
+    }
+  }
+  __syncthreads();
+  u32 R[kFinE], Q[kFinE];         // members below; equal members before this one | all equal members << 16
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    R[e] = 0; Q[e] = 0;
+    if (A[e] >= 0) {
+      const u32 lp = tid + (u32)e * kFinTPB;
+      const u32 me = s_S[lp];
+      u32 below = 0, eq_before = 0, eq_all = 0;
+      for (u32 j = (u32)A[e]; j < (u32)A[e] + G[e]; ++j) {
+        const u64 d0 = s_ch[2u * j], d1 = s_ch[2u * j + 1u];
+        const u32 sj = s_S[j];
+        bool lt = d0 < c0[e] || (d0 == c0[e] && d1 < c1[e]);
+        bool eq = d0 == c0[e] && d1 == c1[e];
+        if (eq && ((sj | me) >> 31) && j != lp) { lt = (sj & 0x7FFFFFFFu) > S[e]; eq = false; }
+        below += lt ? 1u : 0u;
+        eq_all += eq ? 1u : 0u;
+        eq_before += (eq && j < lp) ? 1u : 0u;
+      }
+      R[e] = below; Q[e] = eq_before | (eq_all << 16);
+    }
+  }
+  __syncthreads();                 // every read of the characters is done: the bytes become the staging
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) st_P[tid + (u32)e * kFinTPB] = kFinNone;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    if (A[e] >= 0) {
+      const u32 np = (u32)A[e] + R[e] + (Q[e] & 0xFFFFu);
+      const u32 fin = (Q[e] >> 16) == 1u ? 0x80000000u : 0u;
+      st_S[np] = S[e];
+      st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
+      st_H[np] = (H[e] + R[e]) | fin;
+      st_C[np] = (u8)C[e];
+    }
+  }
+  // the hard entries of this workgroup's stride range, in any order
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const bool hd = (hard_mask >> e) & 1u;
+    const u64 bal = __ballot(hd);
+    if (bal) {
+      u32 base = 0;
+      const u32 first = (u32)__ffsll((unsigned long long)bal) - 1u;
+      if (lane == first) base = atomicAdd(hard_count, (u32)__popcll(bal));
+      base = __shfl(base, (int)first, kWave);
+      if (hd) {
+        const u32 i = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+        hardS[i] = S[e];
+        hardHP[i] = ((u64)H[e] << 32) | (u64)P[e];
+      }
+    }
+  }
+  __syncthreads();
+  // in position order: finals leave, the rest is compacted into the next list
+  u32 oS[kFinE], oP[kFinE], oH[kFinE], oC[kFinE];
+  u32 left = 0;
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid * (u32)kFinE + (u32)e;
+    oP[e] = st_P[lp]; oS[e] = st_S[lp]; oH[e] = st_H[lp]; oC[e] = st_C[lp];
+    if (oP[e] != kFinNone && !(oH[e] >> 31)) ++left;
+  }
+  u32 total;
+  u32 at = block_scan_excl_add<kFinTPB>(left, scr, &total);
+  if (tid == 0) s_base = total ? atomicAdd(next_count, total) : 0u;
+  __syncthreads();
+  at += s_base;
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    if (oP[e] == kFinNone) continue;
+    if (oH[e] >> 31) {
+      const u32 slot = oP[e], sfx = oS[e];
+      SA[slot] = sfx;
+      if (sfx == 0u) *em.pidx = slot;
+      if (slot < em.out_n) em.out[slot] = (u8)oC[e];
+      else *em.last_char = oC[e];
+      lf_note(em, n, sfx, slot);
+    } else {
+      next.S[at] = oS[e]; next.P[at] = oP[e]; next.H[at] = oH[e]; next.C[at] = (u8)oC[e];
+      ++at;
+    }
+  }
+}
+
+// ---- bridge from the finisher to the doubling rounds: what is still tied (the hard list, with the
+// last pass's leftovers appended) is sorted by slot and dressed up as a list the rounds understand
+// (key = head slot | character << 56, value = suffix, positional slot array), and rank[] is completed
+// for everybody: rank[SA[slot]] = slot for the finished, the group's head slot for the others.
+__global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __restrict__ hardS,
+                                                     u64* __restrict__ hardHP, u32 at) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  hardS[at + i] = in.S[i];
+  hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)in.P[i];
+}
+__global__ __launch_bounds__(256) void k_bridge_dress(const u64* __restrict__ hp, const u32* __restrict__ sfx, u32 m,
+                                                      const u8* __restrict__ T, u64* __restrict__ key,
+                                                      u32* __restrict__ aglob) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  const u64 x = hp[i];
+  const u32 s = sfx[i];
+  key[i] = (x >> 32) | ((u64)(s ? T[s - 1u] : 0u) << 56);
+  aglob[i] = (u32)x;
+}
+__global__ __launch_bounds__(256) void k_bridge_pairs_all(const u32* __restrict__ SA, u32 n,
+                                                          u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+  const u32 p0 = blockIdx.x * 1024u + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32 p = p0 + (u32)e * 256u;
+    if (p < n) { pair_s[p] = SA[p]; pair_r[p] = p; }      // unfinished slots hold anything: k_bridge_pairs_fix rewrites them
+  }
+}
+__global__ __launch_bounds__(256) void k_bridge_pairs_fix(const u64* __restrict__ key, const u32* __restrict__ sfx,
+                                                          const u32* __restrict__ aglob, u32 m,
+                                                          u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  const u32 p = aglob[i];
+  pair_s[p] = sfx[i];
+  pair_r[p] = (u32)(key[i] & 0xFFFFFFFFull);
 }
 
 constexpr int kSimpleE = 4;   // independent items per thread in the latency-bound kernels
@@ -883,16 +1199,17 @@ __global__ __launch_bounds__(256) void k_bwt_gather(const u32* __restrict__ SA,
 // raw mode: out[pidx] = the input byte at pidx (divsufsort.c:507-511 leaves it untouched).
 // LF[0] = pidx, LF[k] = ISA[n - k*(n/nLF)] (divsufsort.c:337-338,350,381,390).
 // last_char (emitting rankers): the character of row n-1, which has no slot in a block's output.
+// lf_noted: LF[1..] were noted as the suffixes became final (lf_note); rank[] is not complete then.
 __global__ void k_finalize(u8* __restrict__ out, const u8* __restrict__ T,
                            const u32* __restrict__ rank, u32* __restrict__ lf, u32 n_lf, u32 n,
-                           const u32* __restrict__ pidx, int raw, const u32* __restrict__ last_char) {
+                           const u32* __restrict__ pidx, int raw, const u32* __restrict__ last_char, int lf_noted = 0) {
   const u32 p = *pidx;
   const u32 k = threadIdx.x;
   if (k == 0) {
     if (raw) out[p] = T[p];
     else if (p + 1u < n) out[p] = last_char ? (u8)*last_char : out[n - 1];
     lf[0] = p;
-  } else if (k < n_lf) {
+  } else if (k < n_lf && !lf_noted) {
     const u32 x = n / n_lf;
     lf[k] = rank[n - k * x];
   }
@@ -905,7 +1222,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -928,6 +1245,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_C1 = take(cap + 64);
   a.off_P0 = take(cap + 64);
   a.off_P1 = take(cap + 64);
+  a.off_W0 = take(cap * 4);
+  a.off_W1 = take(cap * 4);
   a.off_table = take(radix_table_words(cap) * 4);
   a.off_partial = take(radix_partial_words(cap) * 4);
   const u64 rr_tiles = (cap + kRrTile - 1) / kRrTile + 1;
@@ -976,6 +1295,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_C1 = base + a.off_C1;
   d_P0 = base + a.off_P0;
   d_P1 = base + a.off_P1;
+  d_W0 = reinterpret_cast<u32*>(base + a.off_W0);
+  d_W1 = reinterpret_cast<u32*>(base + a.off_W1);
   d_table = reinterpret_cast<u32*>(base + a.off_table);
   d_partial = reinterpret_cast<u32*>(base + a.off_partial);
   d_aggA = reinterpret_cast<u32*>(base + a.off_aggA);
@@ -1005,6 +1326,10 @@ int BwtEngine::init(int dev, u32 max_block_size) {
       gram_keys = gr[0] != '0';
       gram_count_override = std::atoi(gr);
     }
+    long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
+    if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
+    finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
+    if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -1114,7 +1439,8 @@ void BwtEngine::release() {
 }
 
 static constexpr int kSmallFreqs = 0, kSmallLf = 256, kSmallPidx = 512, kSmallCounts = 520,
-                     kSmallLut = 600;   // 64 words = 256-byte alphabet remap table
+                     kSmallLut = 600,   // 64 words = 256-byte alphabet remap table
+                     kSmallInv = 664;   // 64 words: dense code -> byte
 
 // Width of the initial sort key.  The alphabet of T is remapped to dense w-bit codes and as
 // many characters as fit are packed into a 32- or 64-bit key: 16 characters of DNA or 4 raw
@@ -1219,14 +1545,20 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
 // that hold ks / vs (free once the apply kernel has run).
 template <typename K, bool INIT>
 int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
-                         RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split) {
+                         RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split,
+                         const RrLong* lg) {
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
-  if (split) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, INIT && sizeof(K) == 8>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
-                                short_len, kmask, d_aggA, d_aggB, d_aggC);
+  constexpr bool kCanSplit = INIT && sizeof(K) == 8;
+  const bool lng = kCanSplit && lg && lg->w;              // items of the long-key sort (always split)
+  const RrLong lgv = lng ? *lg : RrLong();
+  if (lng) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, kCanSplit, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                              short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
+  else if (split) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                                short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
   else hipLaunchKernelGGL((k_rerank_reduce<K, INIT, false>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
-                          short_len, kmask, d_aggA, d_aggB, d_aggC);
+                          short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
   {
     const u32 parts = ceil_div(tiles, kRrScanChunk);
     hipLaunchKernelGGL(k_rerank_scan_tiles<0>, dim3(parts), dim3(1024), 0, st, d_aggA, d_aggB, d_aggC, tiles, d_agg_part, counts);
@@ -1245,17 +1577,30 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   if (emit && m_next && nbits > 56) return -3;         // can_carry() promised this cannot happen
   const bool dense = dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
   u32* sa_out = emit ? nullptr : d_SA;
+  // Long items of which at most a quarter is still tied: the finisher settles the rest by direct
+  // comparison (suffix_sort); rank[] is not written at all.
+  res->finish = lng && emit && finisher && (u64)m_next * 4 <= m;
+  if (res->finish) {
+    sa_out = d_SA;
+    if constexpr (kCanSplit)
+      hipLaunchKernelGGL((k_rerank_apply<K, INIT, 3, 3, true, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
+                         (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,
+                         rb.v_free, rb.aglob_next, d_GRP, (u32*)nullptr, (u32*)nullptr, re, lgv);
+    return 0;
+  }
   constexpr int kEmitKind = INIT ? 2 : 1;               // where the character comes from (see RrEmit)
   u64* recA = static_cast<u64*>(rb.rec_free);
   u64* recB = static_cast<u64*>(rb.rec_keys);
 
-#define BWTC_APPLY_S(MODE, EMIT, SP, PS, PR, AIDX)                                                          \
-  hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT, SP>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,   \
+#define BWTC_APPLY_S(MODE, EMIT, SP, LG, PS, PR, AIDX)                                                      \
+  hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT, SP, LG>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, \
                      (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,  \
-                     AIDX, rb.aglob_next, d_GRP, PS, PR, re)
+                     AIDX, rb.aglob_next, d_GRP, PS, PR, re, lgv)
+  // long items carry their character's code in the key: EMIT kind 3 whatever the caller names
 #define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
-  do { if (split) BWTC_APPLY_S(MODE, EMIT, (INIT && sizeof(K) == 8), PS, PR, AIDX);                       \
-       else BWTC_APPLY_S(MODE, EMIT, false, PS, PR, AIDX); } while (0)
+  do { if (lng) BWTC_APPLY_S(MODE, ((EMIT) ? 3 : 0), kCanSplit, kCanSplit, PS, PR, AIDX);                  \
+       else if (split) BWTC_APPLY_S(MODE, EMIT, kCanSplit, false, PS, PR, AIDX);                          \
+       else BWTC_APPLY_S(MODE, EMIT, false, false, PS, PR, AIDX); } while (0)
   if (dense) {
     u32* tri_key = reinterpret_cast<u32*>(recA);
     // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
@@ -1315,6 +1660,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
 // the base-sigma key.  The gram length is the longest whose universe fits kGramMaxU; the key takes
 // as few grams as cover the base-sigma key's characters, and is used when that saves a radix pass.
 static constexpr int kSmallGram = 526;
+static constexpr int kSmallFin = 528;     // finisher: entries of the next list, of the hard list
 int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp) {
   hipStream_t st = stream;
   gp->G = 0;
@@ -1386,6 +1732,13 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   re.achr_out = d_C0;
   re.rec_plane = nullptr;
   re.rec_shift = 0;
+  re.inv_lut = reinterpret_cast<const u8*>(d_small + kSmallInv);
+  re.lf = d_small + kSmallLf; re.lf_n = 0; re.lf_x = 0; re.lf_inv = 0;
+  if (emit && em->n_lf > 1 && n / em->n_lf > 1) {
+    re.lf_n = em->n_lf; re.lf_x = n / em->n_lf; re.lf_inv = (u32)((1ull << 32) / re.lf_x);
+  }
+  bridged = false;
+  lf_noted = false;
   u8* achr_other = d_C1;
 
   RankBuffers rb;
@@ -1393,6 +1746,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   rb.aglob_next = d_G0;
   u32* aglob_spare = d_G1;
   RankResult res;
+  res.finish = false;
   u64 h = (u64)plan.k;                    // the next round compares rank[s + h]
 
   // initial sort + ranking
@@ -1416,9 +1770,49 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // Keys of at most 48 bits leave room for the upper bits of the suffix number: the passes of
     // the initial sort then carry (u64 key, u16 low half) = 10 bytes per item instead of 12.
     const int split = (split_index && implied_idx && key_bits <= 48 && n <= (1u << 29)) ? 1 : 0;
-    if (gp.G > 0) {
+    // Long keys: the sort also orders by a second key word (the next G2 grams) and the items carry
+    // their predecessor character's code -- when the fields fit: key bits + 13 + code bits <= 64.
+    LongKey lk;
+    lk.w = nullptr; lk.G2 = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
+    if (long_keys && gp.G > 0 && split && emit && key_plane && n >= kGramMinN) {
+      const int cb = std::max(1, bit_width_u64(plan.sigma - 1));
+      int G2 = std::min(32 / gp.b, (64 - gp.g * gp.G) / gp.g);
+      G2 = std::min(G2, long_grams_override > 0 ? long_grams_override : 2);
+      if (G2 >= 1 && key_bits + 13 + cb <= 64) {
+        lk.w = d_W0; lk.G2 = G2; lk.hi_shift = key_bits; lk.chr_shift = key_bits + 13; lk.chr_mask = (1u << cb) - 1u;
+        u8 inv[256];
+        std::memset(inv, 0, sizeof inv);
+        for (int c = 255; c >= 0; --c) if (hist[c] && !(c == 0 && lone_sentinel)) inv[plan.lut[c]] = (u8)c;
+        std::memcpy(h_small + kSmallInv, inv, 256);
+        BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallInv, h_small + kSmallInv, 256, hipMemcpyHostToDevice, st));
+      }
+    }
+    if (lk.w) {
+      const int w_bits = gp.b * lk.G2;
+      short_len = (u32)(gp.g * (gp.G + lk.G2));
+      h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const uint4*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split);
+                         (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, 1, lk);
+      u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
+      radix_sort_long<unsigned short>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
+                                      d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
+      BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+      u32* vs = reinterpret_cast<u32*>(vs16);
+      rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
+      rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
+      RrLong lg;
+      lg.w = ws; lg.wmask = w_bits >= 32 ? ~0u : (1u << w_bits) - 1u;
+      lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask;
+      if (std::getenv("BWTC_HIP_DEBUG"))
+        std::fprintf(stderr, "long keys: %d + %d bits, %d + %d grams of %d characters, character code at bit %d\n",
+                     key_bits, w_bits, gp.G, lk.G2, gp.g, lk.chr_shift);
+      rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, 1u, &lg);
+      if (rc) return rc;
+      stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits);
+      key_bits = 0;                                      // counted
+    } else if (gp.G > 0) {
+      hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
+                         (const uint4*)d_rank, ka, idx_out, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split, lk);
     } else {
       u64 top = 1;
       for (int t = 1; t < plan.k; ++t) top *= plan.sigma;
@@ -1426,7 +1820,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
                          idx_out, n, plan.k, plan.sigma, top, key_plane, split);
     }
     u64* ks = nullptr; u32* vs = nullptr;
-    if (split) {
+    if (lk.w) {
+      // sorted and ranked above
+    } else if (split) {
       unsigned short* vs16 = nullptr;
       radix_sort_pairs<u64, unsigned short>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
                                             n, key_bits, d_table, d_partial, stream, &ks, &vs16, &probe, 0, false, false, 0,
@@ -1436,10 +1832,12 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     } else {
       sort_pairs<u64>(ka, kb, d_V0, d_V1, n, key_bits, &ks, &vs, true, 0, 0, key_plane != nullptr, implied_idx);
     }
-    BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-    rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
-    rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
-    rc = rank_step<u64, true>(ks, vs, n, n, short_len, split ? ((1ull << 48) - 1ull) : ~0ull, rb, re, emit, h, &res, (u32)split);
+    if (!lk.w) {
+      BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
+      rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
+      rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
+      rc = rank_step<u64, true>(ks, vs, n, n, short_len, split ? ((1ull << 48) - 1ull) : ~0ull, rb, re, emit, h, &res, (u32)split);
+    }
   } else {
     u32* ka = static_cast<u32*>(d_R1);
     u32* kb = ka + cap;
@@ -1459,12 +1857,23 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 
   const u64 round_mask = emit ? ((1ull << 56) - 1ull) : ~0ull;
   u32 m = res.m;
+  bool keep_h = false;                     // the list handed over by the bridge is sorted to depth h as it stands
+  if (res.finish) {
+    if (re.lf_n == 0 && em->n_lf > 1) return -3;
+    u32 m2 = 0; u64 h2 = 0;
+    rc = finish_list(n, m, short_len, rb, re, &res, &m2, &h2);
+    if (rc) return rc;
+    m = m2;
+    if (m) { h = h2; keep_h = true; }
+    lf_noted = !bridged;
+  }
   while (m > 0) {
     if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
     ++stats.rounds;
     stats.active_sum += m;
     if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u: h=%llu m=%u groups=%u\n", stats.rounds, (unsigned long long)h, m, res.groups);
-    h *= 2;
+    if (!keep_h) h *= 2;
+    keep_h = false;
     // the list just sorted: positions are the active list's, aglob gives their global slots
     rb.aglob = rb.aglob_next;
     rb.aglob_next = aglob_spare;
@@ -1480,6 +1889,61 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   }
   BWTC_HIP_TRY(hipGetLastError());
   BWTC_HIP_TRY(take_sticky_error());
+  return 0;
+}
+
+// The finisher passes over the list the long-key ranking left (k_finish), and -- when something is
+// still tied after them, or a group was too large for them -- the bridge into the doubling rounds.
+// On return *m_out entries (0: all done) wait in res / rb as a sorted list of depth *h_out.
+int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
+  hipStream_t st = stream;
+  u32* cnt = d_small + kSmallFin;                      // [0] next list, [1] hard list
+  FinList a{rb.v_free, rb.aglob_next, d_GRP, re.achr_out};
+  FinList b{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, re.achr_out == d_C0 ? d_C1 : d_C0};
+  u64* hardHP = static_cast<u64*>(rb.rec_free);
+  u32* hardS = rb.v_keys;
+  BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
+  u32 hard = 0;
+  for (int it = 0; it < fin_max_passes && m > 0; ++it) {
+    ++stats.rounds;
+    stats.active_sum += m;
+    BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
+    hipLaunchKernelGGL(k_finish, dim3(ceil_div(m, kFinStride)), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, depth,
+                       b, cnt, hardS, hardHP, cnt + 1, d_SA, re);
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 8, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(wait());
+    if (std::getenv("BWTC_HIP_DEBUG"))
+      std::fprintf(stderr, "finisher pass %d: depth %u, %u entries -> %u still tied, %u hard\n", it, depth, m,
+                   h_small[kSmallFin], h_small[kSmallFin + 1]);
+    m = h_small[kSmallFin];
+    hard = h_small[kSmallFin + 1];
+    depth += kFinChars;
+    std::swap(a, b);
+  }
+  *m_out = 0;
+  if (m == 0 && hard == 0) return 0;
+  // ---- bridge
+  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard);
+  const u32 total = hard + m;
+  if ((u64)total > cap) return -3;
+  u64* hp_sorted = nullptr; u32* s_sorted = nullptr;
+  sort_pairs<u64>(hardHP, static_cast<u64*>(rb.rec_keys), hardS, rb.v_free, total, bit_width_u64(n ? n - 1 : 0),
+                  &hp_sorted, &s_sorted, false);
+  u64* fkey = reinterpret_cast<u64*>(d_W0);              // d_W0 and d_W1 are neighbours in the arena: 8 * cap bytes
+  hipLaunchKernelGGL(k_bridge_dress, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)hp_sorted, (const u32*)s_sorted,
+                     total, (const u8*)d_T, fkey, d_G0);
+  u32* pairs = static_cast<u32*>(d_R1);
+  hipLaunchKernelGGL(k_bridge_pairs_all, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u32*)d_SA, n, pairs, pairs + cap);
+  hipLaunchKernelGGL(k_bridge_pairs_fix, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)fkey, (const u32*)s_sorted,
+                     (const u32*)d_G0, total, pairs, pairs + cap);
+  scatter_rank_pairs(pairs, static_cast<u32*>(d_R2), n, n);
+  res->m = total; res->groups = 0;
+  res->ks = fkey; res->rec_other = d_R1;
+  res->vs = s_sorted; res->v_other = s_sorted == d_V0 ? d_V1 : d_V0;
+  rb.aglob_next = d_G0;
+  *m_out = total;
+  *h_out = depth;
+  bridged = true;
   return 0;
 }
 
@@ -1524,11 +1988,12 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
     EmitTarget em;
     em.out = d_dst;
     em.out_n = raw ? n : size;
+    em.n_lf = n_lf;
     rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0, &em);
     if (rc) return rc;
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d_dst, d_T, d_rank,
                        d_small + kSmallLf, n_lf, n, d_small + kSmallPidx, raw ? 1 : 0,
-                       d_small + kSmallLastChar);
+                       d_small + kSmallLastChar, lf_noted ? 1 : 0);
   } else {
     rc = suffix_sort(n, hist_T, h_small[kSmallFreqs] == 0, nullptr);
     if (rc) return rc;

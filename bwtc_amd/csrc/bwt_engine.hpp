@@ -36,6 +36,7 @@
 namespace bwtc_hip {
 
 struct RrEmit;
+struct RrLong;
 
 // ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
 // Page-locked host bytes: the packed streams are copied from the device straight into the
@@ -266,6 +267,8 @@ struct BwtEngine {
   u8* d_C1 = nullptr;
   u8* d_P0 = nullptr;      // cap : digit planes of the radix passes (radix_sort.hpp)
   u8* d_P1 = nullptr;
+  u32* d_W0 = nullptr;     // cap : second key words of the long-key initial sort (ping-pong)
+  u32* d_W1 = nullptr;
   u32* d_table = nullptr;  // radix tables
   u32* d_partial = nullptr;
   u32* d_aggA = nullptr;   // rerank tile aggregates
@@ -353,7 +356,7 @@ struct BwtEngine {
   // em != nullptr: instead of storing the suffix array the ranking kernels write the
   // transform's bytes, out[slot] = T[SA[slot]-1] for slot < out_n, as suffixes become final
   // (blocks for which can_carry() holds only; see k_rerank_apply).
-  struct EmitTarget { u8* out; u32 out_n; };
+  struct EmitTarget { u8* out; u32 out_n; u32 n_lf; };
   int suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const EmitTarget* em = nullptr);
   // radix sort front door: picks the chained single-read passes or the classic ones
   template <typename K>
@@ -361,10 +364,11 @@ struct BwtEngine {
                   bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false, bool values_descend = false);
   // one ranking step of the suffix sorter (bwt_engine.hip)
   struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
-  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; };
+  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; bool finish; };
   template <typename K, bool INIT>
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
-                struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0);
+                struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0,
+                const struct RrLong* lg = nullptr);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
@@ -374,6 +378,13 @@ struct BwtEngine {
   struct GramPlan { int g = 0, G = 0, b = 0; u32 top = 0; };
   int plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp);
   bool no_emit = false;      // BWTC_HIP_NO_EMIT: suffix array + gather even for blocks that could carry
+  bool long_keys = true;     // BWTC_HIP_LONG=0: never the long-key initial sort
+  bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
+  int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
+  bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
+  bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
+  int finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
+  int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
   // Device-resident block transform: d_src (size bytes) -> d_dst (size bytes).

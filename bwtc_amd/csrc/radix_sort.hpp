@@ -14,6 +14,7 @@
 #pragma once
 #include "common.hpp"
 #include "scan.hpp"
+#include <algorithm>
 
 namespace bwtc_hip {
 
@@ -40,6 +41,21 @@ template <typename K> constexpr int radix_tile() { return kRadixTPB * RadixCfg<K
 template <typename K>
 __device__ __forceinline__ u32 radix_digit(K k, int shift) {
   return (u32)(k >> shift) & (kRadixBins - 1);
+}
+
+// Long items (the suffix sorter's long-key initial sort): every item carries a second 32-bit key word w
+// beside (key, value).  The early passes take their digits from w, the later ones from the key; dmask
+// cuts a field's top digit to the field's bits (whatever sits above them is payload, not order).
+struct LongArgs {
+  const u32* win; u32* wout;
+  u32 dmask;                     // this pass's digit mask
+  int nshift, nfrom_w; u32 ndmask;   // the NEXT pass's digit (for the plane this pass leaves)
+};
+template <typename K, int LONG>
+__device__ __forceinline__ u32 long_digit(K k, u32 w, int shift, u32 dmask) {
+  if (LONG == 2) return (w >> shift) & dmask;
+  if (LONG == 1) return (u32)(k >> shift) & dmask;
+  return radix_digit(k, shift);
 }
 
 // skip: items whose key is all ones do not exist (first pass of a sort whose input was written
@@ -84,21 +100,23 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 // KEYS: keys only (no values staged: half the LDS of a 32-bit pair tile, twice the workgroups per CU).
 // V: the values' type in memory, u32 or u16 (the suffix sorter's initial sort keeps the upper bits
 // of a suffix number in spare bits of its key, so that a pass moves 10 bytes per item instead of 12).
-template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32>
+// LONG (see LongArgs): 0 plain items; 1 long items, digit from the key; 2 long items, digit from w.
+template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32, int LONG = 0, int E_ = RadixCfg<K>::E>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const V* __restrict__ vin, K* __restrict__ kout,
     V* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
-    u8* __restrict__ plane) {
-  constexpr int E = RadixCfg<K>::E;
+    u8* __restrict__ plane, LongArgs la) {
+  constexpr int E = E_;
   constexpr int TILE = kRadixTPB * E;
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
   // tile slots, so the reorder staging (keys, then values) reuses their bytes; that keeps
   // the (u64,u32) kernel at 50 KiB = three workgroups per CU.
-  constexpr int kStageBytes = TILE * (int)(sizeof(K) + (KEYS ? 0 : sizeof(V)));
+  constexpr int kStageBytes = TILE * (int)(sizeof(K) + (KEYS ? 0 : sizeof(V)) + (LONG ? sizeof(u32) : 0));
   constexpr int kCntBytes = kRadixWaves * kRadixBins * (int)sizeof(u32);
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStageBytes > kCntBytes ? kStageBytes : kCntBytes];
   K* s_key = reinterpret_cast<K*>(s_raw);
-  V* s_val = reinterpret_cast<V*>(s_raw + TILE * sizeof(K));
+  u32* s_w = reinterpret_cast<u32*>(s_raw + TILE * sizeof(K));                       // LONG only
+  V* s_val = reinterpret_cast<V*>(s_raw + TILE * (sizeof(K) + (LONG ? sizeof(u32) : 0)));
   u32 (*s_cnt)[kRadixBins] = reinterpret_cast<u32 (*)[kRadixBins]>(s_raw);
   __shared__ u32 s_base[kRadixBins];               // first tile slot of each digit
   __shared__ u32 s_gofs[kRadixBins];               // global base minus tile slot
@@ -135,6 +153,14 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const u32 slot = wslot + e * kWave;
     k[e] = slot < tile_n ? kin[tile_base + slot] : (K)0;
   }
+  u32 w[LONG ? E : 1] = {};
+  if (LONG) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const u32 slot = wslot + e * kWave;
+      w[LONG ? e : 0] = slot < tile_n ? la.win[tile_base + slot] : 0u;
+    }
+  }
   // values_mode 1 / 3: first pass of a sort whose values are the items' own positions (3: counted
   // down from n - 1, the suffix sorter's descending slots), nothing to read; 2: keys only.
   if (KEYS) {
@@ -163,7 +189,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const bool ok = BWTC_EXISTS(e);
-    const u32 d = radix_digit(k[e], shift);
+    const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask);
     u32 below, peers;
     wave_digit_rank<kRadixBits>(d, ok, &below, &peers);
     u32 prev = 0;
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (BWTC_EXISTS(e)) {
-      const u32 d = radix_digit(k[e], shift);
+      const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask);
       r[e] += s_base[d] + s_cnt[wave][d];          // final tile slot
     }
   }
@@ -207,6 +233,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     if (BWTC_EXISTS(e)) {
       s_key[r[e]] = k[e];
       if (!KEYS) s_val[r[e]] = (V)v[e];
+      if (LONG) s_w[r[e]] = w[LONG ? e : 0];
     }
   }
 #undef BWTC_EXISTS
@@ -216,15 +243,17 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   // all LDS reads of a thread's E items first, then the offsets, then the stores (a loop over i
   // ran two dependent LDS latencies per item, one item at a time)
   K kk[E];
-  u32 vv[E], dst[E];
+  u32 vv[E], dst[E], ww[LONG ? E : 1] = {};
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const u32 i = tid + (u32)e * kRadixTPB;
     kk[e] = i < tile_out ? s_key[i] : (K)0;
     vv[e] = (i < tile_out && !KEYS) ? s_val[i] : 0u;
+    if (LONG) ww[LONG ? e : 0] = i < tile_out ? s_w[i] : 0u;
   }
 #pragma unroll
-  for (int e = 0; e < E; ++e) dst[e] = s_gofs[radix_digit(kk[e], shift)] + tid + (u32)e * kRadixTPB;
+  for (int e = 0; e < E; ++e)
+    dst[e] = s_gofs[long_digit<K, LONG>(kk[e], ww[LONG ? e : 0], shift, la.dmask)] + tid + (u32)e * kRadixTPB;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (tid + (u32)e * kRadixTPB < tile_out) {
@@ -232,7 +261,11 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
       // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
       kout[dst[e]] = kk[e];
       if (!KEYS) vout[dst[e]] = (V)vv[e];
-      if (PLANE) plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
+      if (LONG) la.wout[dst[e]] = ww[LONG ? e : 0];
+      if (PLANE) {
+        if (LONG) plane[dst[e]] = (u8)((la.nfrom_w ? ww[LONG ? e : 0] >> la.nshift : (u32)(kk[e] >> la.nshift)) & la.ndmask);
+        else plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
+      }
     }
   }
 }
@@ -366,7 +399,7 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
       else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr)
+#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr, LongArgs())
       if (keys_only) { if (make_plane) BWTC_SCATTER(false, true, true); else BWTC_SCATTER(false, false, true); }   // never with holes
       else if (skip) { if (make_plane) BWTC_SCATTER(true, true, false); else BWTC_SCATTER(true, false, false); }
       else { if (make_plane) BWTC_SCATTER(false, true, false); else BWTC_SCATTER(false, false, false); }
@@ -381,6 +414,48 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
   }
   *k_sorted = kin;
   *v_sorted = vin;
+}
+
+// Long-key sort of the suffix sorter: items (u64 key, V value, u32 w) ordered by (key bits [0, kbits),
+// w bits [0, wbits)) -- w is the LESS significant word, so its passes come first.  Stable.  The
+// producer of the items left the first pass's digits (of w) in plane0; both planes are required.
+// The first pass makes the values up (item i's value is n - 1 - i).
+template <typename V>
+static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32* w1, u64 n, int kbits, int wbits,
+                                   u32* table, u32* partial, hipStream_t st, u64** k_sorted, V** v_sorted,
+                                   u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1) {
+  u64 *kin = k0, *kout = k1;
+  V *vin = v0, *vout = v1;
+  u32 *win = w0, *wout = w1;
+  struct Pass { int from_w, shift; u32 dmask; };
+  Pass ps[24];
+  int np = 0;
+  for (int s = 0; s < wbits; s += kRadixBits) ps[np++] = Pass{1, s, (1u << std::min(kRadixBits, wbits - s)) - 1u};
+  for (int s = 0; s < kbits; s += kRadixBits) ps[np++] = Pass{0, s, (1u << std::min(kRadixBits, kbits - s)) - 1u};
+  if (n > 1) {
+    const u32 ntiles = ceil_div(n, radix_tile<u64>());
+    const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
+    for (int p = 0; p < np; ++p) {
+      hipLaunchKernelGGL(k_radix_hist_plane<u64>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles);
+      exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
+      const bool last = p + 1 == np;
+      LongArgs la;
+      la.win = win; la.wout = wout; la.dmask = ps[p].dmask;
+      la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
+      const int vmode = p == 0 ? 3 : 0;
+      const bool timed = probe && probe->begin(st);
+#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la)
+      if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
+      else { if (last) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
+#undef BWTC_SCATTER_L
+      if (timed) probe->end(st, 2 * n * (sizeof(u64) + sizeof(V) + sizeof(u32)) + (last ? 0 : n));
+      { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
+      { u64* t = kin; kin = kout; kout = t; }
+      { V* t = vin; vin = vout; vout = t; }
+      { u32* t = win; win = wout; wout = t; }
+    }
+  }
+  *k_sorted = kin; *v_sorted = vin; *w_sorted = win;
 }
 
 
