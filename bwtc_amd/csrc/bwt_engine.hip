@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
         pair_r[p] = a ? grp : 0xFFFFFFFFu;
         if (em.rec_plane) em.rec_plane[p] = (u8)(s >> em.rec_shift);
       } else if (MODE == 1) { pair_s[p] = s; pair_r[p] = nr; }
-      else if (MODE == 0) rank[s] = nr;
+      else if (MODE == 0) { if (rank) rank[s] = nr; }
       if (a) {
         const u32 q = qs[e];
         aglob_out[q] = g;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
           if (s == 0u) *em.pidx = g;
           if (g < em.out_n) em.out[g] = (u8)c;
           else *em.last_char = c;
-          if (MODE == 3) lf_note(em, n, s, g);
+          lf_note(em, n, s, g);                    // nothing unless the caller asked for notes (lf_n)
         }
       }
     }
@@ -985,14 +985,13 @@ __global__ __launch_bounds__(256) void k_bridge_pairs_all(const u32* __restrict_
     if (p < n) { pair_s[p] = SA[p]; pair_r[p] = p; }      // unfinished slots hold anything: k_bridge_pairs_fix rewrites them
   }
 }
-__global__ __launch_bounds__(256) void k_bridge_pairs_fix(const u64* __restrict__ key, const u32* __restrict__ sfx,
-                                                          const u32* __restrict__ aglob, u32 m,
+__global__ __launch_bounds__(256) void k_bridge_pairs_fix(const u32* __restrict__ sfx, const u32* __restrict__ aglob, u32 m,
                                                           u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= m) return;
   const u32 p = aglob[i];
   pair_s[p] = sfx[i];
-  pair_r[p] = (u32)(key[i] & 0xFFFFFFFFull);
+  pair_r[p] = p;
 }
 
 constexpr int kSimpleE = 4;   // independent items per thread in the latency-bound kernels
@@ -1170,6 +1169,24 @@ __global__ __launch_bounds__(256) void k_gather_key2(const u32* __restrict__ aid
   }
 }
 
+// Text round (after the finisher, for the groups it could not take): the second sort key is the
+// suffix's next c characters themselves, no rank[] needed:
+//   key = group << (8c + 4) | characters << 4 | t,   t = c - (characters past the end of T), so that of
+// suffixes equal on those characters the one that ends there comes first, shortest first.
+__global__ __launch_bounds__(256) void k_gather_text(const u32* __restrict__ aidx, const u32* __restrict__ agrp,
+                                                     const u8* __restrict__ T, const u8* __restrict__ achr,
+                                                     u64* __restrict__ key, u32 m, u32 n, u32 h, u32 c) {
+  const u32 p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= m) return;
+  const u32 s = aidx[p];
+  u64 c0, c1;
+  fin_chars(T, s + h, n, &c0, &c1);                      // s + h < 2^31: h stays small in text rounds
+  const u64 chars = c0 >> (64u - 8u * c);
+  const u64 end = (u64)s + h + c;
+  const u32 over = end > (u64)n ? (u32)min((u64)c, end - (u64)n) : 0u;
+  key[p] = ((u64)agrp[p] << (8u * c + 4u)) | (chars << 4) | (u64)(c - over) | (achr ? (u64)achr[p] << 56 : 0ull);
+}
+
 // ---------------------------------------------------------------------------------------
 // K9  BWT gather: out[j] = T[SA[j]-1]; the row of suffix 0 is the end-of-block row.
 // ---------------------------------------------------------------------------------------
@@ -1330,6 +1347,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
+    if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS")));
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -1546,7 +1564,7 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
 template <typename K, bool INIT>
 int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
                          RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split,
-                         const RrLong* lg) {
+                         const RrLong* lg, bool text) {
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
@@ -1575,13 +1593,15 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   const int b1 = bit_width_u64(groups ? groups - 1 : 0);
   const int nbits = b1 + b2;
   if (emit && m_next && nbits > 56) return -3;         // can_carry() promised this cannot happen
-  const bool dense = dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
-  u32* sa_out = emit ? nullptr : d_SA;
+  const bool dense = !text && dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
+  u32* sa_out = (emit && !fin_active) ? nullptr : d_SA;   // finisher route: the bridge will want the finished suffixes' slots
+  u32* rank_arg = text ? nullptr : d_rank;                // text rounds: rank[] is neither complete nor needed
   // Long items of which at most a quarter is still tied: the finisher settles the rest by direct
   // comparison (suffix_sort); rank[] is not written at all.
   res->finish = lng && emit && finisher && (u64)m_next * 4 <= m;
   if (res->finish) {
     sa_out = d_SA;
+    fin_active = true;
     if constexpr (kCanSplit)
       hipLaunchKernelGGL((k_rerank_apply<K, INIT, 3, 3, true, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
                          (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,
@@ -1594,7 +1614,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
 
 #define BWTC_APPLY_S(MODE, EMIT, SP, LG, PS, PR, AIDX)                                                      \
   hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT, SP, LG>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, \
-                     (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,  \
+                     (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, rank_arg, sa_out, \
                      AIDX, rb.aglob_next, d_GRP, PS, PR, re, lgv)
   // long items carry their character's code in the key: EMIT kind 3 whatever the caller names
 #define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
@@ -1630,6 +1650,21 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     return 0;
   }
   u32* pairs = reinterpret_cast<u32*>(recA);
+  if (text) {
+    // text round: rank[] is neither complete nor needed
+    res->text_chars = (u32)std::min(6, (56 - b1 - 4) / 8);
+    if (emit) BWTC_APPLY(0, kEmitKind, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    else BWTC_APPLY(0, 0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    if (m_next == 0) return 0;
+    const int tbits = b1 + 8 * (int)res->text_chars + 4;
+    hipLaunchKernelGGL(k_gather_text, dim3(ceil_div(m_next, 256)), dim3(256), 0, st, (const u32*)rb.v_free, (const u32*)d_GRP,
+                       (const u8*)d_T, emit ? (const u8*)re.achr_out : (const u8*)nullptr, recA, m_next, n, (u32)h_next, res->text_chars);
+    sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m_next, tbits, &res->ks, &res->vs, false);
+    stats.sort_pass_items += (u64)m_next * (u64)((tbits + kRadixBits - 1) / kRadixBits);
+    res->rec_other = res->ks == recA ? recB : recA;
+    res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
+    return 0;
+  }
   if (m >= kPairsMin || INIT) {
     if (emit) BWTC_APPLY(1, kEmitKind, pairs, pairs + cap, rb.v_free);
     else BWTC_APPLY(1, 0, pairs, pairs + cap, rb.v_free);
@@ -1739,6 +1774,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   }
   bridged = false;
   lf_noted = false;
+  fin_active = false;
   u8* achr_other = d_C1;
 
   RankBuffers rb;
@@ -1857,23 +1893,34 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 
   const u64 round_mask = emit ? ((1ull << 56) - 1ull) : ~0ull;
   u32 m = res.m;
-  bool keep_h = false;                     // the list handed over by the bridge is sorted to depth h as it stands
+  bool keep_h = false;                     // the list is sorted to depth h as it stands (no doubling before the next step)
+  int text_left = 0;                       // rounds that compare the text itself (finisher route, rank[] incomplete)
+  bool ranks_complete = true;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
     u32 m2 = 0; u64 h2 = 0;
     rc = finish_list(n, m, short_len, rb, re, &res, &m2, &h2);
     if (rc) return rc;
     m = m2;
-    if (m) { h = h2; keep_h = true; }
-    lf_noted = !bridged;
+    if (m) { h = h2; keep_h = true; text_left = text_rounds; ranks_complete = false; }
+    lf_noted = true;
   }
   while (m > 0) {
     if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
     ++stats.rounds;
     stats.active_sum += m;
-    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u: h=%llu m=%u groups=%u\n", stats.rounds, (unsigned long long)h, m, res.groups);
+    const bool text = text_left > 0;
+    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u%s: h=%llu m=%u groups=%u\n", stats.rounds, text ? " (text)" : "", (unsigned long long)h, m, res.groups);
     if (!keep_h) h *= 2;
     keep_h = false;
+    if (!text && !ranks_complete) {
+      // the doubling rounds start here: rank[] for everybody first (the finished from SA; the list's own
+      // ranks come from the ranking step below, before anything reads them)
+      complete_ranks(n, res.vs, rb.aglob_next, m, res.rec_other == d_R2 ? (res.ks == (u64*)d_R1 ? (void*)d_W0 : d_R1) : d_R2, res.rec_other);
+      ranks_complete = true;
+      bridged = true;
+      lf_noted = false;
+    }
     // the list just sorted: positions are the active list's, aglob gives their global slots
     rb.aglob = rb.aglob_next;
     rb.aglob_next = aglob_spare;
@@ -1883,9 +1930,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     rb.v_keys = res.vs; rb.v_free = res.v_other;
     const u64* ks = res.ks;
     const u32* vs = res.vs;
-    rc = rank_step<u64, false>(ks, vs, m, n, 0u, round_mask, rb, re, emit, h, &res);
+    rc = rank_step<u64, false>(ks, vs, m, n, 0u, round_mask, rb, re, emit, h, &res, 0u, nullptr, text);
     if (rc) return rc;
     m = res.m;
+    if (text) { h += res.text_chars; keep_h = true; --text_left; }
   }
   BWTC_HIP_TRY(hipGetLastError());
   BWTC_HIP_TRY(take_sticky_error());
@@ -1903,7 +1951,7 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
   u64* hardHP = static_cast<u64*>(rb.rec_free);
   u32* hardS = rb.v_keys;
   BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
-  u32 hard = 0;
+  u32 hard = 0, hard_depth = depth;
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
@@ -1916,13 +1964,15 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
       std::fprintf(stderr, "finisher pass %d: depth %u, %u entries -> %u still tied, %u hard\n", it, depth, m,
                    h_small[kSmallFin], h_small[kSmallFin + 1]);
     m = h_small[kSmallFin];
+    if (hard == 0 && h_small[kSmallFin + 1]) hard_depth = depth;
     hard = h_small[kSmallFin + 1];
     depth += kFinChars;
     std::swap(a, b);
   }
   *m_out = 0;
   if (m == 0 && hard == 0) return 0;
-  // ---- bridge
+  // ---- what is still tied becomes a list the rounds understand: sorted by slot (groups contiguous,
+  // a positional slot array), key = head slot | character << 56, value = suffix
   if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard);
   const u32 total = hard + m;
   if ((u64)total > cap) return -3;
@@ -1932,19 +1982,23 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
   u64* fkey = reinterpret_cast<u64*>(d_W0);              // d_W0 and d_W1 are neighbours in the arena: 8 * cap bytes
   hipLaunchKernelGGL(k_bridge_dress, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)hp_sorted, (const u32*)s_sorted,
                      total, (const u8*)d_T, fkey, d_G0);
-  u32* pairs = static_cast<u32*>(d_R1);
-  hipLaunchKernelGGL(k_bridge_pairs_all, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u32*)d_SA, n, pairs, pairs + cap);
-  hipLaunchKernelGGL(k_bridge_pairs_fix, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)fkey, (const u32*)s_sorted,
-                     (const u32*)d_G0, total, pairs, pairs + cap);
-  scatter_rank_pairs(pairs, static_cast<u32*>(d_R2), n, n);
   res->m = total; res->groups = 0;
   res->ks = fkey; res->rec_other = d_R1;
   res->vs = s_sorted; res->v_other = s_sorted == d_V0 ? d_V1 : d_V0;
   rb.aglob_next = d_G0;
   *m_out = total;
-  *h_out = depth;
-  bridged = true;
+  *h_out = hard ? hard_depth : depth;                    // every group of the list shares at least that many characters
   return 0;
+}
+
+// rank[] for everybody, late: rank[SA[slot]] = slot for the finished suffixes, any rank for the list's
+// (the ranking step that follows writes theirs).  pairs / tmp: two free 8 * cap-byte regions.
+void BwtEngine::complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region) {
+  hipStream_t st = stream;
+  u32* pairs = static_cast<u32*>(pairs_region);
+  hipLaunchKernelGGL(k_bridge_pairs_all, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u32*)d_SA, n, pairs, pairs + cap);
+  if (m) hipLaunchKernelGGL(k_bridge_pairs_fix, dim3(ceil_div(m, 256)), dim3(256), 0, st, list_sfx, list_slot, m, pairs, pairs + cap);
+  scatter_rank_pairs(pairs, static_cast<u32*>(tmp_region), n, n);
 }
 
 // Loads `ncopy` bytes of d_src into d_T (reversed or not), zero-fills up to n + padding and

@@ -364,11 +364,11 @@ struct BwtEngine {
                   bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false, bool values_descend = false);
   // one ranking step of the suffix sorter (bwt_engine.hip)
   struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
-  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; bool finish; };
+  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; bool finish; u32 text_chars; };
   template <typename K, bool INIT>
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
                 struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0,
-                const struct RrLong* lg = nullptr);
+                const struct RrLong* lg = nullptr, bool text = false);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
@@ -381,8 +381,11 @@ struct BwtEngine {
   bool long_keys = true;     // BWTC_HIP_LONG=0: never the long-key initial sort
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
   int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
+  int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
+  bool fin_active = false;   // this block takes the finisher route: finished suffixes also go to d_SA
   bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
+  void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
   int finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
