@@ -179,6 +179,40 @@ def cpu_baseline_c4(size_mib, coder, cpus, n=8):
                       "value = all their bytes / the slowest run" % (n, size_mib, 30 + n - 1, _ranges(cpus))}
 
 
+def _cpu_seconds():
+    """user + system CPU seconds of this process so far (all threads)."""
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
+def _thread_cpu():
+    """{tid: (name, CPU seconds)} of this process's threads."""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open("/proc/self/task/%s/stat" % tid).read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tck)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def _cgroup_throttle():
+    """(periods, throttled periods, throttled seconds) of this process's cgroup, or None."""
+    try:
+        d = {}
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, _, v = line.partition(" ")
+            d[k] = int(v)
+        return (d.get("nr_periods", 0), d.get("nr_throttled", 0), d.get("throttled_usec", 0) / 1e6)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     if len(sys.argv) == 6 and sys.argv[1] == "--cpu-c4-worker":
         _cpu_c4_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
@@ -278,21 +312,33 @@ def main():
     def upload(i):
         ctx.to_device_async(d_in[i % 2], pool[i % nblk])
 
+    feeder_cpu = {}                                      # BWTC_BENCH_THREAD_CPU=1: CPU seconds of this thread per call site
+
+    def cpu_of(name, fn, *a):
+        if os.environ.get("BWTC_BENCH_THREAD_CPU") != "1":
+            return fn(*a)
+        c0, w0 = time.thread_time(), time.perf_counter()
+        r = fn(*a)
+        v = feeder_cpu.setdefault(name, [0.0, 0.0])
+        v[0] += time.thread_time() - c0
+        v[1] += time.perf_counter() - w0
+        return r
+
     def step():
         i = issued[0]
         if coder == "B" and len(pending) >= depth:
-            collect()                                    # the oldest block's record (host memory)
+            cpu_of("collect", collect)                   # the oldest block's record (host memory)
         t = time.perf_counter()
-        ctx.copy_wait()                                  # block i has landed (its copy ran under block i-1's kernels)
-        upload(i + 1)                                    # block i+1 goes up while block i is transformed
-        lf, freqs = ctx.bwt_block_device(d_in[i % 2], d_out, size, 8)
+        cpu_of("copy_wait", ctx.copy_wait)               # block i has landed (its copy ran under block i-1's kernels)
+        cpu_of("upload", upload, i + 1)                  # block i+1 goes up while block i is transformed
+        lf, freqs = cpu_of("bwt_block_device", ctx.bwt_block_device, d_in[i % 2], d_out, size, 8)
         if coder == "H":
             comp[0] = ctx.huffman_encode_device(d_out, size, lf, freqs, d_comp)
             rc = ctx.lib.bwtc_hip_memcpy_to_host(ctx.handle, h_rec.ctypes.data, d_comp, comp[0])
             if rc:
                 raise hip.BwtcHipError("bwtc_hip_memcpy_to_host failed with code %d" % rc)
         elif coder == "B":
-            pending.append(ctx.wavelet_encode_device_begin(d_out, size, lf, freqs, ring[i % (depth + 1)], threads))
+            pending.append(cpu_of("wavelet_begin", ctx.wavelet_encode_device_begin, d_out, size, lf, freqs, ring[i % (depth + 1)], threads))
         clock["gpu_s"] += time.perf_counter() - t
         issued[0] += 1
 
@@ -339,7 +385,18 @@ def main():
             print("step %d: rss/hwm %s" % (len(dev_ms), _rss_gb()), file=sys.stderr, flush=True)
 
     # ---- timed: K steps, each begins one block and (B) collects one ------------------------------
+    cpu0, thr0 = _cpu_seconds(), _cgroup_throttle()
+    tc0 = _thread_cpu() if os.environ.get("BWTC_BENCH_THREAD_CPU") == "1" else None
     elapsed = farm.timed(timed_step, args.steps, 0, None)
+    cpu1, thr1 = _cpu_seconds(), _cgroup_throttle()
+    if tc0 is not None:
+        tc1 = _thread_cpu()
+        rows = sorted(((tc1[t][1] - tc0.get(t, ("", 0.0))[1], t, tc1[t][0]) for t in tc1), reverse=True)
+        print("feeder thread, CPU s / wall s per call site (whole run): %s" % {k: [round(x, 3) for x in v] for k, v in feeder_cpu.items()}, file=sys.stderr)
+        print("CPU seconds per thread inside the timed region (%.3f s wall):" % elapsed, file=sys.stderr)
+        for dt, t, name in rows:
+            if dt > 0.0:
+                print("  tid %d %-16s %.3f" % (t, name, dt), file=sys.stderr)
     rss["after_timed_region"] = _rss_gb()
     m1, c1, b1 = ctx.wavelet_host_clock()
     f1 = ctx.wavelet_host_progress()[1]
@@ -522,6 +579,11 @@ def main():
             "block_latency_ms": round(1e3 * block_latency, 1) if coder == "B" else 0.0,
             "depth_needed": int(-(-(1e3 * block_latency if block_latency else single_ms) // max(step_ms, 1e-3))) if coder == "B" else 1,
             "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,
+            # what the kernel charged this process inside the timed region (all threads: workers, the thread
+            # that feeds the GPU, the runtime's helpers), per step; and whether the cgroup's CPU quota bit
+            "process_cpu_s_per_step": round((cpu1 - cpu0) / args.steps, 3),
+            "cgroup_throttled": ({"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1],
+                                  "throttled_s": round(thr1[2] - thr0[2], 3)} if thr0 and thr1 else None),
             "host_model_s_per_block": round((m1 - m0) / blocks_done, 3) if coder == "B" else 0.0,
             "host_coder_s_per_block": round((c1 - c0) / blocks_done, 3) if coder == "B" else 0.0,
             "device_ms_bwt": round(statistics.mean(dev_ms), 3), "rounds": st.rounds,

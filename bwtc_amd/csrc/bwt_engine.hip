@@ -5,6 +5,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <ctime>
+#include <sys/prctl.h>
 
 namespace bwtc_hip {
 
@@ -1390,7 +1393,38 @@ hipError_t BwtEngine::ensure_d2h_stream() {
 hipError_t BwtEngine::codes_wait() {
   if (!codes_in_flight) return hipSuccess;
   codes_in_flight = false;
-  return hipEventSynchronize(ev_codes);
+  return sleepy_wait(ev_codes, kWaitSlots - 1);
+}
+
+// A wait that gives the CPU away.  On this runtime hipEventSynchronize spins even on an event made with
+// hipEventBlockingSync (scripts/r4/wait_probe.py: the waiting thread's CPU time equals the wall time), and
+// with the 'B' coder the thread that feeds the GPU then takes a whole CPU of a quota that the range coders
+// need (measured: 0.04 CPU-seconds per 256 MiB block, a twentieth of sixteen CPUs).  So: poll the event
+// and sleep in between, in slices that are a quarter of what the wait is still expected to take (every
+// wait of a block has a slot, and remembers how long it took for the previous blocks), at most 200 us and
+// at least 20 us -- a wake-up comes at most a slice late.
+hipError_t BwtEngine::sleepy_wait(hipEvent_t ev, int slot) {
+  using clk = std::chrono::steady_clock;
+  static thread_local bool slack_set = false;
+  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }   // default: 50 us of slack on every sleep
+  const auto t0 = clk::now();
+  float& ema = wait_us[slot < 0 ? 0 : slot >= kWaitSlots ? kWaitSlots - 1 : slot];
+  double slice = 20.0;
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    const double el = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+    if (q != hipErrorNotReady) {
+      ema = ema > 0.f ? 0.5f * ema + 0.5f * (float)el : (float)el;
+      return q;
+    }
+    const double left = (double)ema - el;
+    if (left > 80.0) slice = std::min(200.0, left * 0.25);
+    else slice = std::min(200.0, std::max(20.0, slice * 1.25));
+    timespec ts;
+    ts.tv_sec = 0;
+    ts.tv_nsec = (long)(slice * 1e3);
+    nanosleep(&ts, nullptr);
+  }
 }
 
 int BwtEngine::reserve_run_arrays() {
@@ -1417,7 +1451,8 @@ hipError_t BwtEngine::wait() {
   if (!block || !ev_wait) return hipStreamSynchronize(stream);
   hipError_t rc = hipEventRecord(ev_wait, stream);
   if (rc != hipSuccess) return rc;
-  return hipEventSynchronize(ev_wait);
+  if (wait_seq < kWaitSlots - 2) ++wait_seq;
+  return sleepy_wait(ev_wait, wait_seq);
 }
 
 void BwtEngine::release() {
@@ -2030,6 +2065,7 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   if ((u64)n > cap) return -1;
   BWTC_HIP_TRY(hipSetDevice(device));
   BWTC_HIP_TRY(hipEventRecord(ev_begin, st));
+  wait_seq = 0;                                          // the block's waits come in the same order for every block of a stream
   u32 hist_T[256];
   int rc = load_text(d_src, nsrc, n, !raw, hist_T);
   if (rc) return rc;

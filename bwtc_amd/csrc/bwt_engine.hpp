@@ -336,6 +336,10 @@ struct BwtEngine {
   // when nothing else runs, but the 'B' coder's worker threads need those CPUs, so the wait then
   // sleeps on an interrupt instead.
   hipError_t wait();
+  static constexpr int kWaitSlots = 64;
+  float wait_us[kWaitSlots] = {};      // how long each of a block's waits took for the previous blocks (sleepy_wait)
+  int wait_seq = 0;
+  hipError_t sleepy_wait(hipEvent_t ev, int slot);
   static constexpr int kMaxSortEvents = 160;
   hipEvent_t ev_sort[kMaxSortEvents];
   int n_sort_events = 0;

@@ -161,7 +161,8 @@ int bwtc_hip_copy_wait(bwtc_hip_ctx* ctx) {
   if (!e.copy_stream) return 0;
   BWTC_HIP_TRY(hipSetDevice(e.device));
   BWTC_HIP_TRY(hipEventRecord(e.ev_copy, e.copy_stream));
-  BWTC_HIP_TRY(hipEventSynchronize(e.ev_copy));
+  if (e.pipeline) BWTC_HIP_TRY(e.sleepy_wait(e.ev_copy, BwtEngine::kWaitSlots - 2));     // the 'B' workers need the CPU
+  else BWTC_HIP_TRY(hipEventSynchronize(e.ev_copy));
   return 0;
 }
 
