@@ -1554,6 +1554,14 @@ static constexpr int kSmallLastChar = 524; // character of row n-1 (emitting ran
 static int rank_bits(u32 n) { return bit_width_u64((u64)n + 1); }   // rank + 1 <= n, and never all ones
 static bool can_carry(u32 n) { return rank_bits(n) + bit_width_u64(n / 2 ? n / 2 - 1 : 0) <= 56; }
 
+// Algorithmic bytes of P radix passes over `items` items of `item` bytes (key `key` bytes): each pass reads a
+// digit plane (or, without planes, the keys) for its histograms, reads and writes the items, and all but the
+// last leave the next pass's plane.
+static u64 sort_bytes(u64 items, int passes, int item, int key, bool planes) {
+  if (passes <= 0) return 0;
+  return items * (u64)passes * (u64)(2 * item + (planes ? 1 : key)) + (planes ? items * (u64)(passes - 1) : 0);
+}
+
 template <typename K>
 void BwtEngine::sort_pairs(K* k0, K* k1, u32* v0, u32* v1, u64 n, int nbits, K** ks, u32** vs,
                            bool probe_it, int bit_lo, u64 n_holes, bool plane_ready, bool values_descend) {
@@ -1585,8 +1593,11 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
   const int bits = bit_width_u64(n ? n - 1 : 0);
   const int lo = bits > window_bits ? bits - window_bits : 0;
   u32 *ws = pairs, *wr = pairs + cap;
-  if (m >= kPairsMin && bits > 12)
+  if (m >= kPairsMin && bits > 12) {
     sort_pairs<u32>(pairs, tmp, pairs + cap, tmp + cap, m, bits, &ws, &wr, false, lo);
+    stats.alg_bytes += sort_bytes(m, (bits - lo + kRadixBits - 1) / kRadixBits, 8, 4, digit_planes);
+  }
+  stats.alg_bytes += (u64)m * (8 + 4);                   // k_scatter_pairs
   hipLaunchKernelGGL(k_scatter_pairs, dim3((ceil_div(m, kWinTile) + 7u) / 8u * 8u), dim3(kWinTPB), 0, st,
                      d_rank, ws, wr, m, lo > 8 ? lo - 8 : 0);
 }
@@ -1622,6 +1633,12 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   BWTC_HIP_TRY(wait());
   if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
   const u32 m_next = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
+  {
+    // reduce and apply read the list (key, suffix, slot; the second key word of long items); apply writes a
+    // byte (and in the finisher route the suffix) per finished suffix and a list entry / record per active one
+    const u64 in_bytes = sizeof(K) + (lng ? 2 + 4 : split ? 2 : 4) + (INIT ? 0 : 4);
+    stats.alg_bytes += (u64)m * in_bytes * 2 + (u64)(m - m_next) * 5 + (u64)m_next * 13;
+  }
   res->m = m_next;
   res->groups = groups;
   const int b2 = rank_bits(n);
@@ -1680,6 +1697,13 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     sort_pairs<u64>(ws, ws_other, wv, wv_other, m_next, nbits, &res->ks, &res->vs, true, 0, (u64)(m - m_next));
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     stats.sort_pass_items += (u64)m + (u64)m_next * (u64)std::max(0, (nbits + kRadixBits - 1) / kRadixBits - 1);
+    {
+      const int P = (nbits + kRadixBits - 1) / kRadixBits;
+      stats.alg_bytes += sort_bytes(m, 2, 12, 8, digit_planes)                         // window partition of the records
+                         + (u64)m * (12 + 4) + (u64)m * (12 + 4 + 1 + 12)             // k_scatter_dense, k_gather_dense
+                         + (u64)m * (8 + 12) + (u64)m_next * 12                        // hole-dropping first pass
+                         + sort_bytes(m_next, std::max(0, P - 1), 12, 8, digit_planes);
+    }
     res->rec_other = res->ks == recA ? recB : recA;
     res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
     return 0;
@@ -1696,6 +1720,8 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
                        (const u8*)d_T, emit ? (const u8*)re.achr_out : (const u8*)nullptr, recA, m_next, n, (u32)h_next, res->text_chars);
     sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m_next, tbits, &res->ks, &res->vs, false);
     stats.sort_pass_items += (u64)m_next * (u64)((tbits + kRadixBits - 1) / kRadixBits);
+    stats.alg_bytes += (u64)m_next * (4 + 4 + 1 + 16 + 8) + sort_bytes(m_next, (tbits + kRadixBits - 1) / kRadixBits, 12, 8, digit_planes);
+    stats.route |= 4u;
     res->rec_other = res->ks == recA ? recB : recA;
     res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
     return 0;
@@ -1720,6 +1746,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m_next, nbits, &res->ks, &res->vs, true);
   if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
   stats.sort_pass_items += (u64)m_next * (u64)((nbits + kRadixBits - 1) / kRadixBits);
+  stats.alg_bytes += (u64)m_next * (4 + 4 + 4 + 1 + 8) + sort_bytes(m_next, (nbits + kRadixBits - 1) / kRadixBits, 12, 8, digit_planes);
   res->rec_other = res->ks == recA ? recB : recA;
   res->v_other = res->vs == rb.v_free ? rb.v_keys : rb.v_free;
   return 0;
@@ -1745,6 +1772,7 @@ int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan*
   uint4* table = reinterpret_cast<uint4*>(d_rank);
   u32 top = 1;
   for (int t = 1; t < g; ++t) top *= plan.sigma;
+  stats.alg_bytes += (u64)n + 64ull * nwords * 2;        // k_gram_mark reads T; the byte map is cleared and packed
   BWTC_HIP_TRY(hipMemsetAsync(present, 0, 64ull * nwords, st));
   hipLaunchKernelGGL(k_gram_mark, dim3(std::min<u32>(ceil_div(n, kGramTile), 4096u)), dim3(256), 0, st,
                      (const u8*)d_T, d_lut, n, g, plan.sigma, top, present);
@@ -1781,6 +1809,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   stats.rounds = 0;
   stats.active_sum = 0;
   stats.sort_pass_items = 0;
+  stats.route = 0;
+  stats.finisher_entries = 0;
   if (n == 0) return 0;
 
   const bool emit = em != nullptr;
@@ -1880,6 +1910,9 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, 1u, &lg);
       if (rc) return rc;
       stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits);
+      stats.alg_bytes += (u64)n * (1 + 14 + 1)               // k_make_keys_gram: T read, key + second word + first plane written (the values are made up by the first pass)
+                         + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits, 14, 8, true);
+      stats.route |= 1u;
       key_bits = 0;                                      // counted
     } else if (gp.G > 0) {
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
@@ -1925,6 +1958,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   }
   if (rc) return rc;
   stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits);
+  if (key_bits) {
+    const int item = plan.wide ? 12 : 8;                  // (u64, u32 or u16 + upper bits in the key) / (u32, u32)
+    stats.alg_bytes += (u64)n * (1 + (u64)(plan.wide ? 8 : 4) + 1) + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits, item, plan.wide ? 8 : 4, digit_planes);
+  }
 
   const u64 round_mask = emit ? ((1ull << 56) - 1ull) : ~0ull;
   u32 m = res.m;
@@ -1954,6 +1991,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       complete_ranks(n, res.vs, rb.aglob_next, m, res.rec_other == d_R2 ? (res.ks == (u64*)d_R1 ? (void*)d_W0 : d_R1) : d_R2, res.rec_other);
       ranks_complete = true;
       bridged = true;
+      stats.route |= 8u;
+      stats.alg_bytes += (u64)n * (4 + 8);                // k_bridge_pairs_all (the partition and scatter count themselves)
       lf_noted = false;
     }
     // the list just sorted: positions are the active list's, aglob gives their global slots
@@ -1990,6 +2029,11 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
+    stats.finisher_entries += m;
+    stats.route |= 2u;
+    // a window of entries is read by two workgroups, sixteen characters (three aligned words) per owned entry,
+    // a byte and a suffix per finished one
+    stats.alg_bytes += (u64)m * (2 * 13 + 24 + 5);
     BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
     hipLaunchKernelGGL(k_finish, dim3(ceil_div(m, kFinStride)), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, depth,
                        b, cnt, hardS, hardHP, cnt + 1, d_SA, re);
@@ -2041,6 +2085,7 @@ void BwtEngine::complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot,
 int BwtEngine::load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T) {
   hipStream_t st = stream;
   BWTC_HIP_TRY(hipMemsetAsync(d_small, 0, 1024 * 4, st));
+  stats.alg_bytes = 2ull * n;                            // k_load_hist: the block read, T written
   const u32 padded = (u32)((((u64)n + kTextPad + 15) / 16) * 16);
   const int aligned = (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0;
   hipLaunchKernelGGL(k_load_hist, dim3(std::min<u32>(ceil_div(padded, kLoadTile), 2048u)), dim3(kLoadTPB), 0, st, d_src,

@@ -62,8 +62,10 @@ HostPipeline::HostPipeline(unsigned threads, uint64_t huge_group_elements, unsig
   // says which), the others share the lanes with the sections of the blocks behind them (a third of
   // the scalar loop's host time per element).
   // (engines: the lanes cost 0.25 core-seconds per text block, the scalar chain 0.47; measured with 16
-  // threads and 51 ms of GPU per block: 2 engines 91 ms per block, 4 just short, 6 and 8 keep up)
-  max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, (P * 3 + 7) / 8)) : 0u;
+  // threads and 51 ms of GPU per block: 2 engines 91 ms per block, 4 just short, 6 and 8 keep up.  Round 4,
+  // 39 ms of GPU per block, the process at its CPU quota: 6 engines 51.5 ms per block, 4 engines 47.0, 3 engines
+  // 58 -- an engine costs a whole thread however full its lanes are, and six were two-thirds full)
+  max_w_engines_ = bwtc::wavelet::simdCoderAvailable() ? envNumber("BWTC_HIP_W_ENGINES", std::max(1u, P / 4)) : 0u;
   if (std::getenv("BWTC_HIP_W_ENGINES") && std::atoi(std::getenv("BWTC_HIP_W_ENGINES")) == 0) max_w_engines_ = 0;
   // The long sections of two blocks stepped alternately by one thread (runChainPairW): 1.25 ns per
   // element instead of 1.65-1.9 on the GPU box's EPYC on random elements (scripts/dev/rc_fma_bench.cpp).

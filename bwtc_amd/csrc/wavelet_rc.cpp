@@ -213,7 +213,7 @@ BWTC_AVX512 void runWords(Lanes& L, uint64_t words, uint32_t busy_mask) {
   const __m512i one = _mm512_set1_epi32(1), c4095 = _mm512_set1_epi32(4095), c2048 = _mm512_set1_epi32(2048);
   const __m512i top = _mm512_set1_epi32(static_cast<int>(0xFF000000u)), c510 = _mm512_set1_epi32(510);
   const __m512i lane0 = _mm512_slli_epi32(_mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), 8);
-  const __m512i c32768 = _mm512_set1_epi32(32768), c32767 = _mm512_set1_epi32(32767), c4096 = _mm512_set1_epi32(4096);
+  const __m512i c32768 = _mm512_set1_epi32(32768), c32767 = _mm512_set1_epi32(32767), cm2049 = _mm512_set1_epi32(-2049);
   alignas(64) uint32_t cw[kAll] = {0};
   alignas(64) uint32_t ev[G][16 * kLanes * 4 + 64];    // at most four bytes per lane and step
   alignas(64) __m512i P[G][16];
@@ -235,20 +235,27 @@ BWTC_AVX512 void runWords(Lanes& L, uint64_t words, uint32_t busy_mask) {
       for (int g = 0; g < G; ++g) {
         __m512i p = P[g][t];
         __mmask16 kBit;
+        const __m512i hi = _mm512_srli_epi32(size[g], 12), lw = _mm512_and_si512(size[g], c4095);
         if (WMODE) {
+          // runChainW's form: next size = (size m + bit - 2049) >> 12 = hi m + ((lw m + bit - 2049) >> 12)
+          // (arithmetic shift; the products wrap modulo 2^32 like the size itself), and a zero bit moves
+          // the low end up by size - next size
           kBit = _mm512_test_epi32_mask(p, c32768);
           const __m512i m = _mm512_and_si512(p, c32767);
-          p = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(c4096, m), m);       // probability of a one
+          __m512i c = _mm512_add_epi32(_mm512_mullo_epi32(lw, m), cm2049);
+          c = _mm512_mask_add_epi32(c, kBit, c, one);
+          const __m512i ns = _mm512_add_epi32(_mm512_mullo_epi32(hi, m), _mm512_srai_epi32(c, 12));
+          lo[g] = _mm512_mask_add_epi32(lo[g], static_cast<__mmask16>(~kBit), lo[g], _mm512_sub_epi32(size[g], ns));
+          size[g] = ns;
         } else {
           kBit = _mm512_test_epi32_mask(W[g], one);
           W[g] = _mm512_srli_epi32(W[g], 2);
+          const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, p),
+                                              _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, p), c2048), 12));
+          const __m512i t1 = _mm512_add_epi32(tt, one);
+          lo[g] = _mm512_mask_add_epi32(lo[g], static_cast<__mmask16>(~kBit), lo[g], t1);          // zero bit: lo += t + 1
+          size[g] = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(size[g], t1), _mm512_sub_epi32(tt, one));
         }
-        const __m512i hi = _mm512_srli_epi32(size[g], 12), lw = _mm512_and_si512(size[g], c4095);
-        const __m512i tt = _mm512_add_epi32(_mm512_mullo_epi32(hi, p),
-                                            _mm512_srli_epi32(_mm512_add_epi32(_mm512_mullo_epi32(lw, p), c2048), 12));
-        const __m512i t1 = _mm512_add_epi32(tt, one);
-        lo[g] = _mm512_mask_add_epi32(lo[g], static_cast<__mmask16>(~kBit), lo[g], t1);          // zero bit: lo += t + 1
-        size[g] = _mm512_mask_blend_epi32(kBit, _mm512_sub_epi32(size[g], t1), _mm512_sub_epi32(tt, one));
         // byte output: lanes whose interval ends share their top byte
         __m512i hiend = _mm512_add_epi32(_mm512_add_epi32(lo[g], size[g]), one);
         __mmask16 m = _mm512_mask_testn_epi32_mask(kBusy[g], _mm512_xor_si512(lo[g], hiend), top);

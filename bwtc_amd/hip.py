@@ -23,7 +23,8 @@ class BwtcHipError(RuntimeError):
 
 class Stats(ctypes.Structure):
     _fields_ = [("n", _u32), ("rounds", _u32), ("active_sum", _u64), ("sort_pass_items", _u64),
-                ("ms_total", ctypes.c_float), ("ms_sort", ctypes.c_float)]
+                ("ms_total", ctypes.c_float), ("ms_sort", ctypes.c_float),
+                ("route", _u32), ("finisher_entries", _u32), ("alg_bytes", _u64)]
 
 
 class KernelTimers(ctypes.Structure):

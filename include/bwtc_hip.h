@@ -32,6 +32,13 @@ typedef struct bwtc_hip_stats {
   uint64_t sort_pass_items;   /* sum over all radix passes of items moved                  */
   float    ms_total;          /* whole transform, device time                              */
   float    ms_sort;           /* radix sort passes only                                    */
+  /* round 4: which way the block went, and the algorithmic bytes of the kernels that ran      */
+  uint32_t route;             /* bit 0: long-key initial sort; bit 1: finisher settled the ties;
+                                 bit 2: text rounds ran; bit 3: rank[] completed late for doubling rounds */
+  uint32_t finisher_entries;  /* list entries over all finisher passes                      */
+  uint64_t alg_bytes;         /* compulsory bytes of the transform's kernels: every array a kernel
+                                 reads counted once, every array it writes counted once (SURVEY.md
+                                 8(d)'s counting rule applied to the kernel list that actually ran) */
 } bwtc_hip_stats;
 
 /* Per-kernel device timing of the dominant kernel (the radix scatter pass), gathered with
