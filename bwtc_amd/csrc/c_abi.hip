@@ -1,5 +1,7 @@
 // extern "C" surface of libbwtc_hip.so (include/bwtc_hip.h).
 #include "bwt_engine.hpp"
+#include "prepr_host.hpp"
+#include <new>
 #include "radix_sort.hpp"
 #include "bwtc_hip.h"
 #include "entropy_host.hpp"
@@ -19,6 +21,12 @@ using namespace bwtc_hip;
 struct bwtc_hip_ctx {
   BwtEngine eng;
 };
+struct bwtc_hip_grammar {
+  bwtc::prepr::Grammar g;
+};
+namespace bwtc_hip {
+int pair_replace_device(BwtEngine& e, bwtc::prepr::Grammar& grammar, const u8* d_src, u64 n, u8* d_dst, u64* n_out, u32* replaced);
+}
 
 template <typename K>
 static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int nbits) {
@@ -706,6 +714,95 @@ int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n) {
   BWTC_HIP_TRY(e.wait());
   BWTC_HIP_TRY(hipGetLastError());
   return e.h_small[1] ? -3 : 0;
+}
+
+// ---- pair-replacing pre-stage (prepr.hip, prepr_host.cpp) ---------------------------------------------
+bwtc_hip_grammar* bwtc_hip_grammar_create(void) { return new (std::nothrow) bwtc_hip_grammar(); }
+void bwtc_hip_grammar_destroy(bwtc_hip_grammar* g) { delete g; }
+uint32_t bwtc_hip_grammar_rules(const bwtc_hip_grammar* g) { return g ? g->g.numberOfRules() : 0; }
+uint32_t bwtc_hip_grammar_special_symbols(const bwtc_hip_grammar* g) { return g ? g->g.numberOfSpecialSymbols() : 0; }
+int bwtc_hip_grammar_is_special(const bwtc_hip_grammar* g, unsigned symbol) { return g && g->g.isSpecial(static_cast<uint8_t>(symbol)) ? 1 : 0; }
+int bwtc_hip_grammar_write(const bwtc_hip_grammar* g, uint8_t* out, uint64_t cap, uint64_t* bytes) {
+  if (!g || !out || !bytes) return -1;
+  std::vector<uint8_t> v;
+  g->g.write(&v);
+  if (v.size() > cap) return -1;
+  std::memcpy(out, v.data(), v.size());
+  *bytes = v.size();
+  return 0;
+}
+int bwtc_hip_grammar_read(bwtc_hip_grammar* g, const uint8_t* in, uint64_t n, uint64_t* consumed) {
+  if (!g || !in || !consumed || g->g.numberOfRules() || g->g.numberOfSpecialSymbols()) return -1;
+  const size_t used = g->g.read(in, static_cast<size_t>(n));
+  if (used == static_cast<size_t>(-1)) return -1;
+  *consumed = used;
+  return 0;
+}
+int bwtc_hip_pair_replace_device(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const uint8_t* d_src, uint64_t n,
+                                 uint8_t* d_dst, uint64_t* n_out, uint32_t* replaced) {
+  if (!ctx || !g || !d_src || !d_dst || !n_out || !replaced) return -1;
+  return bwtc_hip::pair_replace_device(ctx->eng, g->g, d_src, n, d_dst, n_out, replaced);
+}
+int bwtc_hip_precompress(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n, uint64_t* n_out) {
+  if (!ctx || !g || !block || !n_out) return -1;
+  *n_out = n;
+  if (!options || !options[0] || n < 3) return 0;
+  BwtEngine& e = ctx->eng;
+  BWTC_HIP_TRY(hipSetDevice(e.device));
+  if (n >= (1ull << 31) || n / 4096 + 2 > e.cap) return -1;
+  uint8_t *d_a = nullptr, *d_b = nullptr;
+  BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_a), 2 * n + 64));
+  if (hipMalloc(reinterpret_cast<void**>(&d_b), 2 * n + 64) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_a); return -2; }
+  int rc = hipMemcpy(d_a, block, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -3;
+  uint64_t length = n;
+  for (const char* c = options; rc == 0 && *c; ++c) {            // Precompressor.cpp:76-105
+    const uint64_t before = length;
+    if (*c == 'p') {
+      uint64_t now = 0;
+      uint32_t replaced = 0;
+      rc = bwtc_hip::pair_replace_device(e, g->g, d_a, length, d_b, &now, &replaced);
+      if (rc) break;
+      std::swap(d_a, d_b);
+      length = now;
+    }
+    if (length == before || length < 3) break;
+  }
+  if (rc == 0 && hipMemcpy(block, d_a, length, hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+  (void)hipFree(d_a);
+  (void)hipFree(d_b);
+  if (rc == 0) *n_out = length;
+  return rc;
+}
+int bwtc_hip_host_precompress(bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n, uint64_t* n_out) {
+  if (!g || !block || !n_out) return -1;
+  *n_out = n;
+  if (!options || !options[0] || n < 3) return 0;
+  std::vector<uint8_t> other(2 * n + 64);
+  std::vector<uint64_t> bf(256), pf(65536);
+  uint64_t length = n;
+  for (const char* c = options; *c; ++c) {
+    const uint64_t before = length;
+    if (*c == 'p') {
+      bwtc::prepr::pairStatisticsOnHost(block, length, bf.data(), pf.data());
+      bwtc::prepr::Replacements r;
+      bwtc::prepr::decideReplacements(&g->g, bf.data(), pf.data(), &r);
+      if (r.count) {
+        length = bwtc::prepr::writeReplacedOnHost(r, block, length, other.data());
+        std::memcpy(block, other.data(), length);
+      }
+    }
+    if (length == before || length < 3) break;
+  }
+  *n_out = length;
+  return 0;
+}
+int bwtc_hip_postprocess(const bwtc_hip_grammar* g, const uint8_t* data, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* n_out) {
+  if (!g || (!data && n) || !out || !n_out) return -1;
+  std::vector<uint8_t> v;
+  if (!bwtc::prepr::postprocess(g->g, data, static_cast<size_t>(n), &v, static_cast<size_t>(cap))) return -1;
+  if (!v.empty()) std::memcpy(out, v.data(), v.size());
+  *n_out = v.size();
+  return 0;
 }
 
 }  // extern "C"

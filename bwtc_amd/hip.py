@@ -46,6 +46,9 @@ EXPORTS = [
     "bwtc_hip_wavelet_depth", "bwtc_hip_numa_node", "bwtc_hip_host_cpu_slice", "bwtc_hip_set_worker_cpus", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
+    "bwtc_hip_grammar_create", "bwtc_hip_grammar_destroy", "bwtc_hip_grammar_rules", "bwtc_hip_grammar_special_symbols",
+    "bwtc_hip_grammar_is_special", "bwtc_hip_grammar_write", "bwtc_hip_grammar_read", "bwtc_hip_pair_replace_device",
+    "bwtc_hip_precompress", "bwtc_hip_host_precompress", "bwtc_hip_postprocess",
 ]
 
 _lib = None
@@ -124,6 +127,22 @@ def load():
                                                  ctypes.POINTER(_u64)]
     L.bwtc_hip_host_wavelet_streams.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
     L.bwtc_hip_host_wavelet_streams_lanes.argtypes = L.bwtc_hip_host_wavelet_sections.argtypes
+    # pair-replacing pre-stage (`--prepr`)
+    L.bwtc_hip_grammar_create.restype = _vp
+    L.bwtc_hip_grammar_create.argtypes = []
+    L.bwtc_hip_grammar_destroy.restype = None
+    L.bwtc_hip_grammar_destroy.argtypes = [_vp]
+    L.bwtc_hip_grammar_rules.restype = _u32
+    L.bwtc_hip_grammar_rules.argtypes = [_vp]
+    L.bwtc_hip_grammar_special_symbols.restype = _u32
+    L.bwtc_hip_grammar_special_symbols.argtypes = [_vp]
+    L.bwtc_hip_grammar_is_special.argtypes = [_vp, ctypes.c_uint]
+    L.bwtc_hip_grammar_write.argtypes = [_vp, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_grammar_read.argtypes = [_vp, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_pair_replace_device.argtypes = [_vp, _vp, _vp, _u64, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u32)]
+    L.bwtc_hip_precompress.argtypes = [_vp, _vp, ctypes.c_char_p, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_host_precompress.argtypes = [_vp, ctypes.c_char_p, _vp, _u64, ctypes.POINTER(_u64)]
+    L.bwtc_hip_postprocess.argtypes = [_vp, _vp, _u64, _vp, _u64, ctypes.POINTER(_u64)]
     L.bwtc_hip_host_huffman_lengths.restype = None
     L.bwtc_hip_host_huffman_lengths.argtypes = [_vp, _vp]
     L.bwtc_hip_host_huffman_codes.restype = None
@@ -149,6 +168,58 @@ def _check(rc, what):
 
 def _ptr(a):
     return a.ctypes.data_as(_vp)
+
+
+class Grammar:
+    """bwtc::Grammar of one precompressor block (bwtc_hip_grammar): what the `--prepr` rounds did to it."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.bwtc_hip_grammar_create()
+        if not self.h:
+            raise BwtcHipError("bwtc_hip_grammar_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.bwtc_hip_grammar_destroy(self.h)
+            self.h = None
+
+    @property
+    def rules(self):
+        return int(self.lib.bwtc_hip_grammar_rules(self.h))
+
+    @property
+    def special_symbols(self):
+        return int(self.lib.bwtc_hip_grammar_special_symbols(self.h))
+
+    def is_special(self, c):
+        return bool(self.lib.bwtc_hip_grammar_is_special(self.h, int(c)))
+
+    def write(self):
+        out = np.zeros(1 << 16, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_grammar_write(self.h, _ptr(out), out.size, ctypes.byref(n)), "bwtc_hip_grammar_write")
+        return out[:n.value].copy()
+
+    def read(self, raw):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_grammar_read(self.h, _ptr(raw), raw.size, ctypes.byref(n)), "bwtc_hip_grammar_read")
+        return int(n.value)
+
+    def host_precompress(self, options, data):
+        """Precompressor::precompress with both sweeps on the calling thread (no device)."""
+        buf = np.ascontiguousarray(data, np.uint8).copy()
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_host_precompress(self.h, options.encode(), _ptr(buf), buf.size, ctypes.byref(n)), "bwtc_hip_host_precompress")
+        return buf[:n.value].copy()
+
+    def postprocess(self, data, max_size):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.zeros(max(1, max_size), np.uint8)
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_postprocess(self.h, _ptr(data), data.size, _ptr(out), out.size, ctypes.byref(n)), "bwtc_hip_postprocess")
+        return out[:n.value].copy()
 
 
 class Context:
@@ -182,6 +253,13 @@ class Context:
 
     def n_lf(self, size, starting_points):
         return int(self.lib.bwtc_hip_n_lf(size, starting_points))
+
+    def precompress(self, grammar, options, data):
+        """Precompressor::precompress on the GPU (bwtc_hip_precompress): the precompressed block."""
+        buf = np.ascontiguousarray(data, np.uint8).copy()
+        n = _u64(0)
+        _check(self.lib.bwtc_hip_precompress(self.handle, grammar.h, options.encode(), _ptr(buf), buf.size, ctypes.byref(n)), "bwtc_hip_precompress")
+        return buf[:n.value].copy()
 
     def stats(self):
         s = Stats()

@@ -454,6 +454,67 @@ inline EntropyEncoder* giveEntropyEncoder(char encoder) {        // EntropyCoder
   std::exit(1);
 }
 
+// ---- pre-stage ("--prepr p...") ---------------------------------------------------------------
+// preprocessors/Grammar.hpp: the grammar of one precompressor block, behind the C ABI.
+class Grammar {
+ public:
+  Grammar() : m_g(bwtc_hip_grammar_create()) { if (!m_g) hipFatal(-2, "bwtc_hip_grammar_create"); }
+  ~Grammar() { bwtc_hip_grammar_destroy(m_g); }
+  uint32 numberOfRules() const { return bwtc_hip_grammar_rules(m_g); }
+  uint32 numberOfSpecialSymbols() const { return bwtc_hip_grammar_special_symbols(m_g); }
+  bool isSpecial(byte symbol) const { return bwtc_hip_grammar_is_special(m_g, symbol) != 0; }
+  uint32 writeGrammar(OutStream* dst) const {                     // Grammar.cpp:309-320
+    std::vector<byte> raw(1 << 16);
+    uint64_t n = 0;
+    hipFatal(bwtc_hip_grammar_write(m_g, &raw[0], raw.size(), &n), "bwtc_hip_grammar_write");
+    dst->writeBlock(&raw[0], &raw[0] + n);
+    return (uint32)n;
+  }
+  // Grammar.cpp:198-307 from bytes in memory; returns what it consumed
+  size_t readGrammar(const byte* in, size_t n) {
+    uint64_t used = 0;
+    hipFatal(bwtc_hip_grammar_read(m_g, in, n, &used), "bwtc_hip_grammar_read");
+    return (size_t)used;
+  }
+  bwtc_hip_grammar* handle() const { return m_g; }
+ private:
+  Grammar(const Grammar&);
+  Grammar& operator=(const Grammar&);
+  bwtc_hip_grammar* m_g;
+};
+
+// preprocessors/Precompressor.hpp: options = one letter per round ('p' = PairReplacer).
+class Precompressor {
+ public:
+  Precompressor() {}
+  explicit Precompressor(const std::string& preprocessing) : m_preprocessingOptions(preprocessing) {}
+  const std::string& options() const { return m_preprocessingOptions; }
+  // Precompressor::precompress (Precompressor.cpp:62-121) over block[0..size): the new size
+  size_t precompress(bwtc_hip_ctx* ctx, Grammar& grammar, byte* block, size_t size) const {
+    uint64_t n = size;
+    if (!m_preprocessingOptions.empty())
+      hipFatal(bwtc_hip_precompress(ctx, grammar.handle(), m_preprocessingOptions.c_str(), block, size, &n), "bwtc_hip_precompress");
+    return (size_t)n;
+  }
+ private:
+  std::string m_preprocessingOptions;
+};
+
+// preprocessors/Postprocessor.hpp
+class Postprocessor {
+ public:
+  Postprocessor(bool, const Grammar& grammar) : m_grammar(grammar) {}
+  size_t uncompress(const byte* data, size_t length, OutStream* to, size_t originalSize) const {   // Postprocessor.cpp:112-133
+    std::vector<byte> out(originalSize + 1);
+    uint64_t n = 0;
+    hipFatal(bwtc_hip_postprocess(m_grammar.handle(), data, length, &out[0], originalSize, &n), "bwtc_hip_postprocess");
+    to->writeBlock(&out[0], &out[0] + n);
+    return (size_t)n;
+  }
+ private:
+  const Grammar& m_grammar;
+};
+
 // ---- Compressor ----------------------------------------------------------------------------
 struct Options {                                                  // Compressor.hpp:40-48
   Options(size_t memLimit_, char entropyCoder_) : memLimit(memLimit_), entropyCoder(entropyCoder_) {}
@@ -475,6 +536,9 @@ class Compressor {
   Compressor(InStream* in, OutStream* out, size_t memLimit, char entropyCoder)
       : m_in(in), m_out(out), m_coder(giveEntropyEncoder(entropyCoder)),
         m_options(memLimit, entropyCoder) {}
+  Compressor(InStream* in, OutStream* out, const std::string& preprocessing, size_t memLimit, char entropyCoder)   // Compressor.cpp:44-47
+      : m_in(in), m_out(out), m_coder(giveEntropyEncoder(entropyCoder)), m_precompressor(preprocessing),
+        m_options(memLimit, entropyCoder) {}
   ~Compressor() { delete m_in; delete m_out; delete m_coder; }
 
   size_t bwtBlockSize() const {                                   // Compressor.cpp:77-79
@@ -482,7 +546,10 @@ class Compressor {
                     static_cast<size_t>(0x7fffffff - 1));
   }
   void initializeBwtAlgorithm(char choice, uint32 startingPoints, int device = 0) {
-    m_bwtmanager.setMaxBlockSize((uint32)bwtBlockSize());
+    // with the pre-stage a BWT block is (memLimit - precompressed size) / 4.5 bytes (Compressor.cpp:94-97): at most memLimit / 4.5
+    const size_t largest = m_precompressor.options().empty() ? bwtBlockSize()
+        : std::min(static_cast<size_t>(m_options.memLimit / 4.5) + 1, static_cast<size_t>(0x7fffffff - 1));
+    m_bwtmanager.setMaxBlockSize((uint32)largest);
     m_bwtmanager.setDevice(device);
     m_bwtmanager.initialize(choice);                              // Compressor.cpp:60-63
     m_bwtmanager.setStartingPoints(startingPoints);
@@ -496,6 +563,7 @@ class Compressor {
   // precompressor block holding one BWT block (pbBlockSize == bwtBlockSize, :81).
   size_t compress(size_t threads) {
     if (threads != 1) { std::fprintf(stderr, "Supporting only single thread!\n"); return 0; }
+    if (!m_precompressor.options().empty()) return compressPrecompressed();
     size_t compressedSize = writeGlobalHeader();
     const size_t bs = bwtBlockSize();
     std::vector<byte> buf(bs + 1);
@@ -522,6 +590,38 @@ class Compressor {
   }
   OutStream* out() { return m_out; }
  private:
+  // Compressor.cpp:65-118 with the pre-stage on: precompressor blocks of 0.74 memLimit bytes, each precompressed
+  // (its grammar goes into the block's header), then cut into BWT blocks of (memLimit - its size) / 4.5 bytes.
+  // Block by block: the coders' overlap is for the streams without a pre-stage.
+  size_t compressPrecompressed() {
+    size_t compressedSize = writeGlobalHeader();
+    const size_t pbBlockSize = static_cast<size_t>(m_options.memLimit * 0.74);
+    if (pbBlockSize == 0) { m_out->writeByte(0); m_out->flush(); return compressedSize + 1; }
+    std::vector<byte> buf(pbBlockSize + 1);
+    for (;;) {
+      const size_t got = m_in->readBlock(&buf[0], pbBlockSize);
+      if (got == 0) break;
+      Grammar grammar;
+      const size_t len = m_precompressor.precompress(m_bwtmanager.hipContext(), grammar, &buf[0], got);
+      const size_t bs = std::min(static_cast<size_t>((m_options.memLimit - len) / 4.5), static_cast<size_t>(0x7fffffff - 1));
+      if (bs == 0) { std::fprintf(stderr, "bwtc-hip: memory limit too small for the precompressed block\n"); std::exit(1); }
+      const size_t slices = (len + bs - 1) / bs;                  // PrecompressorBlock::sliceIntoBlocks
+      compressedSize += detail::writePacked(got, m_out);          // PrecompressorBlock::writeBlockHeader
+      compressedSize += detail::writePacked(slices, m_out);
+      compressedSize += grammar.writeGrammar(m_out);
+      for (size_t s = 0; s < slices; ++s) {
+        const size_t at = s * bs, size = std::min(bs, len - at);
+        const byte keep = buf[at + size];                         // the slice's sentinel slot is its neighbour's first byte
+        BWTBlock block(&buf[at], (uint32)size, false);
+        if (m_coder->overlapsBlocks()) { m_coder->begin(block, m_bwtmanager); compressedSize += m_coder->finishOldest(m_out); }
+        else compressedSize += m_coder->transformAndEncode(block, m_bwtmanager, m_out);
+        buf[at + size] = keep;
+      }
+    }
+    m_out->writeByte(0); ++compressedSize;
+    m_out->flush();
+    return compressedSize;
+  }
   size_t writeBlockPrefix(size_t got) {                           // PrecompressorBlock.cpp:64-90
     size_t n = detail::writePacked(got, m_out);
     n += detail::writePacked(1, m_out);
@@ -536,6 +636,7 @@ class Compressor {
   OutStream* m_out;
   EntropyEncoder* m_coder;
   BWTManager m_bwtmanager;
+  Precompressor m_precompressor;
   Options m_options;
 };
 

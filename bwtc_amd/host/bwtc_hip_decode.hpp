@@ -29,6 +29,10 @@ class MemoryBitReader {
   uint64 readBits(unsigned k) { uint64 v = 0; while (k--) v = (v << 1) | (readBit() ? 1u : 0u); return v; }
   byte readByte() { return (byte)readBits(8); }
   void flushBuffer() { if (m_bit) { m_bit = 0; ++m_pos; } }
+  // whole bytes from here on (after flushBuffer): where they are, how many, and a step over some of them
+  const byte* here() const { return m_p + (m_pos < m_n ? m_pos : m_n); }
+  size_t left() const { return m_pos < m_n ? m_n - m_pos : 0; }
+  void advance(size_t bytes) { m_pos += bytes; }
   // peek up to 16 bits without consuming (zero padded past the end)
   unsigned peek16() const {
     uint32_t w = 0;
@@ -567,12 +571,18 @@ class Decompressor {
       const uint64 originalSize = in.readPackedInteger();           // PrecompressorBlock.cpp:97-108
       if (originalSize == 0) break;
       const uint64 slices = in.readPackedInteger();
-      if (in.readByte() != 0) MemoryBitReader::fail("grammar with rules (precompressed stream)");
-      buf.resize(originalSize + 1);
+      // PrecompressorBlock::readBlockHeader reads the block's grammar here (PrecompressorBlock.cpp:97-108); a
+      // grammar with rules means the slices hold the PRECOMPRESSED block, which the Postprocessor expands
+      Grammar grammar;
+      in.flushBuffer();
+      in.advance(grammar.readGrammar(in.here(), in.left()));
+      const bool rules = grammar.numberOfRules() > 0;
+      const size_t room = rules ? 2 * (size_t)originalSize + 64 : (size_t)originalSize;
+      buf.resize(room + 1);
       size_t used = 0;
       for (uint64 i = 0; i < slices; ++i) {
         BWTBlock block(&buf[used], 0, true);
-        m_decoder->decodeBlock(block, in, originalSize - used);
+        m_decoder->decodeBlock(block, in, room - used);
         if (!ibwt || block.size() > ibwtCap) {
           delete ibwt;
           ibwtCap = (uint32)std::max<size_t>(block.size(), 1u << 20);
@@ -580,6 +590,13 @@ class Decompressor {
         }
         ibwt->doTransform(block);
         used += block.size();
+      }
+      if (rules) {
+        Postprocessor postprocessor(false, grammar);               // Decompressor.cpp:82-88
+        const size_t postSize = postprocessor.uncompress(&buf[0], used, m_out, (size_t)originalSize);
+        if (postSize != originalSize) MemoryBitReader::fail("postprocessed block size");
+        decompressedSize += postSize;
+        continue;
       }
       if (used != originalSize) MemoryBitReader::fail("precompressor block size");
       m_out->writeBlock(&buf[0], &buf[0] + used);

@@ -21,7 +21,7 @@
 //                        two to three times less host time.
 //     -v, --verb N       verbosity
 // Differences from the reference, on purpose: --bwt d/s (CPU back-ends) and --enc m/M (models
-// whose reference implementation reads past its table) are rejected, --prepr is not offered.
+// whose reference implementation reads past its table) are rejected, 'm' / 'M' are not offered.
 #include <getopt.h>
 #include <algorithm>
 #include <chrono>
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
   unsigned pipeline = 0;
   unsigned starts = 8;
   char bwt = 'a', enc = 'B';                                     // compress.cpp:115-118 defaults
+  std::string prepr;                                             // compress.cpp:126-131: one 'p' per PairReplacer round
   bool from_stdin = false, to_stdout = false;
   int verbosity = 0, device = 0;
   std::vector<int> devices;
@@ -59,9 +60,10 @@ int main(int argc, char** argv) {
                               {"stdin", no_argument, 0, 'i'},       {"stdout", no_argument, 0, 'c'},
                               {"device", required_argument, 0, 'd'}, {"verb", required_argument, 0, 'v'},
                               {"devices", required_argument, 0, 'D'}, {"pipeline", required_argument, 0, 'P'},
+                              {"prepr", required_argument, 0, 'p'},
                               {"help", no_argument, 0, 'h'},        {0, 0, 0, 0}};
   int o;
-  while ((o = getopt_long(argc, argv, "m:s:e:icd:D:P:v:h", longopts, 0)) != -1) {
+  while ((o = getopt_long(argc, argv, "m:s:e:icd:D:P:v:p:h", longopts, 0)) != -1) {
     switch (o) {
       case 'm': mem = std::strtoul(optarg, 0, 10); break;
       case 's': starts = (unsigned)std::strtoul(optarg, 0, 10); break;
@@ -75,8 +77,13 @@ int main(int argc, char** argv) {
         break;
       case 'P': pipeline = (unsigned)std::strtoul(optarg, 0, 10); break;
       case 'v': verbosity = std::atoi(optarg); break;
+      case 'p':
+        prepr = optarg;
+        for (size_t i = 0; i < prepr.size(); ++i)
+          if (prepr[i] != 'p') { std::fprintf(stderr, "Invalid choice for preprocessing: %c (p = pair replacer)\n", prepr[i]); return 1; }   // compress.cpp:45-60
+        break;
       default:
-        std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|b|u|H] [-i] [-c] [input] [output]\n");
+        std::fprintf(stderr, "usage: compress [-m MB] [-s starts] [--bwt g] [-e B|b|u|H] [--prepr p...] [-i] [-c] [input] [output]\n");
         return o == 'h' ? 0 : 1;
     }
   }
@@ -138,9 +145,10 @@ int main(int argc, char** argv) {
     if (pipeline == 0 || pipeline > lim) pipeline = lim;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name),
+  bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name), prepr,
                               mem * 1000000, enc);                // compress.cpp:192-193
   size_t compressed;
+  if (!prepr.empty()) devices.clear();                            // the pre-stage runs block by block on one context
   if (!devices.empty()) {
     compressed = compressor.compressFarmed(devices, starts < 1 ? 1 : starts > 256 ? 256 : starts, pipeline);
   } else {

@@ -340,6 +340,38 @@ int bwtc_hip_test_sort_u32(bwtc_hip_ctx* ctx, uint32_t* keys, uint32_t* vals, ui
 int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int nbits);
 int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n);
 
+/* ---- pair-replacing pre-stage, `--prepr p...` ------------------------------------------
+ * Replaces preprocessors/PairReplacer.cpp (analyseData :53-63, decideReplacements :402-484,
+ * writeReplacedVersion :330-400), Grammar.cpp (writeGrammar :309-320, readGrammar :198-307),
+ * Precompressor::precompress (Precompressor.cpp:62-121) and Postprocessor::uncompress (Postprocessor.cpp:112-133).
+ * A grammar object is what a PrecompressorBlock carries (PrecompressorBlock.hpp:70): it is updated by every
+ * round over the block and written into the block's header (PrecompressorBlock.cpp:64-90). */
+typedef struct bwtc_hip_grammar bwtc_hip_grammar;
+bwtc_hip_grammar* bwtc_hip_grammar_create(void);                       /* Grammar::Grammar: no rules */
+void     bwtc_hip_grammar_destroy(bwtc_hip_grammar* g);
+uint32_t bwtc_hip_grammar_rules(const bwtc_hip_grammar* g);            /* Grammar::numberOfRules          */
+uint32_t bwtc_hip_grammar_special_symbols(const bwtc_hip_grammar* g);  /* Grammar::numberOfSpecialSymbols */
+int      bwtc_hip_grammar_is_special(const bwtc_hip_grammar* g, unsigned symbol);
+/* Grammar::writeGrammar into out (cap bytes): 0, *bytes = size; -1 when it does not fit */
+int      bwtc_hip_grammar_write(const bwtc_hip_grammar* g, uint8_t* out, uint64_t cap, uint64_t* bytes);
+/* Grammar::readGrammar into an EMPTY grammar: 0, *consumed = bytes read; -1 when the input is cut short */
+int      bwtc_hip_grammar_read(bwtc_hip_grammar* g, const uint8_t* in, uint64_t n, uint64_t* consumed);
+/* One PairReplacer (analyseData + decideReplacements + writeReplacedVersion) over a device-resident text of
+ * 3 <= n < 2^31 bytes: d_src -> d_dst (room for 2 n bytes; must not overlap), *n_out = the new length,
+ * *replaced = pairs replaced (0: the text is copied unchanged). */
+int      bwtc_hip_pair_replace_device(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const uint8_t* d_src, uint64_t n,
+                                      uint8_t* d_dst, uint64_t* n_out, uint32_t* replaced);
+/* Precompressor::precompress over a host block, in place: one round per letter of `options` ('p'), stopped by the
+ * first round that does not shorten the block; *n_out = the new length.  Blocks shorter than three bytes are left
+ * alone (the reference asserts length > 2). */
+int      bwtc_hip_precompress(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n,
+                              uint64_t* n_out);
+/* the same with both sweeps on the calling thread (no device; the CPU test suite, and the mirror's blocks below 64 KiB) */
+int      bwtc_hip_host_precompress(bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n, uint64_t* n_out);
+/* Postprocessor::uncompress: data (n bytes) expanded into out (cap bytes); -1 when it does not fit */
+int      bwtc_hip_postprocess(const bwtc_hip_grammar* g, const uint8_t* data, uint64_t n, uint8_t* out, uint64_t cap,
+                              uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

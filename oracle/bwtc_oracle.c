@@ -613,7 +613,9 @@ static void bic_decode(bitr *r, uint32_t *list, size_t *n, size_t lo, size_t hi,
  * BWTBlock::readHeader (BWTBlock.cpp:88-102), then the inverse BWT. */
 size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_cap)
 {
-    bitr r; size_t opos = 0;
+    bitr r; size_t opos = 0, dpos = 0, dcap = 0, gram_n = 0;
+    const uint8_t *gram = NULL;
+    uint8_t *aside = NULL, *dst = NULL;
     r.p = in; r.n = in_size; r.pos = 0; r.bit = 0;
     if (in_size < 2 || in[0] != 'H') return (size_t)-1;
     r.pos = 1;
@@ -621,7 +623,21 @@ size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t 
         uint64_t orig = br_packed(&r), slices, s;
         if (orig == 0) break;
         slices = br_packed(&r);
-        if (br_bits(&r, 8) != 0) return (size_t)-1;    /* grammar with rules: unsupported */
+        /* the grammar (PrecompressorBlock::readBlockHeader, PrecompressorBlock.cpp:97-108): one 0x00 byte when the
+         * pre-stage was off; with rules the slices are decoded aside and expanded by the Postprocessor */
+        {
+            const size_t glen = r.pos <= r.n ? orc_grammar_span(in + r.pos, r.n - r.pos) : (size_t)-1;
+            if (glen == (size_t)-1) return (size_t)-1;
+            gram = in + r.pos; gram_n = glen;
+            r.pos += glen;
+        }
+        aside = NULL; dst = out + opos; dcap = out_cap - opos; dpos = 0;
+        if (!(gram_n == 1 && gram[0] == 0)) {
+            dcap = 2 * (size_t)orig + 64;
+            aside = (uint8_t *)malloc(dcap);
+            if (!aside) return (size_t)-1;
+            dst = aside;
+        }
         for (s = 0; s < slices; ++s) {
             uint64_t clen48 = br_bits(&r, 48);
             size_t start = r.pos, bsize = 0, done = 0;
@@ -632,8 +648,8 @@ size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t 
             br_flush(&r);
             nsec = (uint32_t)br_bits(&r, 8); if (nsec == 0) nsec = 256;
             for (i = 0; i < nsec; ++i) { sect[i] = br_packed(&r); bsize += sect[i]; }
-            if (opos + bsize > out_cap) return (size_t)-1;
-            blk = out + opos;
+            if (dpos + bsize > dcap) { free(aside); return (size_t)-1; }
+            blk = dst + dpos;
             for (i = 0; i < nsec; ++i) {
                 uint64_t n_runs, k;
                 uint32_t clen[256], code[256], alphabet[256];
@@ -675,7 +691,15 @@ size_t orc_decompress_H(const uint8_t *in, size_t in_size, uint8_t *out, size_t 
             }
             if (done != bsize || r.pos - start != clen48) return (size_t)-1;
             if (orc_inverse_bwt_block(blk, (uint32_t)bsize, lf, n_lf) != 0) return (size_t)-1;
-            opos += bsize;
+            dpos += bsize;
+        }
+        if (aside) {
+            const size_t got = orc_postprocess_bytes(gram, gram_n, aside, dpos, out + opos, out_cap - opos);
+            free(aside);
+            if (got == (size_t)-1 || got != orig) return (size_t)-1;
+            opos += got;
+        } else {
+            opos += dpos;
         }
     }
     return opos;

@@ -81,6 +81,36 @@ size_t orc_compress_wavelet(char coder, const uint8_t *in, size_t size, size_t b
 size_t orc_decompress_wavelet(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_cap,
                               uint8_t *bwt_out);
 
+/* ---- pair-replacing pre-stage, `--prepr p...` (oracle/prepr_oracle.cpp; preprocessors/PairReplacer.cpp,
+ * Grammar.cpp, FrequencyTable.cpp, Precompressor.cpp, Postprocessor.cpp) ---- */
+typedef struct orc_grammar orc_grammar;
+orc_grammar *orc_grammar_new(void);
+void     orc_grammar_free(orc_grammar *g);
+uint32_t orc_grammar_rules(const orc_grammar *g);
+uint32_t orc_grammar_specials(const orc_grammar *g);
+int      orc_grammar_is_special(const orc_grammar *g, unsigned symbol);
+void     orc_grammar_frequencies(const orc_grammar *g, uint64_t f[256]);
+size_t   orc_grammar_write(const orc_grammar *g, uint8_t *out, size_t cap);       /* Grammar::writeGrammar */
+size_t   orc_grammar_read(orc_grammar *g, const uint8_t *in, size_t n);           /* Grammar::readGrammar: bytes consumed */
+size_t   orc_grammar_span(const uint8_t *in, size_t n);                           /* bytes a serialised grammar occupies */
+void     orc_grammar_add_rule(orc_grammar *g, unsigned variable, unsigned first, unsigned second);
+size_t   orc_grammar_expand_alphabet(orc_grammar *g, const uint8_t *freed, size_t n_freed, const uint8_t *specials,
+                                     size_t n_specials, uint16_t *next_pairs);
+/* PairReplacer::analyseData: byte counts (grammar's included) and the 65536 pair counts */
+void     orc_pair_statistics(const orc_grammar *g, const uint8_t *data, size_t n, uint64_t freqs[256], uint64_t *pair_freqs);
+/* analyseData + decideReplacements + writeReplacedVersion: returns the replacements made; out needs 2 n bytes */
+size_t   orc_pair_replace_round(orc_grammar *g, const uint8_t *data, size_t n, uint8_t *out, size_t *out_n);
+size_t   orc_precompress(orc_grammar *g, const char *options, uint8_t *data, size_t n);   /* in place, new length */
+size_t   orc_postprocess(const orc_grammar *g, const uint8_t *data, size_t n, uint8_t *out, size_t cap);
+size_t   orc_postprocess_bytes(const uint8_t *gram, size_t gram_n, const uint8_t *data, size_t n, uint8_t *out, size_t cap);
+/* Compressor::compress with the pre-stage: mem_limit in bytes as Compressor.cpp:77-97 uses it */
+size_t   orc_compress_prepr(char coder, const char *options, const uint8_t *in, size_t size, uint64_t mem_limit,
+                            uint32_t starting_points, uint8_t *out, size_t out_cap);
+void    *orc_wavelet_stream_new(char coder);
+size_t   orc_wavelet_stream_encode_block(void *ws, const uint8_t *bwt, uint32_t size, const uint32_t *lf,
+                                         uint32_t n_lf, const uint32_t freqs[256], uint8_t *out);
+void     orc_wavelet_stream_free(void *ws);
+
 /* restatements of what test/WaveletTest.cpp pins with known answers (see wavelet_oracle.c) */
 void   orc_min_heap_order(const int *values, const uint64_t *weights, size_t n, int *out);
 size_t orc_create_huffman_shape(const uint64_t run_freqs[256], uint32_t *symbols, uint32_t *depths,

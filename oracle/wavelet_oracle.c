@@ -724,6 +724,22 @@ size_t orc_compress_wavelet(char coder, const uint8_t *in, size_t size, size_t b
     return pos;
 }
 
+/* one WaveletEncoder object for streams that are framed elsewhere (prepr_oracle.cpp) */
+void *orc_wavelet_stream_new(char coder)
+{
+    wstate *ws = (wstate *)malloc(sizeof(wstate));
+    if (!ws) return NULL;
+    if (!model_init(coder, &ws->pm, &ws->gm, &ws->gapm)) { free(ws); return NULL; }
+    ws->rc.low = 0; ws->rc.high = 0xFFFFFFFFu;
+    return ws;
+}
+size_t orc_wavelet_stream_encode_block(void *ws, const uint8_t *bwt, uint32_t size, const uint32_t *lf,
+                                       uint32_t n_lf, const uint32_t freqs[256], uint8_t *out)
+{
+    return wavelet_encode_block((wstate *)ws, bwt, size, lf, n_lf, freqs, out);
+}
+void orc_wavelet_stream_free(void *ws) { free(ws); }
+
 size_t orc_compress_B(const uint8_t *in, size_t size, size_t block_size, uint32_t starting_points,
                       uint8_t *out, size_t out_cap)
 {
@@ -1148,7 +1164,7 @@ size_t orc_decompress_wavelet(const uint8_t *in_bytes, size_t in_size, uint8_t *
     instream in;
     model pm, gm, gapm;
     rdecoder dec;
-    size_t opos = 0;
+    size_t opos = 0, bpos = 0;
     memset(&in, 0, sizeof in);
     in.p = in_bytes; in.n = in_size;
     if (in_size < 2) return (size_t)-1;
@@ -1159,20 +1175,35 @@ size_t orc_decompress_wavelet(const uint8_t *in_bytes, size_t in_size, uint8_t *
         size_t slices, s;
         if (in.overrun) return (size_t)-1;
         if (orig == 0) break;
+        const uint8_t *gram;
+        size_t gram_n, dpos = 0, dcap;
+        uint8_t *aside = NULL, *dst;
         slices = read_packed(&in);
-        if (in_read_byte(&in) != 0) return (size_t)-1;            /* grammar with rules: not on this path */
+        /* the grammar (PrecompressorBlock.cpp:97-108): one 0x00 byte when the pre-stage was off; with rules the
+         * slices are decoded aside and expanded by the Postprocessor (Decompressor.cpp:82-88) */
+        gram_n = in.pos <= in.n ? orc_grammar_span(in.p + in.pos, in.n - in.pos) : (size_t)-1;
+        if (gram_n == (size_t)-1) return (size_t)-1;
+        gram = in.p + in.pos;
+        in.pos += gram_n;
+        dst = out + opos; dcap = out_cap - opos;
+        if (!(gram_n == 1 && gram[0] == 0)) {
+            dcap = 2 * orig + 64;
+            aside = (uint8_t *)malloc(dcap);
+            if (!aside) return (size_t)-1;
+            dst = aside;
+        }
         for (s = 0; s < slices; ++s) {
             const uint64_t clen48 = in_read48(&in);                /* readBlockHeader, :231-244 */
             const size_t start = in.pos;
             uint32_t n_lf = in_read_byte(&in) + 1, lf[256], i, nsec, j;
             uint64_t sect[256];
             size_t bsize = 0, len = 0;
-            uint8_t *blk = out + opos;
+            uint8_t *blk = dst + dpos;
             for (i = 0; i < n_lf; ++i) { uint32_t pos = 0; for (j = 0; j < 31; ++j) pos = (pos << 1) | (uint32_t)in_read_bit(&in); lf[i] = pos; }
             in_flush(&in);                                         /* BWTBlock::readHeader, BWTBlock.cpp:88-102 */
             nsec = in_read_byte(&in); if (nsec == 0) nsec = 256;
             for (i = 0; i < nsec; ++i) { sect[i] = read_packed_bytes(&in); bsize += sect[i]; }
-            if (in.overrun || opos + bsize > out_cap) return (size_t)-1;
+            if (in.overrun || dpos + bsize > dcap) { free(aside); return (size_t)-1; }
             for (i = 0; i < nsec; ++i) {                           /* decodeBlock, :246-288 */
                 dtree t;
                 size_t root_size, clen;
@@ -1193,9 +1224,17 @@ size_t orc_decompress_wavelet(const uint8_t *in_bytes, size_t in_size, uint8_t *
                 model_reset(&pm); model_reset(&gm); model_reset(&gapm);   /* endContextBlock, :70-75 */
             }
             if (len != bsize || in.pos - start != clen48) return (size_t)-1;
-            if (bwt_out) memcpy(bwt_out + opos, blk, bsize);
+            if (bwt_out) { memcpy(bwt_out + bpos, blk, bsize); bpos += bsize; }
             if (orc_inverse_bwt_block(blk, (uint32_t)bsize, lf, n_lf) != 0) return (size_t)-1;
-            opos += bsize;
+            dpos += bsize;
+        }
+        if (aside) {
+            const size_t got = orc_postprocess_bytes(gram, gram_n, aside, dpos, out + opos, out_cap - opos);
+            free(aside);
+            if (got == (size_t)-1 || got != orig) return (size_t)-1;
+            opos += got;
+        } else {
+            opos += dpos;
         }
     }
     return opos;

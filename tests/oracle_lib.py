@@ -89,6 +89,40 @@ def lib():
         L.orc_fixed_integer_code.argtypes = [_u32, _u32, _vp]
         L.orc_wavelet_symbol_codes.restype = None
         L.orc_wavelet_symbol_codes.argtypes = [_vp, _vp, _vp]
+        # pair-replacing pre-stage (oracle/prepr_oracle.cpp)
+        L.orc_grammar_new.restype = _vp
+        L.orc_grammar_new.argtypes = []
+        L.orc_grammar_free.restype = None
+        L.orc_grammar_free.argtypes = [_vp]
+        L.orc_grammar_rules.restype = _u32
+        L.orc_grammar_rules.argtypes = [_vp]
+        L.orc_grammar_specials.restype = _u32
+        L.orc_grammar_specials.argtypes = [_vp]
+        L.orc_grammar_is_special.argtypes = [_vp, ctypes.c_uint]
+        L.orc_grammar_frequencies.restype = None
+        L.orc_grammar_frequencies.argtypes = [_vp, _vp]
+        L.orc_grammar_write.restype = _sz
+        L.orc_grammar_write.argtypes = [_vp, _vp, _sz]
+        L.orc_grammar_read.restype = _sz
+        L.orc_grammar_read.argtypes = [_vp, _vp, _sz]
+        L.orc_grammar_span.restype = _sz
+        L.orc_grammar_span.argtypes = [_vp, _sz]
+        L.orc_grammar_add_rule.restype = None
+        L.orc_grammar_add_rule.argtypes = [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+        L.orc_grammar_expand_alphabet.restype = _sz
+        L.orc_grammar_expand_alphabet.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp]
+        L.orc_pair_statistics.restype = None
+        L.orc_pair_statistics.argtypes = [_vp, _vp, _sz, _vp, _vp]
+        L.orc_pair_replace_round.restype = _sz
+        L.orc_pair_replace_round.argtypes = [_vp, _vp, _sz, _vp, _vp]
+        L.orc_precompress.restype = _sz
+        L.orc_precompress.argtypes = [_vp, ctypes.c_char_p, _vp, _sz]
+        L.orc_postprocess.restype = _sz
+        L.orc_postprocess.argtypes = [_vp, _vp, _sz, _vp, _sz]
+        L.orc_postprocess_bytes.restype = _sz
+        L.orc_postprocess_bytes.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz]
+        L.orc_compress_prepr.restype = _sz
+        L.orc_compress_prepr.argtypes = [ctypes.c_char, ctypes.c_char_p, _vp, _sz, ctypes.c_uint64, _u32, _vp, _sz]
         _lib = L
     return _lib
 
@@ -247,3 +281,83 @@ def oracle_decompress_wavelet(stream, max_size, want_bwt=False):
     if n == ctypes.c_size_t(-1).value:
         return (None, None) if want_bwt else None
     return (out[:n].copy(), bwt[:n].copy()) if want_bwt else out[:n].copy()
+
+
+# ---- pair-replacing pre-stage (`--prepr p...`; oracle/prepr_oracle.cpp) --------------------------------
+class OracleGrammar:
+    """bwtc::Grammar as the oracle restates it."""
+
+    def __init__(self):
+        self.h = lib().orc_grammar_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_grammar_free(self.h)
+            self.h = None
+
+    @property
+    def rules(self):
+        return int(lib().orc_grammar_rules(self.h))
+
+    @property
+    def specials(self):
+        return int(lib().orc_grammar_specials(self.h))
+
+    def is_special(self, c):
+        return bool(lib().orc_grammar_is_special(self.h, int(c)))
+
+    def frequencies(self):
+        f = np.zeros(256, np.uint64)
+        lib().orc_grammar_frequencies(self.h, _ptr(f))
+        return f
+
+    def write(self):
+        out = np.zeros(1 << 16, np.uint8)
+        n = lib().orc_grammar_write(self.h, _ptr(out), out.size)
+        assert n != ctypes.c_size_t(-1).value
+        return out[:n].copy()
+
+    def read(self, raw):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        return int(lib().orc_grammar_read(self.h, _ptr(raw), raw.size))
+
+
+def oracle_pair_statistics(data, grammar=None):
+    data = np.ascontiguousarray(data, np.uint8)
+    f = np.zeros(256, np.uint64)
+    pf = np.zeros(1 << 16, np.uint64)
+    lib().orc_pair_statistics(grammar.h if grammar else None, _ptr(data), data.size, _ptr(f), _ptr(pf))
+    return f, pf
+
+
+def oracle_pair_replace_round(grammar, data):
+    """One PairReplacer over `data` with `grammar` (updated): (replacements made, new bytes)."""
+    data = np.ascontiguousarray(data, np.uint8)
+    out = np.zeros(2 * data.size + 8, np.uint8)
+    n = ctypes.c_size_t(0)
+    rep = lib().orc_pair_replace_round(grammar.h, _ptr(data), data.size, _ptr(out), ctypes.byref(n))
+    return int(rep), out[:n.value].copy()
+
+
+def oracle_precompress(grammar, options, data):
+    buf = np.ascontiguousarray(data, np.uint8).copy()
+    n = lib().orc_precompress(grammar.h, options.encode(), _ptr(buf), buf.size)
+    return buf[:n].copy()
+
+
+def oracle_postprocess(grammar, data, max_size):
+    data = np.ascontiguousarray(data, np.uint8)
+    out = np.zeros(max_size, np.uint8)
+    n = lib().orc_postprocess(grammar.h, _ptr(data), data.size, _ptr(out), out.size)
+    if n == ctypes.c_size_t(-1).value:
+        return None
+    return out[:n].copy()
+
+
+def oracle_compress_prepr(coder, options, data, mem_limit, sp=8):
+    """Compressor::compress with `--prepr options --mem` (mem_limit in bytes, Compressor.cpp:77-97)."""
+    data = np.ascontiguousarray(data, np.uint8)
+    out = np.zeros(int(lib().orc_compress_bound(data.size)) * 2 + 4096, np.uint8)
+    n = lib().orc_compress_prepr(coder.encode(), options.encode(), _ptr(data), data.size, int(mem_limit), sp, _ptr(out), out.size)
+    assert n > 0
+    return out[:n].copy()

@@ -361,3 +361,55 @@ def test_host_pipeline_program(oracle):
     for simd in ("1", "0"):
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, BWTC_HIP_SIMD=simd))
         assert r.returncode == 0 and "all tests passed" in r.stdout, (simd, r.stdout + r.stderr)
+
+
+# ---- pair-replacing pre-stage (`--prepr`): the product's host half against the oracle ---------------------
+def _prepr_inputs():
+    from bwtc_amd import synth
+    rng = np.random.default_rng(5)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "prepr_known_answers.json")) as f:
+        cases = json.load(f)["pair_replacer"]
+    out = []
+    for c in cases:
+        parts = [np.frombuffer((c["repeat"] * c["times"]).encode(), np.uint8)]
+        for fl in c["fill"]:
+            parts += [np.array([x for x in range(256) if chr(x) not in fl["skip"]], np.uint8)] * fl["times"]
+        parts.append(np.frombuffer(c["tail"].encode(), np.uint8))
+        out.append((c["name"], np.concatenate(parts)))
+    words = [bytes(rng.integers(97, 110, rng.integers(2, 8)).astype(np.uint8)) for _ in range(60)]
+    out.append(("words", np.frombuffer(b" ".join(words[int(i)] for i in rng.integers(0, 60, 30000)), np.uint8)))
+    # runs of one byte of every length and parity between other text: a replaced pair of equal bytes
+    runs = b"".join(b"a" * int(k) + bytes([98 + int(k) % 5]) for k in rng.integers(1, 40, 6000))
+    out.append(("runs", np.frombuffer(runs, np.uint8)))
+    out.append(("runs_odd", np.frombuffer(runs[1:-2], np.uint8)))
+    out.append(("zeros", np.zeros(50001, np.uint8)))
+    out.append(("zeros_then_text", np.concatenate([np.zeros(30000, np.uint8), out[-4][1][:20000]])))
+    out.append(("random", rng.integers(0, 256, 40000).astype(np.uint8)))
+    out.append(("text", synth.gen_text(300000, 11)))
+    for n in (3, 4, 5, 8):
+        out.append(("tiny%d" % n, np.frombuffer(b"abababab"[:n], np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("name,data", _prepr_inputs(), ids=[n for n, _ in _prepr_inputs()])
+def test_prepr_host_half_matches_the_oracle(name, data):
+    """Precompressor::precompress (Precompressor.cpp:62-121) by the product's host half -- statistics and replaced
+    text in their position-by-position form, the choice of pairs, the grammar -- against the oracle's sequential
+    restatement: same bytes, same serialised grammar, and the product's Postprocessor gives the input back."""
+    from bwtc_amd import hip
+    import oracle_lib
+    for opts in ("p", "pp", "ppppp"):
+        g, og = hip.Grammar(), oracle_lib.OracleGrammar()
+        mine = g.host_precompress(opts, data)
+        want = oracle_lib.oracle_precompress(og, opts, data)
+        assert mine.size == want.size and (mine == want).all(), (name, opts)
+        assert g.write().tobytes() == og.write().tobytes(), (name, opts)
+        assert (g.rules, g.special_symbols) == (og.rules, og.specials)
+        back = g.postprocess(mine, data.size + 8)
+        assert back.size == data.size and (back == data).all(), (name, opts)
+        g2 = hip.Grammar()
+        assert g2.read(og.write()) == og.write().size
+        back = g2.postprocess(want, data.size + 8)
+        assert back.size == data.size and (back == data).all(), (name, opts)
+        ob = oracle_lib.oracle_postprocess(og, mine, data.size + 8)
+        assert ob is not None and ob.size == data.size and (ob == data).all(), (name, opts)

@@ -255,3 +255,85 @@ def test_oracle_wavelet_decoder_rejects_damage(oracle):
     st = oracle.oracle_compress_B(d, d.size, 1)
     assert oracle.oracle_decompress_wavelet(st, d.size + 8).tobytes() == d.tobytes()
     assert oracle.oracle_decompress_wavelet(st[: st.size // 2], d.size + 8) is None
+
+
+# ---- pair-replacing pre-stage: the known answers of the reference's own tests ---------------------------
+def _prepr_input(case):
+    parts = [np.frombuffer((case["repeat"] * case["times"]).encode(), np.uint8)]
+    for f in case["fill"]:
+        sweep = np.array([c for c in range(256) if chr(c) not in f["skip"]], np.uint8)
+        parts += [sweep] * f["times"]
+    parts.append(np.frombuffer(case["tail"].encode(), np.uint8))
+    return np.concatenate(parts)
+
+
+def _prepr_cases():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "prepr_known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _prepr_cases()["pair_replacer"], ids=lambda c: c["name"])
+def test_pair_replacer_known_answers(oracle, case):
+    """test/PairReplacerTest.cpp: replacements decided, size of the replaced text, special symbols and rules of
+    the grammar; and the grammar's serialised form read back expands the text to the input."""
+    data = _prepr_input(case)
+    g = oracle.OracleGrammar()
+    cur = data
+    for k, rnd in enumerate(case["rounds"]):
+        if rnd.get("first_byte_not_special_before"):
+            assert not g.is_special(cur[0])
+        rep, cur = oracle.oracle_pair_replace_round(g, cur)
+        if rnd["rep"] is not None:
+            assert rep == rnd["rep"], (case["name"], k)
+        if rnd["size"] is not None:
+            assert cur.size == rnd["size"], (case["name"], k)
+    if case["specials"] is not None:
+        assert g.specials == case["specials"]
+    if case["rules"] is not None:
+        assert g.rules == case["rules"]
+    raw = g.write()
+    g2 = oracle.OracleGrammar()
+    assert g2.read(raw) == raw.size
+    assert (g2.frequencies() == g.frequencies()).all()
+    back = oracle.oracle_postprocess(g2, cur, data.size + 16)
+    assert back is not None and back.size == data.size and (back == data).all()
+
+
+def test_grammar_known_answers(oracle):
+    """test/GrammarTest.cpp: the empty grammar, and two freed symbols over two new special symbols."""
+    ka = _prepr_cases()["grammar"]
+    g = oracle.OracleGrammar()
+    raw = g.write()
+    assert raw.tolist() == [0]
+    g2 = oracle.OracleGrammar()
+    assert g2.read(raw) == 1 and g2.rules == 0 and g2.specials == 0
+    sp = ka["special_symbols"]
+    g = oracle.OracleGrammar()
+    L = oracle.lib()
+    L.orc_grammar_add_rule(g.h, ord(sp["rule"][0]), ord(sp["rule"][1]), ord(sp["rule"][2]))
+    freed = np.frombuffer(sp["freed"].encode(), np.uint8)
+    spec = np.frombuffer(sp["specials"].encode(), np.uint8)
+    pairs = np.zeros(8, np.uint16)
+    n = L.orc_grammar_expand_alphabet(g.h, oracle._ptr(freed), freed.size, oracle._ptr(spec), spec.size, oracle._ptr(pairs))
+    assert n == len(sp["next_pairs"])
+    for k, (a, b) in enumerate(sp["next_pairs"]):
+        assert (int(pairs[k]) >> 8, int(pairs[k]) & 0xFF) == (ord(a), ord(b))
+    assert g.rules == sp["rules"] and g.specials == sp["n_specials"]
+    raw = g.write()
+    g2 = oracle.OracleGrammar()
+    assert g2.read(raw) == raw.size and g2.rules == g.rules and g2.specials == g.specials
+
+
+@pytest.mark.parametrize("coder", ["H", "B"])
+@pytest.mark.parametrize("prep", ["", "p", "pp", "ppppp"])
+def test_prepr_streams_round_trip_in_the_oracle(oracle, coder, prep):
+    """The matrix of test/CompressorAndDecompressorTest.cpp:61-205 with the pre-stage on: the oracle's own
+    encoder against its own (independent) decoders, several precompressor blocks and slices."""
+    rng = np.random.default_rng(17 + len(prep))
+    words = [bytes(rng.integers(97, 105, rng.integers(2, 7)).astype(np.uint8)) for _ in range(40)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 40, 12000))
+    for data, mem in ((np.frombuffer(text, np.uint8), 40000), (np.frombuffer(text[:3000], np.uint8), 100000),
+                      (rng.integers(0, 256, 5000).astype(np.uint8), 9000)):
+        stream = oracle.oracle_compress_prepr(coder, prep, data, mem)
+        back = oracle.oracle_decompress_H(stream, data.size + 64) if coder == "H" else oracle.oracle_decompress_wavelet(stream, data.size + 64)
+        assert back is not None and back.size == data.size and (back == data).all(), (coder, prep, mem)
