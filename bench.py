@@ -230,6 +230,9 @@ def main():
                          "this run codes (compress.cpp: 128 / 96 blocks -- the fused lane engines -- only for streams "
                          "of 256 blocks and more, when the host has AVX-512 and 40 / 24 GB per rank; else 20, 16 below 40 GB)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
+    ap.add_argument("--workload", default="c3",
+                    help="extras only (the headline is c3): realtext, realtext_rep, dna, random, zeros, period9, reptext -- "
+                         "the inputs of scripts/r4/workloads.py instead of the C3 generator's blocks")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -262,7 +265,7 @@ def main():
     # (deep pipelines are for the host-model routes; with the models on the GPU 13-14 blocks carry the
     # rate and 20 absorb the spread of the host half)
     deep = stream_blocks >= 256 and has_avx512() and os.environ.get("BWTC_HIP_MODELS") == "host"
-    auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 20 if mem_per_rank >= 40 else 16
+    auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 24 if mem_per_rank >= 48 else 20 if mem_per_rank >= 40 else 16
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
@@ -287,7 +290,15 @@ def main():
     # distinct blocks in page-locked host memory: C3 seeds 3, 4, ... (one rank) / C4 seeds 30 + rank + 8 j
     nblk = max(1, args.blocks)
     seeds = [(3 + j) if world == 1 else (30 + rank + 8 * j) for j in range(nblk)]
-    pool = [hip.synth_into("t", s, ctx.host_alloc(size)) for s in seeds]
+    if args.workload == "c3":
+        pool = [hip.synth_into("t", s, ctx.host_alloc(size)) for s in seeds]
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "scripts", "r4"))
+        import workloads
+        data, workload_what = workloads.gen(args.workload, size)
+        pool = [ctx.host_alloc(size)]
+        pool[0][:] = data
+        nblk = 1
     d_in = [ctx.dmalloc(size + 64), ctx.dmalloc(size + 64)]
     d_out = ctx.dmalloc(size + 64)
     bound = ctx.compress_bound(size)
@@ -338,7 +349,7 @@ def main():
             if rc:
                 raise hip.BwtcHipError("bwtc_hip_memcpy_to_host failed with code %d" % rc)
         elif coder == "B":
-            pending.append(cpu_of("wavelet_begin", ctx.wavelet_encode_device_begin, d_out, size, lf, freqs, ring[i % (depth + 1)], threads))
+            pending.append(cpu_of("wavelet_begin", ctx.wavelet_encode_device_begin, d_out, size, lf, freqs, ring[i % len(ring)], threads))
         clock["gpu_s"] += time.perf_counter() - t
         issued[0] += 1
 
@@ -368,6 +379,15 @@ def main():
     for _ in range(settle):
         step()
     fill_blocks += settle
+    # The depth the stream has shown to need (the library's own figure: block latency over block interval, a quarter
+    # more, plus two) replaces the memory-derived default for the timed region -- fewer blocks under way hold less
+    # page-locked memory, and what an 8-GPU node has to provide per rank is this number, not the default.
+    depth_default = depth
+    depth_measured = ctx.wavelet_depth_needed() if coder == "B" else 0
+    if coder == "B" and args.depth == 0 and depth_measured and os.environ.get("BWTC_BENCH_FIXED_DEPTH") != "1":
+        depth = max(8, min(depth_default, depth_measured))
+        while len(pending) > depth:
+            collect()
     fill_ms = 1e3 * (time.perf_counter() - t0)
     rss = {"before_first_block": rss0, "after_fill": _rss_gb()}
     ctx.reset_kernel_timers()
@@ -410,6 +430,19 @@ def main():
     # records the host workers finished inside the timed region: the rate the host half really
     # sustained (the records COLLECTED there may all have been finished during the fill)
     finished = (f1 - f0) if coder == "B" else args.steps
+    # what every rank got and did (a skewed NUMA slice or a starved rank shows here, not in the maximum alone)
+    per_rank = {
+        "host_threads": farm.all_gather_int(threads if coder == "B" else 0),
+        "numa_node": farm.all_gather_int(numa_node),
+        "cpus_in_slice": farm.all_gather_int(len(my_cpus)),
+        "staging_peak_MB": farm.all_gather_int(hip.host_staging_bytes()[1] // 1000000),
+        "gpu_us_per_step": farm.all_gather_int(1e6 * gpu_s / args.steps),
+        "collect_wait_us_per_step": farm.all_gather_int(1e6 * collect_s / args.steps),
+        "records_finished_in_region": farm.all_gather_int(finished),
+        "depth_used": farm.all_gather_int(depth),
+        "depth_needed": farm.all_gather_int(ctx.wavelet_depth_needed() if coder == "B" else 1),
+        "process_cpu_ms_per_step": farm.all_gather_int(1e3 * (cpu1 - cpu0) / args.steps),
+    }
     finished = int(-farm.max(-finished))                 # the slowest rank's count
 
     # a real corpus (enwik8 / enwik9 ...) when one is supplied, cut into blocks of
@@ -554,10 +587,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64 integer", "data": "synthetic",
-            "config": {"workload": "%s: %d MiB enwik8-style synthetic text blocks (splitmix64 token generator, "
-                                   "seeds %s, %d distinct blocks cycled), 8 starting points, one block per step per GPU"
-                                   % ("C5" if coder is None and args.size_mib >= 1024 else "C3" if world == 1 else "C4",
-                                      args.size_mib, "3.." if world == 1 else "30+rank+8j", nblk),
+            "config": {"workload": ("%s: %d MiB enwik8-style synthetic text blocks (splitmix64 token generator, "
+                                    "seeds %s, %d distinct blocks cycled), 8 starting points, one block per step per GPU"
+                                    % ("C5" if coder is None and args.size_mib >= 1024 else "C3" if world == 1 else "C4",
+                                       args.size_mib, "3.." if world == 1 else "30+rank+8j", nblk))
+                                   if args.workload == "c3" else
+                                   ("EXTRA (not the headline workload) %s: %d MiB, %s; the one block every step"
+                                    % (args.workload, args.size_mib, workload_what)),
                        "timed_region": "block in page-locked host memory -> " +
                                        ("transformed block in HBM" if coder is None else "record in host memory") +
                                        "; upload of block i+1 overlaps the kernels of block i" +
@@ -586,6 +622,18 @@ def main():
             "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,
+            "per_rank": [{"rank": r, "host_threads": per_rank["host_threads"][r], "numa_node": per_rank["numa_node"][r],
+                          "cpus_in_slice": per_rank["cpus_in_slice"][r],
+                          "staging_peak_gb": round(per_rank["staging_peak_MB"][r] / 1e3, 2),
+                          "gpu_ms_per_step": round(per_rank["gpu_us_per_step"][r] / 1e3, 2),
+                          "collect_wait_ms_per_step": round(per_rank["collect_wait_us_per_step"][r] / 1e3, 2),
+                          "records_finished_in_region": per_rank["records_finished_in_region"][r],
+                          "depth_used": per_rank["depth_used"][r], "depth_needed": per_rank["depth_needed"][r],
+                          "process_cpu_s_per_step": round(per_rank["process_cpu_ms_per_step"][r] / 1e3, 3),
+                          "host_bound": bool(coder == "B" and (per_rank["collect_wait_us_per_step"][r] > 100.0 * step_ms
+                                                               or per_rank["records_finished_in_region"][r] < args.steps))}
+                         for r in range(world)],
+            "depth_default": depth_default, "depth_measured_after_fill": depth_measured,
             "block_latency_ms": round(1e3 * block_latency, 1) if coder == "B" else 0.0,
             "depth_needed": int(-(-(1e3 * block_latency if block_latency else single_ms) // max(step_ms, 1e-3))) if coder == "B" else 1,
             "host_core_s_per_block": round(((m1 - m0) + (c1 - c0)) / blocks_done, 3) if coder == "B" else 0.0,

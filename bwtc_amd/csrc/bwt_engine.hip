@@ -1349,6 +1349,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
+    if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS")));
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
@@ -1467,6 +1468,7 @@ void BwtEngine::release() {
   if (d_gm) { (void)hipFree(d_gm); d_gm = nullptr; gm_bytes = 0; }
   if (d_gm_w) { (void)hipFree(d_gm_w); d_gm_w = nullptr; gm_w_bytes = 0; }
   if (h_gm) { (void)hipHostFree(h_gm); h_gm = nullptr; h_gm_bytes = 0; }
+  if (ev_gm_upload) { (void)hipEventDestroy(ev_gm_upload); ev_gm_upload = nullptr; gm_upload_pending = false; }
   if (ev_codes) { (void)hipEventDestroy(ev_codes); ev_codes = nullptr; }
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);
@@ -1610,14 +1612,16 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
 template <typename K, bool INIT>
 int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
                          RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split,
-                         const RrLong* lg, bool text) {
+                         const RrLong* lg, bool text, bool carry_in) {
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
   constexpr bool kCanSplit = INIT && sizeof(K) == 8;
-  const bool lng = kCanSplit && lg && lg->w;              // items of the long-key sort (always split)
+  const bool lng = kCanSplit && lg && lg->w;              // items of the long-key sort (split: 16-bit values + upper bits in the key)
   const RrLong lgv = lng ? *lg : RrLong();
-  if (lng) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, kCanSplit, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+  if (lng && split) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, kCanSplit, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
+                              short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
+  else if (lng) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, false, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
                               short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
   else if (split) hipLaunchKernelGGL((k_rerank_reduce<K, INIT, kCanSplit>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, m, n,
                                 short_len, kmask, d_aggA, d_aggB, d_aggC, lgv);
@@ -1644,7 +1648,10 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   const int b2 = rank_bits(n);
   const int b1 = bit_width_u64(groups ? groups - 1 : 0);
   const int nbits = b1 + b2;
-  if (emit && m_next && nbits > 56) return -3;         // can_carry() promised this cannot happen
+  // a key of more than 56 bits has no room for the carried character (blocks above 256 MiB with many groups): the
+  // next list then goes without, and its ranking reads T[s-1] for what it finishes
+  const bool carry_next = emit && nbits <= 56;
+  res->carry = carry_next;
   const bool dense = !text && dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
   u32* sa_out = (emit && !fin_active) ? nullptr : d_SA;   // finisher route: the bridge will want the finished suffixes' slots
   u32* rank_arg = text ? nullptr : d_rank;                // text rounds: rank[] is neither complete nor needed
@@ -1654,13 +1661,19 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   if (res->finish) {
     sa_out = d_SA;
     fin_active = true;
-    if constexpr (kCanSplit)
-      hipLaunchKernelGGL((k_rerank_apply<K, INIT, 3, 3, true, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
-                         (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,
-                         rb.v_free, rb.aglob_next, d_GRP, (u32*)nullptr, (u32*)nullptr, re, lgv);
+    if constexpr (kCanSplit) {
+      if (split)
+        hipLaunchKernelGGL((k_rerank_apply<K, INIT, 3, 3, true, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
+                           (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,
+                           rb.v_free, rb.aglob_next, d_GRP, (u32*)nullptr, (u32*)nullptr, re, lgv);
+      else
+        hipLaunchKernelGGL((k_rerank_apply<K, INIT, 3, 3, false, true>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs,
+                           (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, d_rank, sa_out,
+                           rb.v_free, rb.aglob_next, d_GRP, (u32*)nullptr, (u32*)nullptr, re, lgv);
+    }
+    res->carry = true;
     return 0;
   }
-  constexpr int kEmitKind = INIT ? 2 : 1;               // where the character comes from (see RrEmit)
   u64* recA = static_cast<u64*>(rb.rec_free);
   u64* recB = static_cast<u64*>(rb.rec_keys);
 
@@ -1668,11 +1681,16 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   hipLaunchKernelGGL((k_rerank_apply<K, INIT, MODE, EMIT, SP, LG>), dim3(tiles), dim3(kRrTPB), 0, st, ks, vs, \
                      (const u32*)rb.aglob, m, n, short_len, kmask, d_aggA, d_aggB, d_aggC, rank_arg, sa_out, \
                      AIDX, rb.aglob_next, d_GRP, PS, PR, re, lgv)
-  // long items carry their character's code in the key: EMIT kind 3 whatever the caller names
-#define BWTC_APPLY(MODE, EMIT, PS, PR, AIDX)                                                              \
-  do { if (lng) BWTC_APPLY_S(MODE, ((EMIT) ? 3 : 0), kCanSplit, kCanSplit, PS, PR, AIDX);                  \
-       else if (split) BWTC_APPLY_S(MODE, EMIT, kCanSplit, false, PS, PR, AIDX);                          \
-       else BWTC_APPLY_S(MODE, EMIT, false, false, PS, PR, AIDX); } while (0)
+  // Where a finished suffix's character comes from (see RrEmit): long items carry its code in the key (3); the
+  // initial ranking of other items, and rounds whose keys had no room for it, read T[s-1] (2); rounds find it in
+  // bits 56..63 of their key (1); 0: nothing is emitted.
+#define BWTC_APPLY(MODE, PS, PR, AIDX)                                                                    \
+  do { if (lng && split) { if (emit) BWTC_APPLY_S(MODE, 3, kCanSplit, kCanSplit, PS, PR, AIDX); else BWTC_APPLY_S(MODE, 0, kCanSplit, kCanSplit, PS, PR, AIDX); } \
+       else if (lng) { if (emit) BWTC_APPLY_S(MODE, 3, false, kCanSplit, PS, PR, AIDX); else BWTC_APPLY_S(MODE, 0, false, kCanSplit, PS, PR, AIDX); } \
+       else if (split) { if (emit) BWTC_APPLY_S(MODE, 2, kCanSplit, false, PS, PR, AIDX); else BWTC_APPLY_S(MODE, 0, kCanSplit, false, PS, PR, AIDX); } \
+       else if (!emit) BWTC_APPLY_S(MODE, 0, false, false, PS, PR, AIDX);                                 \
+       else if (INIT || !carry_in) BWTC_APPLY_S(MODE, 2, false, false, PS, PR, AIDX);                     \
+       else BWTC_APPLY_S(MODE, 1, false, false, PS, PR, AIDX); } while (0)
   if (dense) {
     u32* tri_key = reinterpret_cast<u32*>(recA);
     // records partitioned by the top 16 bits of s (bits 32.. of the record), two stable passes
@@ -1680,8 +1698,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     const int lo = bits > window_bits ? bits - window_bits : 0;
     re.rec_plane = digit_planes ? d_P0 : nullptr;
     re.rec_shift = lo;
-    if (emit) BWTC_APPLY(2, kEmitKind, tri_key, rb.v_free, (u32*)nullptr);
-    else BWTC_APPLY(2, 0, tri_key, rb.v_free, (u32*)nullptr);
+    BWTC_APPLY(2, tri_key, rb.v_free, (u32*)nullptr);
     u64* ws = nullptr; u32* wv = nullptr;
     sort_pairs<u64>(recA, recB, rb.v_free, rb.v_keys, m, 32 + bits, &ws, &wv, false, 32 + lo, 0, true);
     u64* ws_other = ws == recA ? recB : recA;
@@ -1691,7 +1708,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     hipLaunchKernelGGL(k_scatter_dense, dim3(grid), dim3(kWinTPB), 0, st, d_rank, (const u64*)ws, m, bin_shift);
     hipLaunchKernelGGL(k_gather_dense, dim3(grid), dim3(kWinTPB), 0, st, ws, wv, (const u32*)d_rank,
                        (const u8*)d_T, m, n, (u32)(h_next > 0xFFFFFFFFull ? 0xFFFFFFFFu : h_next), b2,
-                       emit ? 1 : 0, bin_shift);
+                       carry_next ? 1 : 0, bin_shift);
     const bool timed = n_sort_events + 2 <= kMaxSortEvents;
     if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
     sort_pairs<u64>(ws, ws_other, wv, wv_other, m_next, nbits, &res->ks, &res->vs, true, 0, (u64)(m - m_next));
@@ -1712,8 +1729,8 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   if (text) {
     // text round: rank[] is neither complete nor needed
     res->text_chars = (u32)std::min(6, (56 - b1 - 4) / 8);
-    if (emit) BWTC_APPLY(0, kEmitKind, (u32*)nullptr, (u32*)nullptr, rb.v_free);
-    else BWTC_APPLY(0, 0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    BWTC_APPLY(0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    res->carry = emit;
     if (m_next == 0) return 0;
     const int tbits = b1 + 8 * (int)res->text_chars + 4;
     hipLaunchKernelGGL(k_gather_text, dim3(ceil_div(m_next, 256)), dim3(256), 0, st, (const u32*)rb.v_free, (const u32*)d_GRP,
@@ -1727,19 +1744,17 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     return 0;
   }
   if (m >= kPairsMin || INIT) {
-    if (emit) BWTC_APPLY(1, kEmitKind, pairs, pairs + cap, rb.v_free);
-    else BWTC_APPLY(1, 0, pairs, pairs + cap, rb.v_free);
+    BWTC_APPLY(1, pairs, pairs + cap, rb.v_free);
     scatter_rank_pairs(pairs, reinterpret_cast<u32*>(recB), m, n);
   } else {
-    if (emit) BWTC_APPLY(0, kEmitKind, (u32*)nullptr, (u32*)nullptr, rb.v_free);
-    else BWTC_APPLY(0, 0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    BWTC_APPLY(0, (u32*)nullptr, (u32*)nullptr, rb.v_free);
   }
 #undef BWTC_APPLY
 #undef BWTC_APPLY_S
   if (m_next == 0) return 0;
   hipLaunchKernelGGL(k_gather_key2, dim3(ceil_div(m_next, 256 * kSimpleE)), dim3(256), 0, st,
                      (const u32*)rb.v_free, (const u32*)d_GRP, (const u32*)d_rank,
-                     emit ? (const u8*)re.achr_out : (const u8*)nullptr, recA, m_next, n,
+                     carry_next ? (const u8*)re.achr_out : (const u8*)nullptr, recA, m_next, n,
                      (u32)(h_next > 0xFFFFFFFFull ? 0xFFFFFFFFu : h_next), b2);
   const bool timed = n_sort_events + 2 <= kMaxSortEvents;
   if (timed) BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
@@ -1895,8 +1910,12 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
                          (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, 1, lk);
       u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
-      radix_sort_long<unsigned short>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                      d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
+      if (long_items_per_thread == 6)
+        radix_sort_long<unsigned short, 6>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
+      else
+        radix_sort_long<unsigned short, 8>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
       BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
       u32* vs = reinterpret_cast<u32*>(vs16);
       rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
@@ -1963,7 +1982,6 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     stats.alg_bytes += (u64)n * (1 + (u64)(plan.wide ? 8 : 4) + 1) + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits, item, plan.wide ? 8 : 4, digit_planes);
   }
 
-  const u64 round_mask = emit ? ((1ull << 56) - 1ull) : ~0ull;
   u32 m = res.m;
   bool keep_h = false;                     // the list is sorted to depth h as it stands (no doubling before the next step)
   int text_left = 0;                       // rounds that compare the text itself (finisher route, rank[] incomplete)
@@ -2004,7 +2022,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     rb.v_keys = res.vs; rb.v_free = res.v_other;
     const u64* ks = res.ks;
     const u32* vs = res.vs;
-    rc = rank_step<u64, false>(ks, vs, m, n, 0u, round_mask, rb, re, emit, h, &res, 0u, nullptr, text);
+    const bool carried = emit && res.carry;             // this list's keys hold the characters in bits 56..63
+    rc = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text, carried);
     if (rc) return rc;
     m = res.m;
     if (text) { h += res.text_chars; keep_h = true; --text_left; }
@@ -2118,7 +2137,9 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   // Blocks up to 256 MiB: the transform's bytes are written by the ranking kernels, straight
   // into the caller's buffer (d_src was consumed by load_text, so d_dst may alias it).
   // Larger blocks (a round's key then needs the character's bits): suffix array + gather.
-  const bool emit = can_carry(n) && !no_emit;
+  // The transform's bytes leave from the ranking kernels (a list whose keys have no room for the carried
+  // character -- more than 56 bits, only possible above 256 MiB -- reads T[s-1] for what it finishes).
+  const bool emit = !no_emit;
   if (emit) {
     EmitTarget em;
     em.out = d_dst;

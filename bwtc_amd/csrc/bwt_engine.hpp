@@ -79,7 +79,15 @@ inline void* lockedHostAlloc(size_t n, int* kind) {
       q = reinterpret_cast<void*>(al);
       (void)madvise(q, bytes, MADV_HUGEPAGE);
       for (size_t i = 0; i < bytes; i += 4096) static_cast<volatile char*>(q)[i] = 0;
-      if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) { *kind = 2; return q; }
+      // Huge pages only where the first touch got them: from here on the range is left alone (no later
+      // collapse by khugepaged under a registered range -- the device's mapping of a page that the kernel
+      // is replacing is what round 3's write fault looked like).
+      (void)madvise(q, bytes, MADV_NOHUGEPAGE);
+      if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) {
+        if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "pinned: registered [%p, %p) (%zu MiB, mapping of its own)\n", q, static_cast<char*>(q) + bytes, bytes >> 20);
+        *kind = 2;
+        return q;
+      }
       (void)hipGetLastError();
       (void)munmap(q, bytes);
       q = nullptr;
@@ -95,6 +103,7 @@ inline void lockedHostFree(void* p, int kind, size_t n) {
   if (!p) return;
   if (kind == 2) {
     if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return; }   // still known to the device: the mapping stays
+    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "pinned: unregistered and unmapped [%p, %p)\n", p, static_cast<char*>(p) + lockedMapBytes(n));
     (void)munmap(p, lockedMapBytes(n));
   } else if (kind == 1) (void)hipHostFree(p);
   else std::free(p);
@@ -222,6 +231,8 @@ struct DeviceWaveletJob : WaveletJob {
   bool streams_ready = false;          // plan + coded_pos + codes are in place for HostPipeline::queue
   bool host_route = false;             // coded by encodeSections at queue time instead
   bool queued = false;
+  bool joins_from_callback = false;    // farmed stream: the block joins the host pipeline from a callback on the d2h stream
+  std::atomic<bool> callback_seen{false};
   bool half = false;                   // scanned and (being) planned; streams not made yet
   bool copying = false;                // streams made, their copy to the host may still be in flight
   int run_buf = 0;                     // which of the engine's run-array buffers holds its runs
@@ -295,6 +306,8 @@ struct BwtEngine {
   void* d_gm = nullptr;  u64 gm_bytes = 0;
   void* d_gm_w = nullptr; u64 gm_w_bytes = 0;
   u8* h_gm = nullptr;    u64 h_gm_bytes = 0;
+  hipEvent_t ev_gm_upload = nullptr;   // the tables' upload from h_gm has finished (the next block may fill h_gm)
+  bool gm_upload_pending = false;
   int reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes);
   ScanChain scan_chain;                // single-launch scans (scan.hpp): BWTC_HIP_SCAN=chained switches them on (slower here)
   // while alive, the calling thread's scans go through this context's chain
@@ -345,6 +358,7 @@ struct BwtEngine {
   int n_sort_events = 0;
 
   bwtc_hip_stats stats;
+  int stream_start_error = 0;   // bwtc_hip_wavelet_start / _reset could not let the old stream's blocks join: the next _begin / _prepare says so
   u32 wavelet_state = 4;   // FSM8 state carried from block to block by one WaveletEncoder
   char wavelet_model = 'B'; // coder letter = main probability model ('B', 'b' or 'u')
   ScatterProbe probe;
@@ -368,11 +382,11 @@ struct BwtEngine {
                   bool probe_it, int bit_lo = 0, u64 n_holes = 0, bool plane_ready = false, bool values_descend = false);
   // one ranking step of the suffix sorter (bwt_engine.hip)
   struct RankBuffers { void* rec_keys; void* rec_free; u32* v_keys; u32* v_free; u32* aglob; u32* aglob_next; };
-  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; bool finish; u32 text_chars; };
+  struct RankResult { u32 m, groups; u64* ks; u32* vs; void* rec_other; u32* v_other; bool finish; u32 text_chars; bool carry; };
   template <typename K, bool INIT>
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
                 struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0,
-                const struct RrLong* lg = nullptr, bool text = false);
+                const struct RrLong* lg = nullptr, bool text = false, bool carry_in = true);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
@@ -383,6 +397,7 @@ struct BwtEngine {
   int plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp);
   bool no_emit = false;      // BWTC_HIP_NO_EMIT: suffix array + gather even for blocks that could carry
   bool long_keys = true;     // BWTC_HIP_LONG=0: never the long-key initial sort
+  int long_items_per_thread = 8;   // BWTC_HIP_LONG_E=6: tiles of 3072 items (three workgroups per CU instead of two)
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
   int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling

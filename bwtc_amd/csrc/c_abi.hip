@@ -370,13 +370,16 @@ int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
   // blocks begun with _begin that have not joined their stream yet belong to the OLD stream:
   // they join it now, with its state and its model, before either changes
   const int rc = wavelet_join_begun(ctx->eng);
-  if (rc) return rc;
+  // whatever became of the old stream's blocks (a failed join is reported, and their _end reports it again), the
+  // NEW stream starts from the fresh state: never the old stream's carried state under a new header
   ctx->eng.wavelet_state = 4;
   ctx->eng.wavelet_model = coder;
-  return 0;
+  ctx->eng.stream_start_error = rc;
+  return rc;
 }
-void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }
+void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }   // a failure is kept: the next _begin returns it
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx) { return ctx ? ctx->eng.max_inflight : 0u; }
+uint32_t bwtc_hip_wavelet_depth_needed(bwtc_hip_ctx* ctx) { return ctx && ctx->eng.pipeline ? ctx->eng.pipeline->depthNeeded() : 0u; }
 int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds, uint64_t* blocks) {
   if (!ctx) return -1;
   const HostPipeline* p = ctx->eng.pipeline;

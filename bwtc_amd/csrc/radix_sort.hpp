@@ -274,14 +274,14 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 // A workgroup takes TWO tiles, half its threads each: the kernel is a chain of latencies (clear
 // LDS, load, count, add up the copies, store) with little to do in between, so twice the bytes per
 // workgroup is close to twice the speed.
-template <typename K>
+template <typename K, int E_ = RadixCfg<K>::E>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __restrict__ plane,
                                                                 u32* __restrict__ table, u64 n,
                                                                 u32 ntiles) {
-  constexpr int E = RadixCfg<K>::E;
+  constexpr int E = E_;
   constexpr int HALF = kRadixTPB / 2;
-  constexpr int B = 2 * E;                          // bytes of the tile per thread (8, 16 or 32)
-  static_assert(B == 8 || B % 16 == 0, "8-byte or whole 16-byte loads");
+  constexpr int B = 2 * E;                          // bytes of the tile per thread (8, 12, 16 or 32)
+  static_assert(B == 8 || B == 12 || B % 16 == 0, "8-byte, 12-byte or whole 16-byte loads");
   __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * 16];
   {
     uint4* z = reinterpret_cast<uint4*>(&hist[0][0]);
@@ -294,12 +294,17 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
     const u64 base = (u64)tile * (kRadixTPB * E) + (u64)t * B;
     const u32 copy = t & 15u;
     u32* h = hist[half];
-    if (B == 8 && base + B <= n) {
+    if (B == 12 && base + B <= n) {
+      const u32* q = reinterpret_cast<const u32*>(plane + base);     // 12 t: a multiple of four
+      const u32 w[3] = {q[0], q[1], q[2]};
+#pragma unroll
+      for (int b = 0; b < 12; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+    } else if (B == 8 && base + B <= n) {
       const uint2 q = *reinterpret_cast<const uint2*>(plane + base);
       const u32 w[2] = {q.x, q.y};
 #pragma unroll
       for (int b = 0; b < 8; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
-    } else if (base + B <= n) {
+    } else if (B % 16 == 0 && base + B <= n) {
       constexpr int Q = B >= 16 ? B / 16 : 1;
       uint4 q[Q];
 #pragma unroll
@@ -327,8 +332,9 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
 }
 
 static inline u64 radix_table_words(u64 max_n) {
-  // sized for the smaller (u64) tile, which gives the larger tile count
-  u64 ntiles = (max_n + radix_tile<u64>() - 1) / radix_tile<u64>();
+  // sized for the smallest tile in use (six items per thread, the long-key sort's), which gives the largest tile count
+  const u64 tile = (u64)kRadixTPB * 6;
+  u64 ntiles = (max_n + tile - 1) / tile;
   return ntiles * kRadixBins;
 }
 static inline u64 radix_partial_words(u64 max_n) {
@@ -420,7 +426,9 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
 // w bits [0, wbits)) -- w is the LESS significant word, so its passes come first.  Stable.  The
 // producer of the items left the first pass's digits (of w) in plane0; both planes are required.
 // The first pass makes the values up (item i's value is n - 1 - i).
-template <typename V>
+// EL: items per thread (a tile is kRadixTPB * EL items; 8 for 14-byte items = 56 KiB of LDS staging, two workgroups
+// per CU; 6 keeps three: 42 KiB for 14-byte, 48 KiB for 16-byte items).
+template <typename V, int EL = 8>
 static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32* w1, u64 n, int kbits, int wbits,
                                    u32* table, u32* partial, hipStream_t st, u64** k_sorted, V** v_sorted,
                                    u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1) {
@@ -433,10 +441,10 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
   for (int s = 0; s < wbits; s += kRadixBits) ps[np++] = Pass{1, s, (1u << std::min(kRadixBits, wbits - s)) - 1u};
   for (int s = 0; s < kbits; s += kRadixBits) ps[np++] = Pass{0, s, (1u << std::min(kRadixBits, kbits - s)) - 1u};
   if (n > 1) {
-    const u32 ntiles = ceil_div(n, radix_tile<u64>());
+    const u32 ntiles = ceil_div(n, (u64)kRadixTPB * EL);
     const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
     for (int p = 0; p < np; ++p) {
-      hipLaunchKernelGGL(k_radix_hist_plane<u64>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles);
+      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool last = p + 1 == np;
       LongArgs la;
@@ -444,7 +452,7 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
       la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
       const int vmode = p == 0 ? 3 : 0;
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la)
+#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la)
       if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
       else { if (last) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
 #undef BWTC_SCATTER_L

@@ -258,6 +258,7 @@ static int wavelet_encode_queue_unguarded(BwtEngine& e, u64 ticket, u32 state_in
     const hipError_t hrc = hipLaunchHostFunc(e.d2h_stream, [](void* p) {
       std::unique_ptr<Join> j(static_cast<Join*>(p));
       DeviceWaveletJob& job = *j->job;
+      job.callback_seen.store(true);
       const u32 n_coded = job.coded_pos.empty() ? 0u : job.coded_pos.back();
       const bool ok = job.h_tail[1] == 0 && job.h_tail[2] == n_coded && job.h_tail[3] == 0 && job.h_tail[0] == job.w_end_state &&
                       !std::getenv("BWTC_HIP_TEST_MODELS_FALLBACK");
@@ -270,7 +271,15 @@ static int wavelet_encode_queue_unguarded(BwtEngine& e, u64 ticket, u32 state_in
       const u32 handed_on = job.w_end_state;
       (void)j->pipe->queue(j->job, j->state_in, 'B', &handed_on);
     }, j);
-    if (hrc != hipSuccess) { delete j; return -3; }
+    if (hrc != hipSuccess) {
+      // the copies of the w-elements and of the tail words are queued: nothing may hand the block's buffers on
+      // (the caller marks it failed, _end gives w_owner back to the pool) while they can still be written
+      delete j;
+      (void)hipStreamSynchronize(e.d2h_stream);
+      (void)hipGetLastError();
+      return -3;
+    }
+    job.joins_from_callback = true;
     return 0;
   }
   if (job.streams_ready && !job.w && !job.fused && job.prob.size() < static_cast<size_t>(job.coded_pos.empty() ? 0 : job.coded_pos.back()) + 8) {
@@ -322,6 +331,7 @@ int wavelet_encode_prepare(BwtEngine& e, const u8* d_bwt, u32 size, const u32* l
                            const u32* freqs, unsigned threads, u8* out, u64 out_cap, u64* ticket,
                            const std::function<void()>* while_scanning) {
   if (!freqs || !lf || !ticket || n_lf == 0 || n_lf > 256) return -1;
+  if (e.stream_start_error) { const int rc = e.stream_start_error; e.stream_start_error = 0; return rc; }   // bwtc_hip_wavelet_reset has no result of its own
   // bounded number of blocks under way; only ..._end frees a place, so waiting here could never help
   if (e.jobs.size() >= e.max_inflight) return -6;
   std::shared_ptr<DeviceWaveletJob> jobp(new DeviceWaveletJob());
@@ -410,7 +420,25 @@ int wavelet_encode_end(BwtEngine& e, u64 ticket, u64* out_bytes) {
       if (rc) return rc;
     }
   }
-  HostPipeline::wait(job);
+  if (job.joins_from_callback) {
+    // The block joins the host pipeline from a callback on the d2h stream.  A stream (or context) in error never
+    // runs it: look at the stream while waiting, and turn that into an error instead of waiting for ever.
+    while (!HostPipeline::waitFor(job, 200)) {
+      const hipError_t q = e.d2h_stream ? hipStreamQuery(e.d2h_stream) : hipSuccess;
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        (void)hipGetLastError();
+        std::fprintf(stderr, "bwtc_hip: the copy stream of a block under way reports %s; the block is given up\n", hipGetErrorString(q));
+        e.jobs.erase(it);
+        return -3;                                    // its buffers are NOT recycled: a copy may still own them
+      }
+      if (q == hipSuccess && HostPipeline::waitFor(job, 2000)) break;   // the stream has drained: the callback has run (or never will)
+      if (q == hipSuccess && !job.callback_seen.load()) {
+        std::fprintf(stderr, "bwtc_hip: a block's join callback did not run although its stream has drained\n");
+        e.jobs.erase(it);
+        return -3;
+      }
+    }
+  } else HostPipeline::wait(job);
   if (std::getenv("BWTC_HIP_DEBUG") && job.coder)
     std::fprintf(stderr, "wavelet block %llu: queued -> modelled %.0f ms, -> finished %.0f ms, -> collected %.0f ms\n",
                  (unsigned long long)ticket,

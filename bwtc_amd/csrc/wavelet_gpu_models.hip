@@ -259,6 +259,12 @@ int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const
   const u64 o_gmap = take((u64)g->ng * 64), o_gL = take((u64)g->ng * 2), o_tg = take((u64)g->ng * 2);
   const u64 o_snaps = take(((u64)n_coded / gm::kSample + 4) * sizeof(gm::SlotMap));
   const u64 o_tail = take(16 + 32);                   // + the eight possible states after the block
+  // h_gm is one staging buffer for every block (and reserve_models may replace it): the previous block's upload
+  // of its tables must have left it.  Until now that followed from waits elsewhere (the transform's read-backs).
+  if (e.gm_upload_pending) {
+    BWTC_HIP_TRY(hipEventSynchronize(e.ev_gm_upload));
+    e.gm_upload_pending = false;
+  }
   int rc = e.reserve_models(at, tables_end, ((u64)n_coded + 8) * 2);
   if (rc) return rc;
   u8* base = static_cast<u8*>(e.d_gm);
@@ -273,6 +279,9 @@ int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const
     for (u32 c = 0; c < nc; ++c) order[first[tasks[chunks[c].task_first & 0x7FFFFFFFu].type]++] = c;
   }
   BWTC_HIP_TRY(hipMemcpyAsync(base, e.h_gm, tables_end, hipMemcpyHostToDevice, st));
+  if (!e.ev_gm_upload) BWTC_HIP_TRY(hipEventCreateWithFlags(&e.ev_gm_upload, hipEventDisableTiming));
+  BWTC_HIP_TRY(hipEventRecord(e.ev_gm_upload, st));
+  e.gm_upload_pending = true;
   g->d_tasks = base + o_tasks; g->d_chunks = base + o_chunks; g->d_order = base + o_order;
   g->d_excl = base + o_excl; g->d_tagg = base + o_tagg; g->d_tstate = base + o_tstate;
   g->d_cmap = base + o_cmap; g->d_cstate = base + o_cstate; g->d_base = base + o_base; g->d_partial = base + o_partial;
@@ -340,6 +349,9 @@ int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_
                      (unsigned short*)g.d_tg, d_tail + 1);
   hipLaunchKernelGGL(k_gm_chain_fill, dim3(ceil_div(g.ng, 64)), dim3(64), 0, st, d_smap, nsc, g.gsize, g.ng, (const unsigned short*)g.d_tg,
                      d_sstart, d_tail + 1);
+  // d_gm_w is one buffer for every block: the copy of the previous block's w-elements (d2h stream, ev_codes) must have
+  // read it before this block's emit pass writes it (so far the callers' codes_wait saw to that)
+  if (e.codes_in_flight && e.ev_codes) BWTC_HIP_TRY(hipStreamWaitEvent(st, e.ev_codes, 0));
   hipLaunchKernelGGL(k_gm_emit, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_base, d_sb, d_sbits, d_snaps, d_smap,
                      d_sstart, d_order, nc, nt, d_w, d_tail + 1);
   // total of the scan = every element counted once (else the tables do not describe the streams)

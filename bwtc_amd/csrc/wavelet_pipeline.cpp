@@ -87,6 +87,11 @@ void HostPipeline::wait(WaveletJob& job) {
   job.cv.wait(g, [&] { return job.done; });
 }
 
+bool HostPipeline::waitFor(WaveletJob& job, unsigned milliseconds) {
+  std::unique_lock<std::mutex> g(job.mu);
+  return job.cv.wait_for(g, std::chrono::milliseconds(milliseconds), [&] { return job.done; });
+}
+
 // Appends the finished sections to the record and closes it (finishBlock,
 // WaveletCoders.cpp:159-163); the worker that finishes a block's last section runs this.
 void HostPipeline::finishNow(WaveletJob& job) {
@@ -149,6 +154,7 @@ void HostPipeline::submitSections(const std::shared_ptr<WaveletJob>& jobp) {
 
 uint32_t HostPipeline::queue(const std::shared_ptr<WaveletJob>& jobp, uint32_t fsm8_state, char model, const uint32_t* expect_end) {
   WaveletJob& job = *jobp;
+  noteBegin();
   if (job.w) {
     // The models ran on the device: what is left are the sections' range-coder chains, each on its
     // own (a chain alone advances at its full speed, and the block's longest one is its latency),

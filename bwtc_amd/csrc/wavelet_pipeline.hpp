@@ -264,6 +264,7 @@ class HostPipeline {
   // models end elsewhere is marked failed before any of its tasks runs
   uint32_t queue(const std::shared_ptr<WaveletJob>& job, uint32_t fsm8_state, char model, const uint32_t* expect_end = nullptr);
   static void wait(WaveletJob& job);
+  static bool waitFor(WaveletJob& job, unsigned milliseconds);   // true: done
   // a block without coded elements (or coded elsewhere): closes the record right away
   static void finishNow(WaveletJob& job);
   unsigned threads() const { return pool_.size(); }
@@ -309,10 +310,38 @@ class HostPipeline {
   // under way: a lone block, or the first blocks of a stream, would crawl through nearly empty
   // vectors.  The caller sets WaveletJob::fused from this before queue().
   bool fusedNow(char model) const { return max_fused_engines_ && model == 'B' && clock.unfinished.load() >= (int)kFusedBacklog; }
-  static constexpr unsigned kFusedDepth = 56;        // 256 MiB text, 16 threads, 45 ms of GPU per block: 48 deep = the scalar route's rate, 64 deep 1.5x, 96 deep 2.3x
+  // From which announced depth on the fused engines pay.  Measured at ONE point -- 256 MiB text blocks (280 M coded
+  // elements in the longest section = 4.5 s in a lane), 16 threads, a block begun every 45 ms: 48 deep = the scalar
+  // route's rate, 56 the break-even, 64 deep 1.5x, 96 deep 2.3x -- i.e. at 0.56 of the blocks that are begun while a
+  // lane holds the longest section.  Away from that point the same ratio is used: fusedDepth(seconds between blocks).
+  static constexpr unsigned kFusedDepth = 56;
+  static unsigned fusedDepth(double block_interval_s) {
+    if (!(block_interval_s > 0.0)) return kFusedDepth;
+    const double d = 0.5625 * 4.48 / block_interval_s;
+    return d < 24.0 ? 24u : d > 256.0 ? 256u : static_cast<unsigned>(d + 0.5);
+  }
   static constexpr unsigned kFusedBacklog = 6;
+  // Blocks a caller has to keep under way for the measured rate: a block's mean time from begun to record
+  // finished over the mean time between two begins, a quarter more, and two (0 until four blocks have finished).
+  unsigned depthNeeded() const {
+    const uint64_t n = clock.finished.load(), iv = begin_interval_ns_.load();
+    if (n < 4 || iv == 0) return 0;
+    const double latency = static_cast<double>(clock.latency_ns.load()) / static_cast<double>(n);
+    return static_cast<unsigned>(1.25 * latency / static_cast<double>(iv)) + 3u;
+  }
+  double beginIntervalSeconds() const { return begin_interval_ns_.load() * 1e-9; }
+  void noteBegin() {                                 // called once per block, by the thread that feeds the GPU
+    const uint64_t now = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
+        std::chrono::steady_clock::now().time_since_epoch()).count());
+    const uint64_t last = last_begin_ns_.exchange(now);
+    if (last && now > last) {
+      const uint64_t d = now - last, old = begin_interval_ns_.load();
+      begin_interval_ns_.store(old ? (old * 7 + d) / 8 : d);
+    }
+  }
   StageClock clock;
  private:
+  std::atomic<uint64_t> last_begin_ns_{0}, begin_interval_ns_{0};
   enum { kSpares = 40 };
   std::atomic<uint32_t> disposed_{0};
   std::mutex spare_mu_;

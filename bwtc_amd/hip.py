@@ -46,7 +46,7 @@ EXPORTS = [
     "bwtc_hip_wavelet_depth", "bwtc_hip_numa_node", "bwtc_hip_host_cpu_slice", "bwtc_hip_set_worker_cpus", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
-    "bwtc_hip_grammar_create", "bwtc_hip_grammar_destroy", "bwtc_hip_grammar_rules", "bwtc_hip_grammar_special_symbols",
+    "bwtc_hip_wavelet_depth_needed", "bwtc_hip_grammar_create", "bwtc_hip_grammar_destroy", "bwtc_hip_grammar_rules", "bwtc_hip_grammar_special_symbols",
     "bwtc_hip_grammar_is_special", "bwtc_hip_grammar_write", "bwtc_hip_grammar_read", "bwtc_hip_pair_replace_device",
     "bwtc_hip_precompress", "bwtc_hip_host_precompress", "bwtc_hip_postprocess",
 ]
@@ -120,6 +120,8 @@ def load():
     L.bwtc_hip_wavelet_encode_queue.argtypes = [_vp, _u64, _u32, ctypes.POINTER(_u32)]
     L.bwtc_hip_wavelet_depth.restype = ctypes.c_uint32
     L.bwtc_hip_wavelet_depth.argtypes = [_vp]
+    L.bwtc_hip_wavelet_depth_needed.restype = ctypes.c_uint32
+    L.bwtc_hip_wavelet_depth_needed.argtypes = [_vp]
     L.bwtc_hip_wavelet_reset.restype = None
     L.bwtc_hip_wavelet_reset.argtypes = [_vp]
     L.bwtc_hip_wavelet_start.argtypes = [_vp, ctypes.c_char]
@@ -324,6 +326,10 @@ class Context:
         _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
                "bwtc_hip_wavelet_host_clock")
         return m.value, c.value, b.value
+
+    def wavelet_depth_needed(self):
+        """Blocks to keep under way for the rate shown so far (0 until four blocks have finished)."""
+        return int(self.lib.bwtc_hip_wavelet_depth_needed(self.handle))
 
     def wavelet_latency(self):
         """Mean seconds a block has been under way (device half started -> record finished)."""

@@ -320,6 +320,8 @@ class EntropyEncoder {
   virtual void begin(BWTBlock&, BWTManager&) {}
   virtual size_t pending() const { return 0; }
   virtual size_t depth() const { return 1; }
+  // how many blocks the caller should keep under way right now (never more than depth())
+  virtual size_t inFlightLimit() const { return depth(); }
   virtual size_t finishOldest(OutStream*) { return 0; }
 };
 
@@ -380,6 +382,13 @@ class WaveletEncoder : public EntropyEncoder {
     return std::max<size_t>(1, std::min<size_t>(kMaxDepth, lim));
   }
   size_t pending() const { return m_order.size(); }
+  // what the stream has shown to need (bwtc_hip_wavelet_depth_needed: block latency over block interval, with a
+  // margin) once it is known, inside what the context allows: fewer blocks under way hold less page-locked memory
+  size_t inFlightLimit() const {
+    const size_t lim = depth();
+    const size_t need = m_ctx ? bwtc_hip_wavelet_depth_needed(m_ctx) : 0;
+    return need ? std::max<size_t>(4, std::min(lim, need)) : lim;
+  }
   // device half: upload, transform on the device, run scanner + stream kernels; the models and
   // range coders of the block are queued on the context's worker threads.  The block's bytes
   // in host memory are left as they were.
@@ -575,7 +584,7 @@ class Compressor {
       if (m_coder->overlapsBlocks()) {
         // the device half of this block runs while worker threads still code earlier blocks;
         // headers and records reach the stream in block order
-        if (m_coder->pending() >= m_coder->depth()) { compressedSize += writeFinished(sizes.front()); sizes.erase(sizes.begin()); }
+        while (m_coder->pending() >= m_coder->inFlightLimit()) { compressedSize += writeFinished(sizes.front()); sizes.erase(sizes.begin()); }
         m_coder->begin(block, m_bwtmanager);
         sizes.push_back(got);
         continue;

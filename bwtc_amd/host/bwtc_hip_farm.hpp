@@ -98,10 +98,12 @@ class BlockFarm {
       Worker& w = *m_workers[d];
       for (int b = 0; b < 2; ++b) bwtc_hip_free(w.ctx, w.d_in[b]);
       for (int b = 0; b < kStaging; ++b) bwtc_hip_host_free(w.ctx, w.h_in[b]);
+      if (w.d_comp) bwtc_hip_free(w.ctx, w.d_comp);
+      // the context first: destroying it lets blocks still under way finish, and they write their records into the
+      // pending buffers (a worker that gave up early leaves some behind)
+      bwtc_hip_destroy(w.ctx);
       for (size_t i = 0; i < w.outFree.size(); ++i) std::free(w.outFree[i]);
       for (size_t i = 0; i < w.pending.size(); ++i) std::free(w.pending[i].out);
-      if (w.d_comp) bwtc_hip_free(w.ctx, w.d_comp);
-      bwtc_hip_destroy(w.ctx);
     }
   }
 

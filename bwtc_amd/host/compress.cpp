@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
       const char* mv = std::getenv("BWTC_HIP_MODELS");
       const bool host_models = (mv && std::strcmp(mv, "host") == 0) || enc != 'B';
       const bool deep = host_models && block_bytes >= 64e6 && stream_bytes / block_bytes >= 256.0 * n_ctx;
-      pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : gb >= 40.0 ? 20 : 16;
+      pipeline = deep && gb >= 40.0 ? 128 : deep && gb >= 24.0 ? 96 : gb >= 48.0 ? 24 : gb >= 40.0 ? 20 : 16;   // an upper bound: the Compressor keeps what the stream shows to need (bwtc_hip_wavelet_depth_needed)
     }
     if (pipeline > 256) pipeline = 256;
     char buf[16];

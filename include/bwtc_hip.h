@@ -229,6 +229,11 @@ int bwtc_hip_wavelet_encode_queue(bwtc_hip_ctx* ctx, uint64_t ticket, uint32_t s
                                   uint32_t* state_out);
 /* Blocks that may be between _begin and _end at once on this context. */
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
+/* Blocks the caller has to keep between _begin and _end for the rate the stream has shown so far: the mean time
+ * from a block's _begin to its finished record over the mean time between two _begins, a quarter more, plus two.
+ * 0 until four blocks have finished.  A caller that keeps fewer in flight waits in _end; more only hold memory
+ * (1.3 GB of page-locked staging per 256 MiB text block under way). */
+uint32_t bwtc_hip_wavelet_depth_needed(bwtc_hip_ctx* ctx);
 /* Host CPUs for the worker threads of the contexts of one node (one context per GPU):
  * the 'B' coder's host half is memory- and cache-hungry, so a context's workers -- and the
  * page-locked buffers they read, placed by first touch / the caller's policy -- belong on the NUMA
