@@ -1655,9 +1655,10 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   const bool dense = !text && dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
   u32* sa_out = (emit && !fin_active) ? nullptr : d_SA;   // finisher route: the bridge will want the finished suffixes' slots
   u32* rank_arg = text ? nullptr : d_rank;                // text rounds: rank[] is neither complete nor needed
-  // Long items of which at most a quarter is still tied: the finisher settles the rest by direct
-  // comparison (suffix_sort); rank[] is not written at all.
-  res->finish = lng && emit && finisher && (u64)m_next * 4 <= m;
+  // Long items of which at most half is still tied (a 256 MiB text block: 21 %, a 1 GiB one: 37 %): the finisher
+  // settles the rest by direct comparison (suffix_sort); rank[] is not written at all.  Above that the list is
+  // dominated by long repeats and the doubling rounds are the better tool.
+  res->finish = lng && emit && finisher && (u64)m_next * 2 <= m;
   if (res->finish) {
     sa_out = d_SA;
     fin_active = true;
@@ -1890,12 +1891,15 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // their predecessor character's code -- when the fields fit: key bits + 13 + code bits <= 64.
     LongKey lk;
     lk.w = nullptr; lk.G2 = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
-    if (long_keys && gp.G > 0 && split && emit && key_plane && n >= kGramMinN) {
+    // (without the split -- blocks above 512 MiB, keys above 48 bits -- the items carry whole 32-bit suffix numbers:
+    // 16 bytes instead of 14, and the key only needs room for the character)
+    if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= kGramMinN) {
       const int cb = std::max(1, bit_width_u64(plan.sigma - 1));
       int G2 = std::min(32 / gp.b, (64 - gp.g * gp.G) / gp.g);
       G2 = std::min(G2, long_grams_override > 0 ? long_grams_override : 2);
-      if (G2 >= 1 && key_bits + 13 + cb <= 64) {
-        lk.w = d_W0; lk.G2 = G2; lk.hi_shift = key_bits; lk.chr_shift = key_bits + 13; lk.chr_mask = (1u << cb) - 1u;
+      const int hi_bits = split ? 13 : 0;
+      if (G2 >= 1 && key_bits + hi_bits + cb <= 64) {
+        lk.w = d_W0; lk.G2 = G2; lk.hi_shift = key_bits; lk.chr_shift = key_bits + hi_bits; lk.chr_mask = (1u << cb) - 1u;
         u8 inv[256];
         std::memset(inv, 0, sizeof inv);
         for (int c = 255; c >= 0; --c) if (hist[c] && !(c == 0 && lone_sentinel)) inv[plan.lut[c]] = (u8)c;
@@ -1908,16 +1912,19 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       short_len = (u32)(gp.g * (gp.G + lk.G2));
       h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, 1, lk);
+                         (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split, lk);
       u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
-      if (long_items_per_thread == 6)
+      u32* vs32 = nullptr;
+      if (!split)
+        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1);
+      else if (long_items_per_thread == 6)
         radix_sort_long<unsigned short, 6>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
                                            d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
       else
         radix_sort_long<unsigned short, 8>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
                                            d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
       BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-      u32* vs = reinterpret_cast<u32*>(vs16);
+      u32* vs = split ? reinterpret_cast<u32*>(vs16) : vs32;
       rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
       rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
       RrLong lg;
@@ -1926,11 +1933,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       if (std::getenv("BWTC_HIP_DEBUG"))
         std::fprintf(stderr, "long keys: %d + %d bits, %d + %d grams of %d characters, character code at bit %d\n",
                      key_bits, w_bits, gp.G, lk.G2, gp.g, lk.chr_shift);
-      rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, 1u, &lg);
+      rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, (u32)split, &lg);
       if (rc) return rc;
       stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits);
-      stats.alg_bytes += (u64)n * (1 + 14 + 1)               // k_make_keys_gram: T read, key + second word + first plane written (the values are made up by the first pass)
-                         + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits, 14, 8, true);
+      stats.alg_bytes += (u64)n * (1 + 12 + 1)               // k_make_keys_gram: T read, key + second word + first plane written (the values are made up by the first pass)
+                         + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits, split ? 14 : 16, 8, true);
       stats.route |= 1u;
       key_bits = 0;                                      // counted
     } else if (gp.G > 0) {
