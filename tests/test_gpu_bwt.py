@@ -278,6 +278,21 @@ def test_baseline_1GiB_single_block_round_trip():
     assert back.size == size and (back == d).all()
 
 
+def test_baseline_1GiB_single_text_block_round_trip():
+    """Config 5 with the C3 generator's text (seed 5): the long-key route with 16-byte items (no split index above
+    512 MiB), the finisher over 37 % of the block, text rounds for its oversize groups -- forward and inverse on
+    the GPU, the inverse verifying every LF power (which this route notes as suffixes become final)."""
+    from bwtc_amd import hip
+    size = 1 << 30
+    with hip.Context(0, size) as ctx:
+        d = hip.synth_into("t", 5, np.empty(size, np.uint8))
+        bwt, lf, freqs = ctx.bwt_block(d, 8)
+        assert ctx.stats().route & 3 == 3
+        assert (freqs == np.bincount(d, minlength=256)).all()
+        back = ctx.inverse_bwt_block(bwt, lf)
+    assert back.size == size and (back == d).all()
+
+
 @pytest.mark.skipif(os.environ.get("BWTC_TEST_1GIB") != "1", reason="set BWTC_TEST_1GIB=1 (takes minutes)")
 def test_baseline_1GiB_single_block(oracle):
     """BASELINE.json config 5: one 1 GiB block, 32-bit indices, N = 2^30 + 1."""
@@ -320,19 +335,29 @@ def test_chained_sort_variant(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["BWTC_HIP_GRAMS=0", "BWTC_HIP_GRAMS=4", "BWTC_HIP_SPLIT_INDEX=0", "BWTC_HIP_PLANES=0",
-                                    "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12", "BWTC_HIP_SCAN=chained"])
+                                    "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12", "BWTC_HIP_SCAN=chained",
+                                    # round 4: the long-key route's pieces, each switched off or cut short so that the
+                                    # next piece (text rounds, late rank completion + doubling rounds) takes over
+                                    "BWTC_HIP_LONG=0", "BWTC_HIP_FINISHER=0", "BWTC_HIP_FIN_PASSES=0", "BWTC_HIP_FIN_PASSES=1",
+                                    "BWTC_HIP_TEXT_ROUNDS=0", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_LONG_E=6", "BWTC_HIP_LONG_G2=1",
+                                    "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
     from bwtc_amd import hip
-    name, value = switch.split("=")
-    monkeypatch.setenv(name, value)
+    for one in switch.split(","):
+        name, value = one.split("=")
+        monkeypatch.setenv(name, value)
     size = 6 << 20
     text = synth.gen_text(size, 21)
     zeros = text.copy()
     zeros[zeros == 101] = 0
+    # text with repeats of every length up to 200 KB (deep ties behind the long keys: hard groups, text rounds, the bridge)
+    rep = text.copy()
+    rep[3 << 20:(3 << 20) + 200000] = rep[:200000]
+    rep[5 << 20:(5 << 20) + 3000] = rep[1000:4000]
     with hip.Context(0, size) as ctx:
-        for d in (text, zeros):
+        for d in (text, zeros, rep):
             a = ctx.bwt_block(d, 7)
             b = oracle.oracle_bwt_block(d, 7)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), switch
