@@ -653,7 +653,7 @@ struct RrEmit {
 __device__ __forceinline__ void lf_note(const RrEmit& em, u32 n, u32 s, u32 slot) {
   if (em.lf_n <= 1u) return;
   const u32 t = n - s;                                  // 1 .. n
-  u32 q = __umulhi(t, em.lf_inv);                       // floor(t / x) or one less
+  u32 q = em.lf_x > 1u ? __umulhi(t, em.lf_inv) : t;    // floor(t / x) or one less (x = 1: a block of a few hundred bytes with 256 powers)
   u32 r = t - q * em.lf_x;
   if (r == em.lf_x) { r = 0u; ++q; }
   if (r == 0u && q >= 1u && q < em.lf_n) em.lf[q] = slot;
@@ -1349,6 +1349,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
+    gram_min_n = kGramMinN;
+    if (std::getenv("BWTC_HIP_GRAM_MIN_N")) gram_min_n = (u32)std::max(64, std::atoi(std::getenv("BWTC_HIP_GRAM_MIN_N")));   // tests: small blocks through the gram / long-key routes
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS")));
@@ -1526,7 +1528,7 @@ static void best_packing(u32 sigma, int maxbits, int* k_out, int* bits_out) {
 // stays at 4 symbols): a suffix whose key window reaches the terminator has length <= k,
 // and all of those are split off as singletons in true order by the "shorter first" rule
 // of the initial ranking, so the merged code is never compared.
-static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
+static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel, bool force_wide = false) {
   KeyPlan p;
   int sigma = 0;
   double total = 0.0, h0 = 0.0;
@@ -1542,7 +1544,7 @@ static KeyPlan plan_keys(const u32 hist[256], u32 n, bool lone_sentinel) {
   best_packing(p.sigma, 32, &k32, &b32);
   best_packing(p.sigma, 64, &k64, &b64);
   const double need = std::log2((double)n + 1.0) + 2.0;
-  p.wide = (k64 > k32) && (k32 * h0 < need);
+  p.wide = (k64 > k32) && (force_wide || k32 * h0 < need);
   p.k = p.wide ? k64 : k32;
   p.bits = p.wide ? b64 : b32;
   return p;
@@ -1777,7 +1779,7 @@ static constexpr int kSmallFin = 528;     // finisher: entries of the next list,
 int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp) {
   hipStream_t st = stream;
   gp->G = 0;
-  if (!gram_keys || n < kGramMinN) return 0;
+  if (!gram_keys || n < gram_min_n) return 0;
   int g = 1;
   u64 U = plan.sigma;
   while (U * plan.sigma <= kGramMaxU && U * plan.sigma <= (u64)cap / 2 && g < 32) { U *= plan.sigma; ++g; }
@@ -1830,7 +1832,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   if (n == 0) return 0;
 
   const bool emit = em != nullptr;
-  const KeyPlan plan = plan_keys(hist, n, lone_sentinel);
+  const KeyPlan plan = plan_keys(hist, n, lone_sentinel, gram_min_n < kGramMinN);   // (the tests' small blocks: 64-bit keys whatever the entropy says)
   std::memcpy(h_small + kSmallLut, plan.lut, 256);
   BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallLut, h_small + kSmallLut, 256, hipMemcpyHostToDevice, st));
   const u8* d_lut = reinterpret_cast<const u8*>(d_small + kSmallLut);
@@ -1850,8 +1852,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   re.rec_shift = 0;
   re.inv_lut = reinterpret_cast<const u8*>(d_small + kSmallInv);
   re.lf = d_small + kSmallLf; re.lf_n = 0; re.lf_x = 0; re.lf_inv = 0;
-  if (emit && em->n_lf > 1 && n / em->n_lf > 1) {
-    re.lf_n = em->n_lf; re.lf_x = n / em->n_lf; re.lf_inv = (u32)((1ull << 32) / re.lf_x);
+  if (emit && em->n_lf > 1 && n / em->n_lf >= 1) {
+    re.lf_n = em->n_lf; re.lf_x = n / em->n_lf; re.lf_inv = re.lf_x > 1 ? (u32)((1ull << 32) / re.lf_x) : 0u;
   }
   bridged = false;
   lf_noted = false;
@@ -1893,7 +1895,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     lk.w = nullptr; lk.G2 = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
     // (without the split -- blocks above 512 MiB, keys above 48 bits -- the items carry whole 32-bit suffix numbers:
     // 16 bytes instead of 14, and the key only needs room for the character)
-    if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= kGramMinN) {
+    if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= gram_min_n) {
       const int cb = std::max(1, bit_width_u64(plan.sigma - 1));
       int G2 = std::min(32 / gp.b, (64 - gp.g * gp.G) / gp.g);
       G2 = std::min(G2, long_grams_override > 0 ? long_grams_override : 2);

@@ -7,7 +7,9 @@ sweeps are the fixed-seed subset of this).  Three phases, each against the oracl
   3. the transform itself on repetitive / periodic / small-alphabet inputs;
   4. the GPU inverse transform of the product's own transform (gives the input back);
   5. `compress` -> `uncompress` round trips of the command-line tools (host decoders + GPU inverse),
-     both coders, and the 'B' / 'H' stream against the oracle's whole-stream encoder.
+     both coders, and the 'B' / 'H' stream against the oracle's whole-stream encoder;
+  6. (round 4) the long-key route -- long keys, finisher, text rounds, late rank completion, each cut short in turn -- on
+     small blocks of every shape, and `--prepr` through the device sweeps.
 usage: fuzz_gpu_parity.py [seconds per phase] [seed] [phases, e.g. 23]      exit code 1 if anything differed.
 FUZZ_BIG=1: phase 2 with streams of 32-96 MB in blocks of 9-33 MB (the page-locked buffers of such blocks are
 registered mappings, recycled across sizes)."""
@@ -39,7 +41,7 @@ def packed(v):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-    phases = sys.argv[3] if len(sys.argv) > 3 else "12345"
+    phases = sys.argv[3] if len(sys.argv) > 3 else "123456"
     oracle_lib.build()
     rng = np.random.default_rng(seed)
     big = os.environ.get("FUZZ_BIG") == "1"
@@ -157,6 +159,72 @@ def main():
                 print("MISMATCH phase 5: kind", kind, "size", n, "coder", enc, (r.stderr or "")[-300:], flush=True)
             n5 += 1
     print("phase 5: %d round trips" % n5, flush=True)
+
+    # ---- 6: the long-key route on small blocks of every shape (round 4) -----------------------------
+    # BWTC_HIP_GRAM_MIN_N lets blocks of a few thousand bytes take long keys, finisher, text rounds and the late
+    # rank completion; every few blocks a new context with one of the route's pieces cut short.  Also `--prepr`
+    # through the device sweeps.
+    t0, n6 = time.time(), 0
+    variants = [{}, {"BWTC_HIP_FIN_PASSES": "1"}, {"BWTC_HIP_TEXT_ROUNDS": "1"}, {"BWTC_HIP_FIN_PASSES": "0", "BWTC_HIP_TEXT_ROUNDS": "0"},
+                {"BWTC_HIP_LONG_G2": "1"}, {"BWTC_HIP_FINISHER": "0"}, {"BWTC_HIP_TEXT_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "2"}]
+    while "6" in phases and time.time() - t0 < budget:
+        var = variants[n6 % len(variants)]
+        os.environ["BWTC_HIP_GRAM_MIN_N"] = "64"
+        for k in ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER"):
+            os.environ.pop(k, None)
+        os.environ.update(var)
+        with hip.Context(device=0, max_block_size=(4 << 20) + 64) as c6:
+            for _ in range(12):
+                n = int(rng.integers(200, int(rng.choice([3000, 60000, 900000, 4000000]))))
+                sigma = int(rng.integers(5, 70))
+                alphabet = rng.choice(np.arange(0 if rng.random() < 0.3 else 1, 256), sigma, replace=False).astype(np.uint8)
+                words = [alphabet[rng.integers(0, sigma, int(rng.integers(1, 12)))] for _ in range(int(rng.integers(2, 300)))]
+                d = np.concatenate([words[int(i)] for i in rng.integers(0, len(words), n // 2 + 8)])[:n].copy()
+                n = d.size
+                for _ in range(int(rng.integers(0, 12))):
+                    what = int(rng.integers(0, 4))
+                    if what == 0:                              # a planted repeat
+                        ln = int(min(n // 3, rng.integers(1, 1 + int(rng.choice([30, 1500, 200000])))))
+                        a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+                        d[b:b + ln] = d[a:a + ln].copy()
+                    elif what == 1:                            # a periodic stretch
+                        per = d[:int(rng.integers(1, 40))].copy()
+                        a = int(rng.integers(0, n - 1))
+                        ln = int(min(n - a, rng.integers(1, 1 + n // 2)))
+                        d[a:a + ln] = np.tile(per, ln // per.size + 1)[:ln]
+                    elif what == 2:                            # a run
+                        a = int(rng.integers(0, n - 1))
+                        d[a:a + int(rng.integers(1, 9000))] = alphabet[int(rng.integers(0, sigma))]
+                    else:                                      # the block ends in its own beginning
+                        ln = int(rng.integers(1, n // 2 + 1))
+                        d[n - ln:] = d[:ln].copy()
+                sp = int(rng.choice([1, 3, 8, 256]))
+                try:
+                    a = c6.bwt_block(d, sp)
+                except hip.BwtcHipError as ex:
+                    bad += 1
+                    print("ERROR phase 6:", ex, "variant", var, "size", n, "sigma", sigma, "sp", sp, flush=True)
+                    np.save(os.path.join(ROOT, "gpurun_out", "fuzz6_error_%d.npy" % n6), d)
+                    n6 += 1
+                    continue
+                b = oracle_lib.oracle_bwt_block(d, sp)
+                if not ((a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()):
+                    bad += 1
+                    print("MISMATCH phase 6: variant", var, "size", n, "sigma", sigma, "sp", sp, "route", c6.stats().route, flush=True)
+                    np.save(os.path.join(ROOT, "gpurun_out", "fuzz6_fail_%d.npy" % n6), d)
+                if n < 600000:
+                    opts = "p" * int(rng.integers(1, 5))
+                    g, og = hip.Grammar(), oracle_lib.OracleGrammar()
+                    mine = c6.precompress(g, opts, d)
+                    want = oracle_lib.oracle_precompress(og, opts, d)
+                    if mine.tobytes() != want.tobytes() or g.write().tobytes() != og.write().tobytes():
+                        bad += 1
+                        print("MISMATCH phase 6 prepr: size", n, "sigma", sigma, "options", opts, flush=True)
+                        np.save(os.path.join(ROOT, "gpurun_out", "fuzz6_prepr_fail_%d.npy" % n6), d)
+                n6 += 1
+    for k in ("BWTC_HIP_GRAM_MIN_N", "BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER"):
+        os.environ.pop(k, None)
+    print("phase 6: %d blocks on the long-key route (and through the pre-stage)" % n6, flush=True)
     print("mismatches:", bad, flush=True)
     return 1 if bad else 0
 

@@ -406,3 +406,51 @@ def test_device_pointers_unaligned_and_aliased(hip_ctx, oracle):
     finally:
         hip_ctx.dfree(buf)
         hip_ctx.dfree(out)
+
+
+@pytest.mark.parametrize("extra", ["", "BWTC_HIP_FIN_PASSES=1", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0"])
+def test_long_key_route_on_small_structured_blocks(oracle, monkeypatch, extra):
+    """The long-key route (long keys, ranking at the long key's depth, finisher, text rounds, late rank completion)
+    on blocks small enough for the oracle but of every shape: BWTC_HIP_GRAM_MIN_N lets blocks of a few thousand bytes
+    take it.  Texts over 20-60 symbols with planted repeats of every length, periodic stretches (groups far above the
+    finisher's 1024 members), runs, zero bytes, blocks that end in their own prefix."""
+    from bwtc_amd import hip
+    monkeypatch.setenv("BWTC_HIP_GRAM_MIN_N", "64")
+    for one in extra.split(","):
+        if one:
+            name, value = one.split("=")
+            monkeypatch.setenv(name, value)
+    rng = np.random.default_rng(1234 + len(extra))
+    taken = 0
+    with hip.Context(0, 1 << 20) as ctx:
+        for it in range(120):
+            n = int(rng.integers(300, 400000))
+            sigma = int(rng.integers(18, 64))
+            alphabet = rng.choice(np.arange(1 if it % 3 else 0, 256), sigma, replace=False).astype(np.uint8)
+            words = [alphabet[rng.integers(0, sigma, int(rng.integers(1, 9)))] for _ in range(int(rng.integers(5, 200)))]
+            d = np.concatenate([words[int(i)] for i in rng.integers(0, len(words), n // 3 + 8)])[:n].copy()
+            n = d.size
+            shape = it % 6
+            if shape == 1:                                    # planted repeats of many lengths
+                for _ in range(int(rng.integers(1, 30))):
+                    ln = int(min(n // 3, rng.integers(1, 1 + int(rng.choice([40, 2000, 100000])))))
+                    a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
+                    d[b:b + ln] = d[a:a + ln].copy()
+            elif shape == 2:                                  # a periodic stretch: one group of thousands of members
+                p = d[:int(rng.integers(1, 30))].copy()
+                a = int(rng.integers(0, n // 2))
+                ln = int(rng.integers(2000, max(2001, n // 2)))
+                d[a:a + ln] = np.tile(p, ln // p.size + 1)[:min(ln, n - a)]
+            elif shape == 3:                                  # long runs of one symbol
+                for _ in range(int(rng.integers(1, 8))):
+                    a = int(rng.integers(0, n - 1))
+                    d[a:a + int(rng.integers(1, 6000))] = alphabet[0]
+            elif shape == 4:                                  # the block ends in its own beginning
+                ln = int(rng.integers(1, n // 2))
+                d[n - ln:] = d[:ln].copy()
+            sp = int(rng.choice([1, 2, 8, 256]))
+            a = ctx.bwt_block(d, sp)
+            taken += 1 if ctx.stats().route & 1 else 0
+            b = oracle.oracle_bwt_block(d, sp)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (extra, it, shape, n, sigma, sp)
+    assert taken > 60, taken                                  # the route under test was the route taken
