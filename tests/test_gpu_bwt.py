@@ -334,6 +334,9 @@ def test_chained_sort_variant(oracle, monkeypatch):
         assert rc == 0 and (inv == d).all()
 
 
+_SWITCH_INPUTS = []
+
+
 @pytest.mark.parametrize("switch", ["BWTC_HIP_GRAMS=0", "BWTC_HIP_GRAMS=4", "BWTC_HIP_SPLIT_INDEX=0", "BWTC_HIP_PLANES=0",
                                     "BWTC_HIP_DENSE=0", "BWTC_HIP_NO_EMIT=1", "BWTC_HIP_WINDOW_BITS=12", "BWTC_HIP_SCAN=chained",
                                     # round 4: the long-key route's pieces, each switched off or cut short so that the
@@ -349,17 +352,19 @@ def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
         name, value = one.split("=")
         monkeypatch.setenv(name, value)
     size = 6 << 20
-    text = synth.gen_text(size, 21)
-    zeros = text.copy()
-    zeros[zeros == 101] = 0
-    # text with repeats of every length up to 200 KB (deep ties behind the long keys: hard groups, text rounds, the bridge)
-    rep = text.copy()
-    rep[3 << 20:(3 << 20) + 200000] = rep[:200000]
-    rep[5 << 20:(5 << 20) + 3000] = rep[1000:4000]
-    with hip.Context(0, size) as ctx:
+    if not _SWITCH_INPUTS:                                    # the inputs and the reference's answers, once for all switches
+        text = synth.gen_text(size, 21)
+        zeros = text.copy()
+        zeros[zeros == 101] = 0
+        # text with repeats of every length up to 200 KB (deep ties behind the long keys: hard groups, text rounds, the bridge)
+        rep = text.copy()
+        rep[3 << 20:(3 << 20) + 200000] = rep[:200000]
+        rep[5 << 20:(5 << 20) + 3000] = rep[1000:4000]
         for d in (text, zeros, rep):
+            _SWITCH_INPUTS.append((d, oracle.oracle_bwt_block(d, 7)))
+    with hip.Context(0, size) as ctx:
+        for d, b in _SWITCH_INPUTS:
             a = ctx.bwt_block(d, 7)
-            b = oracle.oracle_bwt_block(d, 7)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), switch
 
 
