@@ -58,6 +58,27 @@ __device__ __forceinline__ u32 long_digit(K k, u32 w, int shift, u32 dmask) {
   return radix_digit(k, shift);
 }
 
+// Segmented sorts (the wavelet coder's step sort): the items are a row of segments, each a whole number
+// of tiles, and every segment is sorted on its own -- its items never leave it.  A pass is the same three
+// steps; only the table is laid out segment by segment (bin-major inside a segment), so that the one
+// exclusive scan over it yields every segment's bases.  A segment's padding carries the all-ones key: the
+// last digit in every pass, so it stays at the segment's end.
+//   tile_first[nseg + 1]  first tile of every segment (tile_first[nseg] = ntiles; empty segments allowed)
+struct SegArgs {
+  const u32* tile_first = nullptr;
+  u32 nseg = 0;
+};
+struct SegTile { u32 seg, first, count; };       // the tile's segment, the segment's first tile and number of tiles
+__device__ __forceinline__ SegTile seg_of_tile(const SegArgs& sa, u32 tile) {
+  u32 lo = 0, hi = sa.nseg;                       // the last segment that starts at or before the tile
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (sa.tile_first[mid] <= tile) lo = mid; else hi = mid; }
+  const u32 f = sa.tile_first[lo];
+  return SegTile{lo, f, sa.tile_first[lo + 1] - f};
+}
+__device__ __forceinline__ u64 seg_table_at(const SegTile& st, u32 bin, u32 tile) {
+  return (u64)kRadixBins * st.first + (u64)bin * st.count + (tile - st.first);
+}
+
 // skip: items whose key is all ones do not exist (first pass of a sort whose input was written
 // with holes, see k_gather_dense): they are neither counted nor moved, so the pass compacts.
 template <typename K, bool SKIP>
@@ -101,11 +122,13 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 // V: the values' type in memory, u32 or u16 (the suffix sorter's initial sort keeps the upper bits
 // of a suffix number in spare bits of its key, so that a pass moves 10 bytes per item instead of 12).
 // LONG (see LongArgs): 0 plain items; 1 long items, digit from the key; 2 long items, digit from w.
-template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32, int LONG = 0, int E_ = RadixCfg<K>::E>
+// SEG (see SegArgs): a segmented pass (32-bit keys only, no long items).
+template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32, int LONG = 0, int E_ = RadixCfg<K>::E, bool SEG = false>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     const K* __restrict__ kin, const V* __restrict__ vin, K* __restrict__ kout,
     V* __restrict__ vout, const u32* __restrict__ table, u64 n, int shift, u32 ntiles, int values_mode,
-    u8* __restrict__ plane, LongArgs la) {
+    u8* __restrict__ plane, LongArgs la, SegArgs sa) {
+  static_assert(!SEG || (sizeof(K) == 4 && LONG == 0 && !SKIP), "segmented passes sort plain 32-bit keys");
   constexpr int E = E_;
   constexpr int TILE = kRadixTPB * E;
   // LDS: the per-wave digit counters are dead once every thread has turned them into its
@@ -133,6 +156,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   const u64 tile_base = (u64)tile * TILE;
   const u64 left = n - tile_base;
   const u32 tile_n = left < (u64)TILE ? (u32)left : (u32)TILE;
+  SegTile sg = {0, 0, 0};
+  if (SEG) sg = seg_of_tile(sa, tile);
 
   for (u32 i = tid; i < kRadixWaves * kRadixBins; i += kRadixTPB) (&s_cnt[0][0])[i] = 0;
 
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   u32 dig_base = block_scan_excl_add<kRadixTPB>(tid < kRadixBins ? dig_total : 0u, s_scr, &tile_valid);
   if (tid < kRadixBins) {
     s_base[tid] = dig_base;
-    s_gofs[tid] = table[(u64)tid * ntiles + tile] - dig_base;
+    s_gofs[tid] = table[SEG ? seg_table_at(sg, tid, tile) : (u64)tid * ntiles + tile] - dig_base;
   }
   __syncthreads();
 
@@ -274,10 +299,10 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 // A workgroup takes TWO tiles, half its threads each: the kernel is a chain of latencies (clear
 // LDS, load, count, add up the copies, store) with little to do in between, so twice the bytes per
 // workgroup is close to twice the speed.
-template <typename K, int E_ = RadixCfg<K>::E>
+template <typename K, int E_ = RadixCfg<K>::E, bool SEG = false>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __restrict__ plane,
                                                                 u32* __restrict__ table, u64 n,
-                                                                u32 ntiles) {
+                                                                u32 ntiles, SegArgs sa) {
   constexpr int E = E_;
   constexpr int HALF = kRadixTPB / 2;
   constexpr int B = 2 * E;                          // bytes of the tile per thread (8, 12, 16 or 32)
@@ -321,12 +346,14 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
   }
   __syncthreads();
   if (tile < ntiles) {
+    SegTile sg = {0, 0, 0};
+    if (SEG) sg = seg_of_tile(sa, tile);
     for (u32 bin = t; bin < (u32)kRadixBins; bin += HALF) {
       const uint4* r4 = reinterpret_cast<const uint4*>(&hist[half][bin * 16u]);
       u32 c = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const uint4 v = r4[r]; c += v.x + v.y + v.z + v.w; }
-      table[(u64)bin * ntiles + tile] = c;
+      table[SEG ? seg_table_at(sg, bin, tile) : (u64)bin * ntiles + tile] = c;
     }
   }
 }
@@ -400,12 +427,12 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
       const bool have_plane = plane0 && (!first || (plane0_ready && !skip));   // the previous pass (or the producer) left this pass's digits
       const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's
-      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles);
+      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles, SegArgs());
       else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr, LongArgs())
+#define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr, LongArgs(), SegArgs())
       if (keys_only) { if (make_plane) BWTC_SCATTER(false, true, true); else BWTC_SCATTER(false, false, true); }   // never with holes
       else if (skip) { if (make_plane) BWTC_SCATTER(true, true, false); else BWTC_SCATTER(true, false, false); }
       else { if (make_plane) BWTC_SCATTER(false, true, false); else BWTC_SCATTER(false, false, false); }
@@ -420,6 +447,26 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
   }
   *k_sorted = kin;
   *v_sorted = vin;
+}
+
+// Segmented sort of 32-bit keys (see SegArgs) by bits [bit_lo, bit_lo + 16): two passes, stable; n = whole
+// tiles.  The producer of the keys left the first pass's digits in plane0; after the two passes the keys are in k0 again.
+static inline void radix_sort_keys_segmented(u32* k0, u32* k1, u64 n, int bit_lo, const u32* tile_first, u32 nseg,
+                                             u32* table, u32* partial, hipStream_t st, u32** k_sorted,
+                                             u8* plane0, u8* plane1) {
+  constexpr int E = RadixCfg<u32>::E;
+  const u32 ntiles = (u32)(n / radix_tile<u32>());
+  const dim3 sgrid(((ntiles + 7u) / 8u) * 8u), hgrid((ntiles + 1u) / 2u), tpb(kRadixTPB);
+  SegArgs sa; sa.tile_first = tile_first; sa.nseg = nseg;
+  hipLaunchKernelGGL((k_radix_hist_plane<u32, E, true>), hgrid, tpb, 0, st, (const u8*)plane0, table, n, ntiles, sa);
+  exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
+  hipLaunchKernelGGL((k_radix_scatter<u32, false, true, true, u32, 0, E, true>), sgrid, tpb, 0, st, (const u32*)k0, (const u32*)nullptr, k1,
+                     (u32*)nullptr, (const u32*)table, n, bit_lo, ntiles, 2, plane1, LongArgs(), sa);
+  hipLaunchKernelGGL((k_radix_hist_plane<u32, E, true>), hgrid, tpb, 0, st, (const u8*)plane1, table, n, ntiles, sa);
+  exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
+  hipLaunchKernelGGL((k_radix_scatter<u32, false, false, true, u32, 0, E, true>), sgrid, tpb, 0, st, (const u32*)k1, (const u32*)nullptr, k0,
+                     (u32*)nullptr, (const u32*)table, n, bit_lo + kRadixBits, ntiles, 2, (u8*)nullptr, LongArgs(), sa);
+  *k_sorted = k0;
 }
 
 // Long-key sort of the suffix sorter: items (u64 key, V value, u32 w) ordered by (key bits [0, kbits),
@@ -444,7 +491,7 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
     const u32 ntiles = ceil_div(n, (u64)kRadixTPB * EL);
     const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
     for (int p = 0; p < np; ++p) {
-      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles);
+      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles, SegArgs());
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool last = p + 1 == np;
       LongArgs la;
@@ -452,7 +499,7 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
       la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
       const int vmode = p == 0 ? 3 : 0;
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la)
+#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la, SegArgs())
       if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
       else { if (last) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
 #undef BWTC_SCATTER_L

@@ -926,6 +926,7 @@ bool planStreams(const std::vector<SectionRuns>& sections, StreamPlan* plan) {
     StreamPlan::Section& sec = plan->sections[s];
     sec.group_base = static_cast<uint32_t>(plan->group_type.size());
     sec.n_nodes = in.n_nodes;
+    sec.n_leaves = in.n_leaves;
     sec.prefix.swap(in.prefix);
     sec.level_first.swap(in.level_first);
     plan->over_first[s] = static_cast<uint32_t>(plan->over.size() / 4);

@@ -70,6 +70,7 @@ struct StreamPlan {
     std::vector<uint8_t> prefix;           // packed bitsInRoot + tree shape
     uint32_t group_base;                   // first group of the section
     uint32_t n_nodes;                      // symbol-tree nodes that are coded (groups 0..n_nodes-1)
+    uint32_t n_leaves;                     // symbol leaves (the leaf ranks of the integer steps are below this)
     std::vector<uint32_t> level_first;     // integer levels: first group of each level, then the end
   };
   std::vector<Section> sections;

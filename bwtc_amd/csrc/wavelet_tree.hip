@@ -139,8 +139,10 @@ constexpr u32 kWtExpandRuns = kWtTPB * kWtExpandR;
 __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ run_start,
                                                       const u8* __restrict__ run_sym, u32 n_runs,
                                                       WtTables t, const u32* __restrict__ off,
-                                                      u32* __restrict__ key, u8* __restrict__ plane) {
+                                                      u32* __restrict__ key, u8* __restrict__ plane,
+                                                      const uint4* __restrict__ segtab) {
   __shared__ u32 s_off[kWtExpandRuns + 1];
+  __shared__ u8 s_sec[kWtExpandRuns];         // segmented layout (k_wt_segments): the run's section
   __shared__ u32 s_sym[kWtExpandRuns];        // pool offset of the run's symbol steps
   __shared__ u32 s_len[kWtExpandRuns];        // pool offset of its length steps
   __shared__ u32 s_meta[kWtExpandRuns];       // symbol steps | common prefix << 8 | leaf rank << 16
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
       if (sy[q].y >> 16) len_off = len[q] < kWtLenDense ? led[q].x : wt_length_entry(t, sec[q], len[q]).x;
       s_sym[x] = sy[q].x;
       s_len[x] = len_off;
+      s_sec[x] = (u8)sec[q];
       s_meta[x] = (sy[q].y & 255u) | (min(common, 64u) << 8) | (((sy[q].y >> 8) & 255u) << 16);
     }
   }
@@ -216,10 +219,11 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
   constexpr int kU = 4;
   for (u32 jb = o0 + threadIdx.x; jb < o1; jb += kWtTPB * kU) {
     u32 addr[kU], extra[kU], w[kU];
+    uint4 sg[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const u32 j = jb + (u32)u * kWtTPB;
-      addr[u] = 0; extra[u] = 0;
+      addr[u] = 0; extra[u] = 0; sg[u] = make_uint4(0, 0, 0, 0);
       if (j < o1) {
         u32 lo;
         if (owned) lo = s_owner[j - o0];
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
         const bool sym = i < ns;
         addr[u] = (sym ? s_sym[lo] : s_len[lo] - ns) + i;
         extra[u] = sym ? (i > ((meta >> 8) & 255u) ? 1u : 0u) << kStepGapShift : (meta >> 16) << kStepLeafShift;
+        if (segtab) sg[u] = segtab[s_sec[lo]];
       }
     }
 #pragma unroll
@@ -241,9 +246,51 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_expand(const u32* __restrict__ ru
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const u32 j = jb + (u32)u * kWtTPB;
-      if (j < o1) { key[j] = w[u]; plane[j] = (u8)(w[u] >> kStepLeafShift); }
+      if (j < o1) {
+        u32 word = w[u];
+        if (segtab) {
+          // the section's own dense id instead of (block-wide group, leaf rank): one per symbol-tree node, then
+          // one per (integer node, symbol leaf)
+          const u32 g = (word >> kStepGroupShift) - sg[u].y;
+          const u32 id = g < sg[u].z ? g : sg[u].z + (g - sg[u].z) * sg[u].w + ((word >> kStepLeafShift) & 255u);
+          word = (id << kStepLeafShift) | (word & 3u);
+        }
+        key[j + sg[u].x] = word; plane[j + sg[u].x] = (u8)(word >> kStepLeafShift);
+      }
     }
   }
+}
+
+// Segmented layout of the steps (radix_sort.hpp, SegArgs): a section's steps only ever meet steps of the same
+// section in sorted order (its groups are its own), so every section is a segment, padded to whole sort tiles, and
+// the sort needs the digits that order ONE section's groups: two passes (leaf rank, group within the section)
+// instead of three over the block-wide group number.
+//   pstart[s]      where section s starts in the padded row (a multiple of the tile), pstart[nsec] = padded total
+//   tile_first[s]  the same in tiles
+//   segtab[s]      {pstart[s] - (steps before the section), first group, symbol-tree groups, symbol leaves}: the
+//                  first is filled in here, the others come from the host; a step's key is its section's dense id
+//                  (k_wt_expand), at most 65 536 per section
+//   totals[0] = steps, totals[1] = padded total
+__global__ void k_wt_segments(const u32* __restrict__ first_run, u32 nsec, const u32* __restrict__ off, u32 tile,
+                              u32* __restrict__ pstart, u32* __restrict__ tile_first, uint4* __restrict__ segtab,
+                              u32* __restrict__ totals) {
+  if (blockIdx.x || threadIdx.x) return;
+  u32 at = 0;
+  for (u32 s = 0; s < nsec; ++s) {
+    const u32 b = off[first_run[s]], e = off[first_run[s + 1]];
+    pstart[s] = at; tile_first[s] = at / tile; segtab[s].x = at - b;
+    at += (e - b + tile - 1u) / tile * tile;
+  }
+  pstart[nsec] = at; tile_first[nsec] = at / tile;
+  totals[0] = off[first_run[nsec]]; totals[1] = at;
+}
+// the padding behind every section's steps: the all-ones key (and its digit in the first plane)
+__global__ __launch_bounds__(kWtTPB) void k_wt_pad_fill(const u32* __restrict__ first_run, const u32* __restrict__ off,
+                                                        const u32* __restrict__ pstart, u32* __restrict__ key,
+                                                        u8* __restrict__ plane) {
+  const u32 s = blockIdx.x;
+  const u32 b = pstart[s] + (off[first_run[s + 1]] - off[first_run[s]]), e = pstart[s + 1];
+  for (u32 j = b + threadIdx.x; j < e; j += kWtTPB) { key[j] = 0xFFFFFFFFu; plane[j] = 0xFF; }
 }
 
 constexpr u8 kWtSkip = 0xFF;
@@ -255,14 +302,34 @@ __device__ __forceinline__ u32 wt_group_of(u32 k, const u32* __restrict__ id_gro
   return DENSE ? id_group[k >> kStepLeafShift] : (k >> kStepGroupShift) & kStepGroupMask;
 }
 
-template <bool DENSE>
+// SEG: the segmented layout -- the tile lies in one section, whose table entry turns a dense id back into the group
+template <bool DENSE, bool SEG>
 __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ key, u32 n,
                                                       const u8* __restrict__ group_type, const u32* __restrict__ id_group,
                                                       u8* __restrict__ code,
                                                       u32* __restrict__ tile_count,
-                                                      u32* __restrict__ group_start) {
+                                                      u32* __restrict__ group_start,
+                                                      const u32* __restrict__ seg_tile_first, u32 nseg,
+                                                      const uint4* __restrict__ segtab, const u32* __restrict__ seg_magic) {
   __shared__ u32 scratch[kWtTPB / kWave + 1];
   const u32 base = blockIdx.x * kWtTile;
+  u32 sg_base = 0, sg_nodes = 0, sg_magic = 0, sg_start = 0;
+  if (SEG) {
+    const u32 tile = base / (u32)radix_tile<u32>();          // the sort's tiles are whole multiples of this kernel's
+    u32 lo = 0, hi = nseg;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (seg_tile_first[mid] <= tile) lo = mid; else hi = mid; }
+    const uint4 t = segtab[lo];
+    sg_base = t.y; sg_nodes = t.z; sg_magic = seg_magic[lo];
+    sg_start = seg_tile_first[lo] * (u32)radix_tile<u32>();
+  }
+  // group of a key of this tile's section: ids below sg_nodes are the groups themselves, the others hold one group per
+  // `leaves` ids (the division as a multiplication by the host's 2^32 / leaves rounded up; 0: one leaf)
+  auto seg_group = [&](u32 k) {
+    const u32 id = k >> kStepLeafShift;
+    if (id < sg_nodes) return sg_base + id;
+    const u32 x = id - sg_nodes;
+    return sg_base + sg_nodes + (sg_magic ? __umulhi(x, sg_magic) : x);
+  };
   // all loads first: sixteen independent pairs in flight per thread instead of one at a time
   u32 k[kWtE], kp[kWtE];
 #pragma unroll
@@ -271,9 +338,14 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
     k[e] = j < n ? key[j] : 0u;
     kp[e] = (j < n && j) ? key[j - 1] : 0u;
   }
+  // (segmented layout: padding carries the all-ones key, in no group and never coded; its group number, kMaxGroups - 1,
+  // is no section's, so the first step behind it starts its group)
   u32 grp[kWtE], grp_prev[kWtE];
 #pragma unroll
-  for (int e = 0; e < kWtE; ++e) { grp[e] = wt_group_of<DENSE>(k[e], id_group); grp_prev[e] = wt_group_of<DENSE>(kp[e], id_group); }   // k = 0 past the end: id / group 0 exists
+  for (int e = 0; e < kWtE; ++e) {
+    grp[e] = k[e] == 0xFFFFFFFFu ? 0u : SEG ? seg_group(k[e]) : wt_group_of<DENSE>(k[e], id_group);       // k = 0 past the end: id / group 0 exists
+    grp_prev[e] = kp[e] == 0xFFFFFFFFu ? 0xFFFFFFFFu : SEG ? seg_group(kp[e]) : wt_group_of<DENSE>(kp[e], id_group);
+  }
   u8 type[kWtE];
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) type[e] = group_type[grp[e]];
@@ -281,9 +353,12 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) {
     const u32 j = base + e * kWtTPB + threadIdx.x;
-    if (j < n) {
+    if (j < n && k[e] == 0xFFFFFFFFu) {
+      code[j] = kWtSkip;
+    } else if (j < n) {
       const u32 g = grp[e];
-      const bool first = j == 0 || grp_prev[e] != g;
+      // (SEG: the step before a section's first one is the last of the section before, read with the wrong table)
+      const bool first = j == 0 || grp_prev[e] != g || (SEG && j == sg_start);
       if (first) group_start[g] = j;
       const u32 bit = k[e] & 1u;
       u8 c;
@@ -411,10 +486,21 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 n_groups = (u32)plan.group_type.size();
   if (nsec == 0 || nsec > 256 || first_run.size() != nsec + 1 || n_runs == 0) return -1;
   BWTC_HIP_TRY(e.codes_wait());                       // the previous block's packed streams have left the device
-  if (plan.max_elements + kWtTile >= (1ull << 32)) return -5;       // step indices are 32 bit
   BWTC_HIP_TRY(hipSetDevice(e.device));
-  const u64 cap = plan.max_elements;
   const bool dense_ids = !plan.id_group.empty();
+  // segmented layout (k_wt_segments): when every section's dense ids fit two digits
+  bool segmented = !dense_ids && e.wt_segmented;
+  for (u32 s = 0; s < nsec && segmented; ++s) {
+    const bwtc::wavelet::StreamPlan::Section& sec = plan.sections[s];
+    const u32 groups = (s + 1 < nsec ? plan.sections[s + 1].group_base : n_groups) - sec.group_base;
+    if (groups < sec.n_nodes || sec.n_leaves > 256u ||
+        sec.n_nodes + (u64)(groups - sec.n_nodes) * std::max(1u, sec.n_leaves) > 65536ull) segmented = false;
+    if (std::getenv("BWTC_HIP_DEBUG_SEG"))
+      std::fprintf(stderr, "section %u: %u groups, %u symbol nodes, %u leaves -> %llu ids\n", s, groups, sec.n_nodes, sec.n_leaves,
+                   (unsigned long long)(sec.n_nodes + (u64)(groups - sec.n_nodes) * std::max(1u, sec.n_leaves)));
+  }
+  const u64 cap = plan.max_elements + (segmented ? (u64)nsec * radix_tile<u32>() : 0ull);
+  if (cap + kWtTile >= (1ull << 32)) return -5;             // step indices are 32 bit
   const int key_bits = dense_ids ? (int)kStepLeafShift + bit_width_u64(plan.id_group.size() - 1)
                                  : (int)kStepGroupShift + bit_width_u64(n_groups ? n_groups - 1 : 0);
 
@@ -430,7 +516,9 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u64 o_pool = take(plan.pool.size() * 4ull + 16);
   const u64 o_gtype = take(n_groups + 16);
   const u64 o_idgroup = take(plan.id_group.size() * 4ull + 16);
+  const u64 o_segtab = take(nsec * 16ull), o_segmagic = take(nsec * 4ull);
   const u64 tables_end = at;
+  const u64 o_pstart = take((nsec + 1) * 4ull), o_tilefirst = take((nsec + 1) * 4ull), o_totals = take(16);
   const u64 o_gstart = take((n_groups + 1) * 4ull);
   const u64 o_gpos = take((n_groups + 1) * 4ull);
   const u64 o_cnt = take(((u64)n_runs + 1) * 4);
@@ -463,6 +551,12 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
     if (!plan.pool.empty()) std::memcpy(h + o_pool, plan.pool.data(), plan.pool.size() * 4ull);
     std::memcpy(h + o_gtype, plan.group_type.data(), n_groups);
     if (dense_ids) std::memcpy(h + o_idgroup, plan.id_group.data(), plan.id_group.size() * 4ull);
+    for (u32 s2 = 0; s2 < nsec; ++s2) {
+      const u32 leaves = std::max(1u, plan.sections[s2].n_leaves);
+      u32* row = reinterpret_cast<u32*>(h + o_segtab) + 4 * s2;
+      row[0] = 0; row[1] = plan.sections[s2].group_base; row[2] = plan.sections[s2].n_nodes; row[3] = leaves;
+      reinterpret_cast<u32*>(h + o_segmagic)[s2] = leaves > 1 ? (u32)((1ull << 32) / leaves + 1) : 0u;    // x / leaves = umulhi(x, this) for x < 65 536
+    }
     BWTC_HIP_TRY(hipMemcpyAsync(base, h, tables_end, hipMemcpyHostToDevice, st));
   }
   WtTables t;
@@ -478,6 +572,9 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32* d_idgroup = dense_ids ? ptr32(o_idgroup) : nullptr;
 
   if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "streams: %u sections, %u groups, step sort %s\n", nsec, n_groups,
+                 segmented ? "segmented (two passes over the sections' own ids)" : dense_ids ? "over dense ids" : "over block-wide group numbers");
+  if (std::getenv("BWTC_HIP_DEBUG"))
     std::fprintf(stderr, "streams: tables of %llu bytes staged and queued %.2f ms after entry\n", (unsigned long long)tables_end,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
   // expand
@@ -485,14 +582,28 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   hipLaunchKernelGGL(k_wt_count, dim3(ceil_div((u64)n_runs + 1, kWtTPB * kWtCountE)), dim3(kWtTPB), 0, st,
                      d_run_start, d_run_sym, n_runs, t, d_cnt);
   exclusive_scan_u32(d_cnt, (u64)n_runs + 1, ptr32(o_cnt_partial), st);
-  BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_cnt + n_runs, 4, hipMemcpyDeviceToHost, st));
+  if (segmented) {
+    hipLaunchKernelGGL(k_wt_segments, dim3(1), dim3(64), 0, st, t.first_run, nsec, (const u32*)d_cnt, (u32)radix_tile<u32>(), ptr32(o_pstart),
+                       ptr32(o_tilefirst), reinterpret_cast<uint4*>(base + o_segtab), ptr32(o_totals));
+    BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, ptr32(o_totals), 8, hipMemcpyDeviceToHost, st));
+  } else {
+    BWTC_HIP_TRY(hipMemcpyAsync(e.h_small, d_cnt + n_runs, 4, hipMemcpyDeviceToHost, st));
+  }
   BWTC_HIP_TRY(e.wait());
-  const u32 n = e.h_small[0];
-  if (n == 0 || (u64)n > cap) return -3;
+  const u32 n_steps = e.h_small[0];
+  if (n_steps == 0 || (u64)n_steps > plan.max_elements) return -3;
+  const u32 n = segmented ? e.h_small[1] : n_steps;        // the length of the row of steps, padding included
+  if ((u64)n > cap || n < n_steps || (segmented && n % radix_tile<u32>())) return -3;
   hipLaunchKernelGGL(k_wt_expand, dim3(ceil_div(n_runs, kWtExpandRuns)), dim3(kWtTPB), 0, st, d_run_start,
-                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), base + o_code);
+                     d_run_sym, n_runs, t, d_cnt, ptr32(o_k0), base + o_code, segmented ? reinterpret_cast<const uint4*>(base + o_segtab) : (const uint4*)nullptr);
   // sort by (group, leaf rank), keys only; the bit and the gap flag ride along in the word
   u32* ks = nullptr; u32* vs = nullptr;
+  if (segmented) {
+    hipLaunchKernelGGL(k_wt_pad_fill, dim3(nsec), dim3(kWtTPB), 0, st, t.first_run, (const u32*)d_cnt, (const u32*)ptr32(o_pstart), ptr32(o_k0),
+                       base + o_code);
+    radix_sort_keys_segmented(ptr32(o_k0), ptr32(o_k1), n, (int)kStepLeafShift, ptr32(o_tilefirst), nsec,
+                              ptr32(o_table), ptr32(o_partial), st, &ks, base + o_code, base + o_compact);
+  } else
   radix_sort_pairs<u32, u32>(ptr32(o_k0), ptr32(o_k1), (u32*)nullptr, (u32*)nullptr, n, key_bits,
                         ptr32(o_table), ptr32(o_partial), st, &ks, &vs, nullptr, (int)kStepLeafShift, false, true,
                         0, base + o_code, base + o_compact, true);     // planes: both byte arrays are free until the select kernel
@@ -502,8 +613,12 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   const u32 tiles = ceil_div(n, kWtTile);
   u8* d_code = base + o_code;
   u32* d_tile = ptr32(o_tile);
-  if (dense_ids) hipLaunchKernelGGL(k_wt_select<true>, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
-  else hipLaunchKernelGGL(k_wt_select<false>, dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart);
+  const u32* d_tf = ptr32(o_tilefirst);
+  const uint4* d_segtab = reinterpret_cast<const uint4*>(base + o_segtab);
+  const u32* d_segmagic = ptr32(o_segmagic);
+  if (segmented) hipLaunchKernelGGL((k_wt_select<false, true>), dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart, d_tf, nsec, d_segtab, d_segmagic);
+  else if (dense_ids) hipLaunchKernelGGL((k_wt_select<true, false>), dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart, d_tf, nsec, d_segtab, d_segmagic);
+  else hipLaunchKernelGGL((k_wt_select<false, false>), dim3(tiles), dim3(kWtTPB), 0, st, ks, n, d_gtype, d_idgroup, d_code, d_tile, d_gstart, d_tf, nsec, d_segtab, d_segmagic);
   BWTC_HIP_TRY(hipMemsetAsync(d_tile + tiles, 0, 4, st));
   exclusive_scan_u32(d_tile, (u64)tiles + 1, ptr32(o_tile_partial), st);
   hipLaunchKernelGGL(k_wt_group_pos, dim3(ceil_div(n_groups, kWtTPB / kWave)), dim3(kWtTPB), 0, st, d_gstart,
@@ -542,7 +657,7 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   (*coded_pos)[n_groups] = n_coded;
   for (u32 g = n_groups; g-- > 0;)
     if ((*coded_pos)[g] == 0xFFFFFFFFu) (*coded_pos)[g] = (*coded_pos)[g + 1];
-  e.wt_elements = n;
+  e.wt_elements = n_steps;
   e.wt_coded = n_coded;
   if (d_packed) *d_packed = ptr32(o_packed);
   return 0;

@@ -388,6 +388,7 @@ def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(mod
         # the device passes run, then every block is treated as flagged: its models are redone on the
         # worker threads from the packed streams (the route that keeps a surprise from costing bytes)
         monkeypatch.setenv("BWTC_HIP_TEST_MODELS_FALLBACK", "1")
+        monkeypatch.setenv("BWTC_HIP_SEG_STEPS", "0")            # and the step sort over block-wide group numbers
     else:
         monkeypatch.setenv("BWTC_HIP_SCAN", "chained")
     rng = np.random.default_rng(31)
