@@ -1349,6 +1349,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
+    gm_partition_lines = std::getenv("BWTC_HIP_GM_PARTITION") && std::strcmp(std::getenv("BWTC_HIP_GM_PARTITION"), "lines") == 0;
     wt_segmented = !(std::getenv("BWTC_HIP_SEG_STEPS") && std::getenv("BWTC_HIP_SEG_STEPS")[0] == '0');
     gram_min_n = kGramMinN;
     if (std::getenv("BWTC_HIP_GRAM_MIN_N")) gram_min_n = (u32)std::max(64, std::atoi(std::getenv("BWTC_HIP_GRAM_MIN_N")));   // tests: small blocks through the gram / long-key routes

@@ -339,6 +339,7 @@ struct BwtEngine {
   PinnedPool codes_pool, w_pool;                                       // recycled: no fresh pages per block
   std::vector<std::unique_ptr<RawBuffer<uint16_t> > > prob_free;
   u64 wt_elements = 0, wt_coded = 0;   // steps / coded elements of the last block
+  bool gm_partition_lines = false;     // BWTC_HIP_GM_PARTITION=lines: the model passes' partition assembled in LDS and stored as whole lines
   bool wt_segmented = true;            // BWTC_HIP_SEG_STEPS=0: the 'B' coder's step sort over block-wide group numbers (three passes)
   bool wavelet_on_host = false;        // BWTC_HIP_WAVELET=host: build the trees on the host instead
 

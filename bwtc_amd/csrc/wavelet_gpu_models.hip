@@ -127,7 +127,73 @@ __global__ __launch_bounds__(kGmTPB) void k_gm_partition(const u32* __restrict__
   const gm::Chunk ch = chunks[c];
   for (u32 k = 0; k < gm::kSlots; ++k) { pos[k][threadIdx.x] = base[(u64)k * nc + c]; acc[k][threadIdx.x] = 0; }
   gm::lanePartition(packed, ch.begin, ch.end, tasks[ch.task_first & 0x7FFFFFFFu].type, cstate[c], &pos[0][threadIdx.x],
-                    &acc[0][threadIdx.x], kGmTPB, sbits);
+                        &acc[0][threadIdx.x], kGmTPB, sbits);
+}
+
+// The same pass with whole lines leaving the workgroup (BWTC_HIP_GM_PARTITION=lines; measured, not the default): its
+// chunks are CONSECUTIVE (no type order here), so in every slot its bits fill one stretch of slot space.  The
+// stretches are assembled in LDS -- a lane takes its next position with one returning ds_add and sets a one-bit with
+// a ds_or -- and stored word by word, consecutive lanes consecutive words; only a stretch's first and last word are
+// shared with the neighbouring workgroups and OR-ed in.  k_gm_partition above lets every lane store its own words as
+// they fill: a line of slot space is completed by eight lanes at different times while 130 000 lanes hold fifteen
+// open lines each, so lines leave the L2 part-filled and come back (8 x the bytes).  But the pass is
+// bound by instruction issue, not by those bytes: this form needs 32 KiB of LDS per 128 lanes (two waves per SIMD
+// instead of five) and takes 0.99 ms per 256 MiB text block against 0.63; non-temporal word stores in the first
+// form: 0.82 ms.
+constexpr int kGmPartTPB = 128;
+constexpr u32 kGmPartWords = kGmPartTPB * gm::kChunk / 32 + 32;     // every slot's stretch may start and end inside a word
+
+template <u32 TYPE>
+__device__ __forceinline__ void gm_partition_walk(const u32* __restrict__ packed, u32 begin, u32 end, u32 state,
+                                                  u32* pos, u32* region) {
+  gm::Machines m = {state & 7u, (state >> 3) & 3u, (state >> 5) & 3u};
+  gm::forElements(packed, begin, end, [&](u32, u32 v) {
+    const u32 slot = gm::stepMachinesT<TYPE>(v, m);
+    const u32 p = __hip_atomic_fetch_add(&pos[slot * kGmPartTPB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v & 1u) (void)__hip_atomic_fetch_or(&region[p >> 5], 1u << (p & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  });
+}
+
+__global__ __launch_bounds__(kGmPartTPB) void k_gm_partition_lines(const u32* __restrict__ packed, const gm::Chunk* __restrict__ chunks,
+                                                                   const gm::Task* __restrict__ tasks, const u32* __restrict__ cstate,
+                                                                   const u32* __restrict__ base, u32 nc, u32* __restrict__ sbits) {
+  __shared__ u32 region[kGmPartWords];
+  __shared__ u32 pos[gm::kSlots][kGmPartTPB];
+  __shared__ u32 s_g0[gm::kSlots], s_nw[gm::kSlots], s_off[gm::kSlots + 1];
+  const u32 tid = threadIdx.x;
+  const u32 c0 = blockIdx.x * kGmPartTPB, c1 = min(c0 + (u32)kGmPartTPB, nc);
+  const u32 c = c0 + tid;
+  for (u32 i = tid; i < kGmPartWords; i += kGmPartTPB) region[i] = 0;
+  if (tid < gm::kSlots) {
+    const u32 g0 = base[(u64)tid * nc + c0], g1 = base[(u64)tid * nc + c1];     // base[k nc + nc] = base[(k + 1) nc]: the array is one prefix
+    s_g0[tid] = g0 >> 5;
+    s_nw[tid] = g1 > g0 ? ((g1 - 1u) >> 5) - (g0 >> 5) + 1u : 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    u32 at = 0;
+    for (u32 k = 0; k < gm::kSlots; ++k) { s_off[k] = at; at += s_nw[k]; }
+    s_off[gm::kSlots] = at;
+  }
+  __syncthreads();
+  if (s_off[gm::kSlots] > kGmPartWords) return;          // cannot happen (see kGmPartWords); the block then fails its element count
+  if (c < nc) {
+    const gm::Chunk ch = chunks[c];
+    for (u32 k = 0; k < gm::kSlots; ++k) pos[k][tid] = (s_off[k] << 5) + (base[(u64)k * nc + c] - (s_g0[k] << 5));
+    const u32 type = tasks[ch.task_first & 0x7FFFFFFFu].type;
+    const u32 st = cstate[c];
+    using namespace gm;
+    BWTC_GM_BY_TYPE(type, gm_partition_walk<TYPE>(packed, ch.begin, ch.end, st, &pos[0][tid], region));
+  }
+  __syncthreads();
+  for (u32 k = 0; k < gm::kSlots; ++k) {
+    const u32 nw = s_nw[k], off = s_off[k], g0 = s_g0[k];
+    for (u32 w = tid; w < nw; w += kGmPartTPB) {
+      const u32 v = region[off + w];
+      if (w == 0 || w + 1u == nw) { if (v) atomicOr(&sbits[g0 + w], v); }
+      else sbits[g0 + w] = v;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kGmTPB) void k_gm_bracket(const u32* __restrict__ sbits, const u32* __restrict__ sb, u32 ns, u32 nt,
@@ -342,7 +408,11 @@ int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_
   hipLaunchKernelGGL(k_gm_count, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_order, nc, d_base);
   exclusive_scan_u32(d_base, g.n_base, static_cast<u32*>(g.d_partial), st);
   hipLaunchKernelGGL(k_gm_streams, dim3(ceil_div((u64)ns + 1, kGmTPB)), tpb, 0, st, d_base, d_tasks, nc, nt, d_sb);
-  hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
+  if (e.gm_partition_lines)
+    hipLaunchKernelGGL(k_gm_partition_lines, dim3(ceil_div(nc, kGmPartTPB)), dim3(kGmPartTPB), 0, st, g.d_packed, d_chunks, d_tasks, d_cstate,
+                       d_base, nc, d_sbits);
+  else
+    hipLaunchKernelGGL(k_gm_partition, gc, tpb, 0, st, g.d_packed, d_chunks, d_tasks, d_cstate, d_base, d_order, nc, d_sbits);
   hipLaunchKernelGGL(k_gm_bracket, gs, tpb, 0, st, d_sbits, d_sb, ns, nt, n_coded, nsc, d_smap, d_snaps, d_tail + 1);
   hipLaunchKernelGGL(k_gm_chain_group, dim3(g.ng), dim3(64), 0, st, d_smap, nsc, g.gsize, (unsigned short*)g.d_gmap, (unsigned short*)g.d_gL);
   hipLaunchKernelGGL(k_gm_chain_top, dim3(1), dim3(1024), 0, st, (const unsigned short*)g.d_gmap, (const unsigned short*)g.d_gL, g.ng,

@@ -391,6 +391,7 @@ def test_wavelet_B_models_on_the_device_and_on_the_host_give_the_same_stream(mod
         monkeypatch.setenv("BWTC_HIP_SEG_STEPS", "0")            # and the step sort over block-wide group numbers
     else:
         monkeypatch.setenv("BWTC_HIP_SCAN", "chained")
+        monkeypatch.setenv("BWTC_HIP_GM_PARTITION", "lines")     # and the partition pass that stores whole lines
     rng = np.random.default_rng(31)
     parts = [synth.gen_text(3 << 20, 5), synth.gen_dna(1 << 20, 6), np.full(300000, 9, np.uint8),
              rng.integers(0, 256, 700000).astype(np.uint8), synth.gen_text((2 << 20) + 12345, 7),
