@@ -343,8 +343,13 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
   u32 grp[kWtE], grp_prev[kWtE];
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) {
-    grp[e] = k[e] == 0xFFFFFFFFu ? 0u : SEG ? seg_group(k[e]) : wt_group_of<DENSE>(k[e], id_group);       // k = 0 past the end: id / group 0 exists
-    grp_prev[e] = kp[e] == 0xFFFFFFFFu ? 0xFFFFFFFFu : SEG ? seg_group(kp[e]) : wt_group_of<DENSE>(kp[e], id_group);
+    if (SEG) {
+      grp[e] = k[e] == 0xFFFFFFFFu ? 0u : seg_group(k[e]);
+      grp_prev[e] = kp[e] == 0xFFFFFFFFu ? 0xFFFFFFFFu : seg_group(kp[e]);
+    } else {
+      grp[e] = wt_group_of<DENSE>(k[e], id_group);         // k = 0 past the end: id / group 0 exists
+      grp_prev[e] = wt_group_of<DENSE>(kp[e], id_group);
+    }
   }
   u8 type[kWtE];
 #pragma unroll
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(kWtTPB) void k_wt_select(const u32* __restrict__ ke
 #pragma unroll
   for (int e = 0; e < kWtE; ++e) {
     const u32 j = base + e * kWtTPB + threadIdx.x;
-    if (j < n && k[e] == 0xFFFFFFFFu) {
+    if (SEG && j < n && k[e] == 0xFFFFFFFFu) {
       code[j] = kWtSkip;
     } else if (j < n) {
       const u32 g = grp[e];
