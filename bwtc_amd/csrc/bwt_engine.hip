@@ -310,6 +310,7 @@ __device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v)
 // characters and the ranking behind it can emit the transform's bytes without going back to T.
 struct LongKey {
   u32* w; int G2;                // make: where the second words go, grams per word
+  int drop;                      // the second word is stored without its lowest `drop` bits (see BwtEngine::long_drop)
   int hi_shift;                  // key bits [hi_shift, hi_shift + 13): the upper bits of the suffix number
   int chr_shift; u32 chr_mask;   // key bits of the predecessor character's dense code
 };
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
       if (lk.w) {
         u32 w = 0;
         for (int j = G; j < Gall; ++j) w = (w << b) | s_g[o + s + (u32)(j * g)];
-        s_w[cntw - 1u - (o + s)] = w;
+        s_w[cntw - 1u - (o + s)] = w >> lk.drop;
         const u32 i = i_base + o + s;                  // its predecessor's code (suffix 0 has none)
         key |= (u64)(i ? (u32)s_c[(int)(o + s) - 1] : 0u) << lk.chr_shift;
       }
@@ -432,7 +433,7 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loaded on their own.
 // LONG (initial ranking after the long-key sort, radix_sort_long): a suffix's order key is (key & kmask,
 // w & wmask); the upper bits of its number sit at hi_shift, its predecessor character's code at chr_shift.
-struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; };
+struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int dropped; };
 
 template <typename K, bool INIT, bool SPLIT, bool LONG = false>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
@@ -1348,6 +1349,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     }
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
+    if (std::getenv("BWTC_HIP_LONG_DROP")) long_drop = std::max(0, std::atoi(std::getenv("BWTC_HIP_LONG_DROP")));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
     gm_partition_lines = std::getenv("BWTC_HIP_GM_PARTITION") && std::strcmp(std::getenv("BWTC_HIP_GM_PARTITION"), "lines") == 0;
     wt_segmented = !(std::getenv("BWTC_HIP_SEG_STEPS") && std::getenv("BWTC_HIP_SEG_STEPS")[0] == '0');
@@ -1662,7 +1664,9 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   // Long items of which at most half is still tied (a 256 MiB text block: 21 %, a 1 GiB one: 37 %): the finisher
   // settles the rest by direct comparison (suffix_sort); rank[] is not written at all.  Above that the list is
   // dominated by long repeats and the doubling rounds are the better tool.
-  res->finish = lng && emit && finisher && (u64)m_next * 2 <= m;
+  // (with the last gram's low bits left out of the sort -- long_drop -- the list also holds what those bits would have
+  // told apart: the bound is three fifths then)
+  res->finish = lng && emit && finisher && (lgv.dropped ? (u64)m_next * 5 <= (u64)m * 3 : (u64)m_next * 2 <= m);
   if (res->finish) {
     sa_out = d_SA;
     fin_active = true;
@@ -1894,7 +1898,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // Long keys: the sort also orders by a second key word (the next G2 grams) and the items carry
     // their predecessor character's code -- when the fields fit: key bits + 13 + code bits <= 64.
     LongKey lk;
-    lk.w = nullptr; lk.G2 = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
+    lk.w = nullptr; lk.G2 = 0; lk.drop = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
     // (without the split -- blocks above 512 MiB, keys above 48 bits -- the items carry whole 32-bit suffix numbers:
     // 16 bytes instead of 14, and the key only needs room for the character)
     if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= gram_min_n) {
@@ -1912,8 +1916,20 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       }
     }
     if (lk.w) {
-      const int w_bits = gp.b * lk.G2;
-      short_len = (u32)(gp.g * (gp.G + lk.G2));
+      // long_drop: the last gram's code goes into the sort without its lowest bits when that saves a pass (the codes
+      // are the grams' ranks, so a code's upper bits still order what they tell apart; what they do not is tied at the
+      // depth of the whole grams before it and left to the finisher, which reads the text from there)
+      // Only with the split index (blocks up to 512 MiB: above that the text no longer sits in the Infinity Cache and
+      // the finisher's reads cost more than the pass saves: 1 GiB text 127.8 ms against 117.4), and not while the
+      // stream's blocks keep coming back with long lists (drop_paused, below).
+      int drop = 0;
+      if (long_drop > 0 && long_drop < gp.b && split && !drop_paused) {
+        const int all = key_bits + gp.b * lk.G2;
+        if ((all - long_drop + kRadixBits - 1) / kRadixBits < (all + kRadixBits - 1) / kRadixBits) drop = long_drop;
+      }
+      lk.drop = drop;
+      const int w_bits = gp.b * lk.G2 - drop;
+      short_len = (u32)(gp.g * (gp.G + lk.G2 - (drop ? 1 : 0)));
       h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
                          (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split, lk);
@@ -1933,15 +1949,21 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
       RrLong lg;
       lg.w = ws; lg.wmask = w_bits >= 32 ? ~0u : (1u << w_bits) - 1u;
-      lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask;
+      lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask; lg.dropped = drop;
       if (std::getenv("BWTC_HIP_DEBUG"))
-        std::fprintf(stderr, "long keys: %d + %d bits, %d + %d grams of %d characters, character code at bit %d\n",
-                     key_bits, w_bits, gp.G, lk.G2, gp.g, lk.chr_shift);
+        std::fprintf(stderr, "long keys: %d + %d bits (%d dropped), %d + %d grams of %d characters, character code at bit %d\n",
+                     key_bits, w_bits, drop, gp.G, lk.G2, gp.g, lk.chr_shift);
       rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, (u32)split, &lg);
       if (rc) return rc;
-      stats.sort_pass_items += (u64)n * (u64)((key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits);
+      // what the dropped bits cost shows in the list the ranking leaves: the 256 MiB text block 31.8 % of the suffixes
+      // against 21.5 (and 24.8 ms against 26.2); past three eighths the finisher's extra entries outweigh the pass, so
+      // the next blocks of the stream sort all the bits again until a list comes back short enough
+      if (drop && (u64)res.m * 8 > (u64)n * 3) drop_paused = true;
+      else if (!drop && drop_paused && (u64)res.m * 4 < (u64)n) drop_paused = false;
+      const int long_passes = (key_bits + w_bits + kRadixBits - 1) / kRadixBits;
+      stats.sort_pass_items += (u64)n * (u64)long_passes;
       stats.alg_bytes += (u64)n * (1 + 12 + 1)               // k_make_keys_gram: T read, key + second word + first plane written (the values are made up by the first pass)
-                         + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits + (w_bits + kRadixBits - 1) / kRadixBits, split ? 14 : 16, 8, true);
+                         + sort_bytes(n, long_passes, split ? 14 : 16, 8, true);
       stats.route |= 1u;
       key_bits = 0;                                      // counted
     } else if (gp.G > 0) {

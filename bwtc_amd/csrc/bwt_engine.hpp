@@ -409,6 +409,8 @@ struct BwtEngine {
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
   int finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
+  int long_drop = 3;             // BWTC_HIP_LONG_DROP=N: the long sort leaves out the N lowest bits of the last gram's code when that saves a pass (0: never)
+  bool drop_paused = false;      // the last block's list was long with the bits dropped: keep them until a short list comes back
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);

@@ -46,13 +46,18 @@ __device__ __forceinline__ u32 radix_digit(K k, int shift) {
 // Long items (the suffix sorter's long-key initial sort): every item carries a second 32-bit key word w
 // beside (key, value).  The early passes take their digits from w, the later ones from the key; dmask
 // cuts a field's top digit to the field's bits (whatever sits above them is payload, not order).
+// When w's bits are no whole number of digits, one "bridge" digit takes w's top `bridge` bits and the key's lowest
+// ones above them, so that the passes number ceil((w bits + key bits) / 8) and not one more.
 struct LongArgs {
   const u32* win; u32* wout;
   u32 dmask;                     // this pass's digit mask
-  int nshift, nfrom_w; u32 ndmask;   // the NEXT pass's digit (for the plane this pass leaves)
+  int bridge;                    // bridge digit: how many of its bits are w's (the pass's shift is into w)
+  int nshift, nfrom_w; u32 ndmask;   // the NEXT pass's digit (for the plane this pass leaves): 0 key, 1 w, 2 bridge
+  int nbridge;
 };
 template <typename K, int LONG>
-__device__ __forceinline__ u32 long_digit(K k, u32 w, int shift, u32 dmask) {
+__device__ __forceinline__ u32 long_digit(K k, u32 w, int shift, u32 dmask, int bridge = 0) {
+  if (LONG == 3) return ((w >> shift) | ((u32)k << bridge)) & dmask;
   if (LONG == 2) return (w >> shift) & dmask;
   if (LONG == 1) return (u32)(k >> shift) & dmask;
   return radix_digit(k, shift);
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
 // KEYS: keys only (no values staged: half the LDS of a 32-bit pair tile, twice the workgroups per CU).
 // V: the values' type in memory, u32 or u16 (the suffix sorter's initial sort keeps the upper bits
 // of a suffix number in spare bits of its key, so that a pass moves 10 bytes per item instead of 12).
-// LONG (see LongArgs): 0 plain items; 1 long items, digit from the key; 2 long items, digit from w.
+// LONG (see LongArgs): 0 plain items; 1 long items, digit from the key; 2 long items, digit from w; 3 the bridge digit.
 // SEG (see SegArgs): a segmented pass (32-bit keys only, no long items).
 template <typename K, bool SKIP, bool PLANE, bool KEYS, typename V = u32, int LONG = 0, int E_ = RadixCfg<K>::E, bool SEG = false>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const bool ok = BWTC_EXISTS(e);
-    const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask);
+    const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask, la.bridge);
     u32 below, peers;
     wave_digit_rank<kRadixBits>(d, ok, &below, &peers);
     u32 prev = 0;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (BWTC_EXISTS(e)) {
-      const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask);
+      const u32 d = long_digit<K, LONG>(k[e], w[LONG ? e : 0], shift, la.dmask, la.bridge);
       r[e] += s_base[d] + s_cnt[wave][d];          // final tile slot
     }
   }
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
   }
 #pragma unroll
   for (int e = 0; e < E; ++e)
-    dst[e] = s_gofs[long_digit<K, LONG>(kk[e], ww[LONG ? e : 0], shift, la.dmask)] + tid + (u32)e * kRadixTPB;
+    dst[e] = s_gofs[long_digit<K, LONG>(kk[e], ww[LONG ? e : 0], shift, la.dmask, la.bridge)] + tid + (u32)e * kRadixTPB;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (tid + (u32)e * kRadixTPB < tile_out) {
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
       if (!KEYS) vout[dst[e]] = (V)vv[e];
       if (LONG) la.wout[dst[e]] = ww[LONG ? e : 0];
       if (PLANE) {
-        if (LONG) plane[dst[e]] = (u8)((la.nfrom_w ? ww[LONG ? e : 0] >> la.nshift : (u32)(kk[e] >> la.nshift)) & la.ndmask);
+        if (LONG) plane[dst[e]] = (u8)((la.nfrom_w == 2 ? (ww[LONG ? e : 0] >> la.nshift) | ((u32)kk[e] << la.nbridge)
+                                         : la.nfrom_w ? ww[LONG ? e : 0] >> la.nshift : (u32)(kk[e] >> la.nshift)) & la.ndmask);
         else plane[dst[e]] = (u8)radix_digit(kk[e], shift + kRadixBits);
       }
     }
@@ -482,11 +488,18 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
   u64 *kin = k0, *kout = k1;
   V *vin = v0, *vout = v1;
   u32 *win = w0, *wout = w1;
-  struct Pass { int from_w, shift; u32 dmask; };
+  struct Pass { int from_w, shift; u32 dmask; int bridge; };    // from_w: 0 key, 1 w, 2 bridge (w's top bits under the key's lowest)
   Pass ps[24];
   int np = 0;
-  for (int s = 0; s < wbits; s += kRadixBits) ps[np++] = Pass{1, s, (1u << std::min(kRadixBits, wbits - s)) - 1u};
-  for (int s = 0; s < kbits; s += kRadixBits) ps[np++] = Pass{0, s, (1u << std::min(kRadixBits, kbits - s)) - 1u};
+  int s = 0;
+  for (; s + kRadixBits <= wbits; s += kRadixBits) ps[np++] = Pass{1, s, (1u << kRadixBits) - 1u, 0};
+  int ks = 0;
+  if (s < wbits) {
+    const int r = wbits - s;                                     // w bits left: the bridge digit's low bits
+    ps[np++] = Pass{2, s, (1u << std::min(kRadixBits, r + kbits)) - 1u, r};
+    ks = std::min(kbits, kRadixBits - r);
+  }
+  for (; ks < kbits; ks += kRadixBits) ps[np++] = Pass{0, ks, (1u << std::min(kRadixBits, kbits - ks)) - 1u, 0};
   if (n > 1) {
     const u32 ntiles = ceil_div(n, (u64)kRadixTPB * EL);
     const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
@@ -495,12 +508,14 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool last = p + 1 == np;
       LongArgs la;
-      la.win = win; la.wout = wout; la.dmask = ps[p].dmask;
+      la.win = win; la.wout = wout; la.dmask = ps[p].dmask; la.bridge = ps[p].bridge;
       la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
+      la.nbridge = last ? 0 : ps[p + 1].bridge;
       const int vmode = p == 0 ? 3 : 0;
       const bool timed = probe && probe->begin(st);
 #define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la, SegArgs())
-      if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
+      if (ps[p].from_w == 2) { if (last) BWTC_SCATTER_L(false, 3); else BWTC_SCATTER_L(true, 3); }
+      else if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
       else { if (last) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
 #undef BWTC_SCATTER_L
       if (timed) probe->end(st, 2 * n * (sizeof(u64) + sizeof(V) + sizeof(u32)) + (last ? 0 : n));

@@ -343,7 +343,10 @@ _SWITCH_INPUTS = []
                                     # next piece (text rounds, late rank completion + doubling rounds) takes over
                                     "BWTC_HIP_LONG=0", "BWTC_HIP_FINISHER=0", "BWTC_HIP_FIN_PASSES=0", "BWTC_HIP_FIN_PASSES=1",
                                     "BWTC_HIP_TEXT_ROUNDS=0", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_LONG_E=6", "BWTC_HIP_LONG_G2=1",
-                                    "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0"])
+                                    "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0",
+                                    # the last gram's low bits in the sort (default: three of them left out, nine passes
+                                    # instead of ten), and more of them left out than pays
+                                    "BWTC_HIP_LONG_DROP=0", "BWTC_HIP_LONG_DROP=7", "BWTC_HIP_LONG_DROP=11,BWTC_HIP_TEXT_ROUNDS=1"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
