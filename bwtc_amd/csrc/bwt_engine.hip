@@ -778,8 +778,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 constexpr int kFinTPB = 256;
 constexpr int kFinE = 8;
 constexpr int kFinWin = kFinTPB * kFinE;            // 2048 entries in LDS
-constexpr int kFinMaxGroup = 1024;
-constexpr int kFinStride = kFinWin - kFinMaxGroup;  // entries whose groups a workgroup owns
+// kFinMaxGroup (template argument of k_finish; BwtEngine::fin_max_group picks 256, 512 or 1024): the largest group settled here
 constexpr u32 kFinChars = 16;                       // characters compared per pass
 constexpr u32 kFinNone = 0xFFFFFFFFu;
 
@@ -803,10 +802,12 @@ __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32
   *c1 = __builtin_bswap64(hi);
 }
 
+template <int kFinMaxGroup>
 __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n, u32 h,
                                                     FinList next, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP,
                                                     u32* __restrict__ hard_count, u32* __restrict__ SA, RrEmit em) {
+  constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
   __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // 32 KiB; later the reorder staging
   __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
   __shared__ u32 s_H[kFinWin];
@@ -1349,6 +1350,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     }
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
+    if (std::getenv("BWTC_HIP_FIN_GROUP")) fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP"));
     if (std::getenv("BWTC_HIP_LONG_DROP")) long_drop = std::max(0, std::atoi(std::getenv("BWTC_HIP_LONG_DROP")));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
     gm_partition_lines = std::getenv("BWTC_HIP_GM_PARTITION") && std::strcmp(std::getenv("BWTC_HIP_GM_PARTITION"), "lines") == 0;
@@ -2087,8 +2089,12 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
     // a byte and a suffix per finished one
     stats.alg_bytes += (u64)m * (2 * 13 + 24 + 5);
     BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
-    hipLaunchKernelGGL(k_finish, dim3(ceil_div(m, kFinStride)), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, depth,
-                       b, cnt, hardS, hardHP, cnt + 1, d_SA, re);
+    // (a workgroup settles the groups that start in the first kFinWin - G entries of its window: the smaller the largest
+    // group it takes, the more of its lanes have work -- and the more entries go to the text rounds instead)
+#define BWTC_FINISH(G) hipLaunchKernelGGL(k_finish<G>, dim3(ceil_div(m, (u32)(kFinWin - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, depth, \
+                                          b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
+    if (fin_max_group <= 256) BWTC_FINISH(256); else if (fin_max_group <= 512) BWTC_FINISH(512); else BWTC_FINISH(1024);
+#undef BWTC_FINISH
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 8, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
     if (std::getenv("BWTC_HIP_DEBUG"))

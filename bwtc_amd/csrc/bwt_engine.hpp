@@ -402,6 +402,7 @@ struct BwtEngine {
   int long_items_per_thread = 8;   // BWTC_HIP_LONG_E=6: tiles of 3072 items (three workgroups per CU instead of two)
   u32 gram_min_n = 1u << 22; // blocks below this keep the plain base-sigma key (BWTC_HIP_GRAM_MIN_N: tests)
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
+  int fin_max_group = 1024;  // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
   int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
   bool fin_active = false;   // this block takes the finisher route: finished suffixes also go to d_SA
