@@ -311,6 +311,8 @@ __device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v)
 struct LongKey {
   u32* w; int G2;                // make: where the second words go, grams per word
   int drop;                      // the second word is stored without its lowest `drop` bits (see BwtEngine::long_drop)
+  int first_r; u32 first_mask;   // a second word of fewer than eight bits: the sort's first digit is the bridge digit
+                                 // (radix_sort_long), w under the key's lowest bits; first_r = w's bits, -1: the digit is w's
   int hi_shift;                  // key bits [hi_shift, hi_shift + 13): the upper bits of the suffix number
   int chr_shift; u32 chr_mask;   // key bits of the predecessor character's dense code
 };
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     if (lk.w) {
       const u32 w = s_w[j];
       lk.w[J0 + j] = w;
-      if (plane) plane[J0 + j] = (u8)w;               // the long sort's first pass is over w
+      if (plane) plane[J0 + j] = lk.first_r < 0 ? (u8)w : (u8)((w | ((u32)key << lk.first_r)) & lk.first_mask);   // the long sort's first digit
     } else if (plane) plane[J0 + j] = (u8)s_key[j];
   }
 }
@@ -1900,7 +1902,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // Long keys: the sort also orders by a second key word (the next G2 grams) and the items carry
     // their predecessor character's code -- when the fields fit: key bits + 13 + code bits <= 64.
     LongKey lk;
-    lk.w = nullptr; lk.G2 = 0; lk.drop = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
+    lk.w = nullptr; lk.G2 = 0; lk.drop = 0; lk.first_r = -1; lk.first_mask = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
     // (without the split -- blocks above 512 MiB, keys above 48 bits -- the items carry whole 32-bit suffix numbers:
     // 16 bytes instead of 14, and the key only needs room for the character)
     if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= gram_min_n) {
@@ -1931,6 +1933,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       }
       lk.drop = drop;
       const int w_bits = gp.b * lk.G2 - drop;
+      if (w_bits < kRadixBits) { lk.first_r = w_bits; lk.first_mask = (1u << std::min(kRadixBits, w_bits + key_bits)) - 1u; }
       short_len = (u32)(gp.g * (gp.G + lk.G2 - (drop ? 1 : 0)));
       h = (u64)short_len;
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,

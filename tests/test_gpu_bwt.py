@@ -464,3 +464,29 @@ def test_long_key_route_on_small_structured_blocks(oracle, monkeypatch, extra):
             b = oracle.oracle_bwt_block(d, sp)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (extra, it, shape, n, sigma, sp)
     assert taken > 60, taken                                  # the route under test was the route taken
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", ["", "BWTC_HIP_LONG_G2=1", "BWTC_HIP_LONG_DROP=0"])
+def test_long_keys_with_a_second_word_of_less_than_one_digit(oracle, monkeypatch, extra):
+    """Few distinct grams make the long key's second word shorter than one radix digit (7 or 4 bits with three
+    dropped): the sort then starts with the bridge digit -- the word under the key's lowest bits -- and the key
+    maker has to leave exactly that digit in the first plane.  (Found by the randomised campaign: the plane held
+    the word alone, the histogram and the scatter disagreed.)"""
+    from bwtc_amd import hip
+    monkeypatch.setenv("BWTC_HIP_GRAM_MIN_N", "64")
+    if extra:
+        name, value = extra.split("=")
+        monkeypatch.setenv(name, value)
+    rng = np.random.default_rng(77 + len(extra))
+    with hip.Context(0, 1 << 20) as ctx:
+        for it in range(60):
+            n = int(rng.integers(200, 3000))
+            sigma = int(rng.integers(3, 24))
+            alphabet = rng.choice(np.arange(1 if it % 3 else 0, 256), sigma, replace=False).astype(np.uint8)
+            words = [alphabet[rng.integers(0, sigma, int(rng.integers(1, 7)))] for _ in range(int(rng.integers(2, 12)))]
+            d = np.concatenate([words[int(i)] for i in rng.integers(0, len(words), n + 8)])[:n].copy()
+            sp = int(rng.choice([1, 8, 256]))
+            a = ctx.bwt_block(d, sp)
+            b = oracle.oracle_bwt_block(d, sp)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (extra, it, n, sigma, sp)
