@@ -532,7 +532,7 @@ def main():
                 # the launches the probe times: the suffix sorter's full-size passes (round 4: the long-key sort's,
                 # whose items carry a 16-bit value and a second key word; not the 'B' coder's keys-only step sort,
                 # not the few-thousand-item passes of the text rounds)
-                is_long = "k_radix_scatter<unsigned long" in name and "unsigned short, 1," in name or "unsigned short, 2," in name
+                is_long = "k_radix_scatter<unsigned long" in name and any("unsigned short, %d," % m in name for m in (1, 2, 3))
                 is_old = "k_radix_scatter<" in name and "unsigned short" not in name and ", true, unsigned int, 0, 16>" not in name
                 if (is_long or (is_old and v["hbm_bytes_per_launch_avg"] > 1e8 and "r04" not in os.path.basename(pmcs[-1]))):
                     tot_b += v["hbm_bytes_per_launch_avg"] * v["launches"]
@@ -548,7 +548,8 @@ def main():
             long_route = bool(getattr(st, "route", 0) & 1)
             own_bytes = int(getattr(st, "alg_bytes", 0))
             roof = {"bound": "hbm",
-                    "kernel": ("k_radix_scatter<u64 key, u16 + u32 values> (the ten passes of the long-key suffix sort, 14-byte items)"
+                    "kernel": ("k_radix_scatter<u64 key, u16 + u32 values> (the %d passes of the long-key suffix sort, 14-byte items)"
+                               % int(round(getattr(st, "sort_pass_items", 0) / max(1, st.n)) or 9)
                                if long_route else "k_radix_scatter<u64> (+<u32> passes of the suffix sorter)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
