@@ -310,7 +310,7 @@ __device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v)
 // characters and the ranking behind it can emit the transform's bytes without going back to T.
 struct LongKey {
   u32* w; int G2;                // make: where the second words go, grams per word
-  int drop;                      // the second word is stored without its lowest `drop` bits (see BwtEngine::long_drop)
+  int drop;                      // the sort leaves out the second word's lowest `drop` bits (see BwtEngine::long_drop)
   int first_r; u32 first_mask;   // a second word of fewer than eight bits: the sort's first digit is the bridge digit
                                  // (radix_sort_long), w under the key's lowest bits; first_r = w's bits, -1: the digit is w's
   int hi_shift;                  // key bits [hi_shift, hi_shift + 13): the upper bits of the suffix number
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
       if (lk.w) {
         u32 w = 0;
         for (int j = G; j < Gall; ++j) w = (w << b) | s_g[o + s + (u32)(j * g)];
-        s_w[cntw - 1u - (o + s)] = w >> lk.drop;
+        s_w[cntw - 1u - (o + s)] = w;
         const u32 i = i_base + o + s;                  // its predecessor's code (suffix 0 has none)
         key |= (u64)(i ? (u32)s_c[(int)(o + s) - 1] : 0u) << lk.chr_shift;
       }
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     if (lk.w) {
       const u32 w = s_w[j];
       lk.w[J0 + j] = w;
-      if (plane) plane[J0 + j] = lk.first_r < 0 ? (u8)w : (u8)((w | ((u32)key << lk.first_r)) & lk.first_mask);   // the long sort's first digit
+      const u32 ws = w >> lk.drop;                    // the bits the sort orders by
+      if (plane) plane[J0 + j] = lk.first_r < 0 ? (u8)ws : (u8)((ws | ((u32)key << lk.first_r)) & lk.first_mask);   // the long sort's first digit
     } else if (plane) plane[J0 + j] = (u8)s_key[j];
   }
 }
@@ -435,7 +436,10 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loaded on their own.
 // LONG (initial ranking after the long-key sort, radix_sort_long): a suffix's order key is (key & kmask,
 // w & wmask); the upper bits of its number sit at hi_shift, its predecessor character's code at chr_shift.
-struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int dropped; };
+// wmask: the bits of w the sort ordered by; lowmask: its lowest bits, which the sort left out (long_drop) -- they ride
+// to the finisher in the list entry's slot word (bits 29..31; such blocks have fewer than 2^29 suffixes)
+struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int dropped; u32 lowmask; };
+constexpr u32 kFinLowShift = 29;
 
 template <typename K, bool INIT, bool SPLIT, bool LONG = false>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
@@ -461,13 +465,17 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
       const bool ok = p < m;
       kraw[e] = ok ? key[p] : (K)0;
       word[e] = ok ? idx[(sizeof(K) == 8 && SPLIT) ? p >> 1 : p] : 0u;
-      if (LONG) wc[LONG ? e : 0] = ok ? lg.w[p] & lg.wmask : 0u;
+      if (LONG) wc[LONG ? e : 0] = ok ? lg.w[p] : 0u;
     }
 #pragma unroll
     for (int e = 0; e < kRrE; ++e) {
       const u32 p = wbase + e * kWave + lane;
       f.sfx[e] = p < m ? suffix_of(kraw[e], word[e], p) : 0u;
       f.chr[e] = LONG ? ((u32)((u64)kraw[e] >> lg.chr_shift) & lg.chr_mask) : sizeof(K) == 8 ? (u32)((u64)kraw[e] >> 56) : 0u;
+      if (LONG) {                                   // the bits of w the sort left out, above the character's code
+        f.chr[e] |= (wc[LONG ? e : 0] & lg.lowmask) << 8;
+        wc[LONG ? e : 0] &= lg.wmask;
+      }
       kc[e] = kraw[e] & kmask;
     }
   }
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       qs[e] = q_run + (u32)__popcll(ac & lt);
       if (EMIT == 1) cs[e] = f.chr[e];
       if (EMIT == 2 && (!a || MODE != 2)) cs[e] = s ? em.T[s - 1u] : 0u;
-      if (EMIT == 3) cs[e] = s_inv[f.chr[e]];
+      if (EMIT == 3) cs[e] = s_inv[f.chr[e] & 0xFFu];
     }
     q_run += (u32)__popcll(ac);
     g_run += (u32)__popcll(ac & hd);
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       else if (MODE == 0) { if (rank) rank[s] = nr; }
       if (a) {
         const u32 q = qs[e];
-        aglob_out[q] = g;
+        aglob_out[q] = (MODE == 3 && LONG) ? g | ((f.chr[e] >> 8) << kFinLowShift) : g;
         if (MODE != 2) {
           aidx_out[q] = s;
           agrp_out[q] = MODE == 3 ? nr : grp;
@@ -778,8 +786,7 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 // (larger suffix number) is the smaller -- they are never equal.
 // ---------------------------------------------------------------------------------------
 constexpr int kFinTPB = 256;
-constexpr int kFinE = 8;
-constexpr int kFinWin = kFinTPB * kFinE;            // 2048 entries in LDS
+// kFinE (template argument E_ of k_finish): entries per thread, 8 or 4; kFinWin = kFinTPB * kFinE: the window in LDS
 // kFinMaxGroup (template argument of k_finish; BwtEngine::fin_max_group picks 256, 512 or 1024): the largest group settled here
 constexpr u32 kFinChars = 16;                       // characters compared per pass
 constexpr u32 kFinNone = 0xFFFFFFFFu;
@@ -804,11 +811,17 @@ __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32
   *c1 = __builtin_bswap64(hi);
 }
 
-template <int kFinMaxGroup>
+// LOW (first pass after a long sort that left out w's lowest bits): those bits ride in the top of every entry's slot
+// word and are the comparison's first key -- they order the last gram's characters -- with fifteen characters
+// behind the WHOLE grams (h) below them; a member alone with its bits inside its group needs no characters at all.
+template <int kFinMaxGroup, bool LOW, int E_ = 8>
 __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n, u32 h,
                                                     FinList next, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP,
                                                     u32* __restrict__ hard_count, u32* __restrict__ SA, RrEmit em) {
+  constexpr int kFinE = E_;                                           // entries per thread: a window of 2048 (54 KiB of LDS, two workgroups per CU) or 1024
+  constexpr int kFinWin = kFinTPB * kFinE;
+  static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
   constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
   __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // 32 KiB; later the reorder staging
   __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
@@ -825,11 +838,13 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
   const u32 lane = lane_id();
 
   u32 S[kFinE], P[kFinE], H[kFinE], C[kFinE];
+  u32 LB[LOW ? kFinE : 1] = {};                       // LOW: the bits of w the sort left out
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
     const bool ok = q < m;
     S[e] = ok ? in.S[q] : 0u; P[e] = ok ? in.P[q] : 0u; H[e] = ok ? in.H[q] : kFinNone; C[e] = ok ? in.C[q] : 0u;
+    if (LOW) { LB[e] = P[e] >> kFinLowShift; P[e] &= (1u << kFinLowShift) - 1u; }
     s_H[lp] = H[e];
     s_g[lp] = 0xFFFFu;
   }
@@ -863,15 +878,43 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
       else if (a >= 0 && a < kFinStride) { A[e] = a; G[e] = g; }
     }
   }
-  // characters of the members this workgroup settles
+  // characters of the members this workgroup settles (LOW: of those that share their bits with another member)
+  // Per group two flags per value of the bits, in the group's first window position (s_H is free by now): "seen" and
+  // "seen again" -- one or two LDS atomics per member instead of a walk over its group.
+  u32 need = 0xFFFFFFFFu;
+  if (LOW) {
+    __syncthreads();                                   // s_H's last readers (the group sizes) are done
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) s_H[tid + (u32)e * kFinTPB] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) {
+      if (A[e] >= 0) {
+        const u32 bit = 1u << LB[LOW ? e : 0];
+        if (atomicOr(&s_H[A[e]], bit) & bit) atomicOr(&s_H[A[e]], bit << 8);
+      }
+    }
+    __syncthreads();
+    need = 0;
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e)
+      if (A[e] >= 0 && ((s_H[A[e]] >> (8u + LB[LOW ? e : 0])) & 1u)) need |= 1u << e;
+  }
   u64 c0[kFinE], c1[kFinE];
 #pragma unroll
-  for (int e = 0; e < kFinE; ++e) { c0[e] = 0; c1[e] = 0; if (A[e] >= 0) fin_chars(T, S[e] + h, n, &c0[e], &c1[e]); }
+  for (int e = 0; e < kFinE; ++e) {
+    c0[e] = 0; c1[e] = 0;
+    if (A[e] >= 0 && ((need >> e) & 1u)) fin_chars(T, S[e] + h, n, &c0[e], &c1[e]);
+    if (LOW) {                                         // the bits above fifteen characters, as one 128-bit key
+      c1[e] = (c0[e] << 61) | ((c1[e] & ~0xFFull) >> 3);
+      c0[e] = ((u64)LB[LOW ? e : 0] << 61) | (c0[e] >> 3);
+    }
+  }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     if (A[e] >= 0) {
       const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 touch = ((u64)S[e] + h + kFinChars > (u64)n) ? 0x80000000u : 0u;
+      const u32 touch = ((u64)S[e] + h + (LOW ? kFinChars - 1u : kFinChars) > (u64)n) ? 0x80000000u : 0u;
       s_ch[2u * lp] = c0[e]; s_ch[2u * lp + 1u] = c1[e];
       s_S[lp] = S[e] | touch;
     }
@@ -967,11 +1010,11 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
 // (key = head slot | character << 56, value = suffix, positional slot array), and rank[] is completed
 // for everybody: rank[SA[slot]] = slot for the finished, the group's head slot for the others.
 __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __restrict__ hardS,
-                                                     u64* __restrict__ hardHP, u32 at) {
+                                                     u64* __restrict__ hardHP, u32 at, u32 slot_mask) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= m) return;
   hardS[at + i] = in.S[i];
-  hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)in.P[i];
+  hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)(in.P[i] & slot_mask);      // (a list no finisher pass has seen may still carry w's low bits)
 }
 __global__ __launch_bounds__(256) void k_bridge_dress(const u64* __restrict__ hp, const u32* __restrict__ sfx, u32 m,
                                                       const u8* __restrict__ T, u64* __restrict__ key,
@@ -1352,7 +1395,9 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     }
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
-    if (std::getenv("BWTC_HIP_FIN_GROUP")) fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP"));
+    if (std::getenv("BWTC_HIP_FIN_GROUP")) { fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP")); fin_fixed = true; }
+    if (std::getenv("BWTC_HIP_FIN_WINDOW")) { fin_window = std::atoi(std::getenv("BWTC_HIP_FIN_WINDOW")); fin_fixed = true; }
+    if (fin_fixed && fin_max_group >= fin_window) fin_max_group = fin_window / 2;
     if (std::getenv("BWTC_HIP_LONG_DROP")) long_drop = std::max(0, std::atoi(std::getenv("BWTC_HIP_LONG_DROP")));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
     gm_partition_lines = std::getenv("BWTC_HIP_GM_PARTITION") && std::strcmp(std::getenv("BWTC_HIP_GM_PARTITION"), "lines") == 0;
@@ -1927,11 +1972,12 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       // the finisher's reads cost more than the pass saves: 1 GiB text 127.8 ms against 117.4), and not while the
       // stream's blocks keep coming back with long lists (drop_paused, below).
       int drop = 0;
-      if (long_drop > 0 && long_drop < gp.b && split && !drop_paused) {
+      if (long_drop > 0 && long_drop <= 3 && long_drop < gp.b && split && n < (1u << kFinLowShift) && !drop_paused) {
         const int all = key_bits + gp.b * lk.G2;
         if ((all - long_drop + kRadixBits - 1) / kRadixBits < (all + kRadixBits - 1) / kRadixBits) drop = long_drop;
       }
       lk.drop = drop;
+      fin_low_len = drop ? (u32)(gp.g * (gp.G + lk.G2)) : 0u;
       const int w_bits = gp.b * lk.G2 - drop;
       if (w_bits < kRadixBits) { lk.first_r = w_bits; lk.first_mask = (1u << std::min(kRadixBits, w_bits + key_bits)) - 1u; }
       short_len = (u32)(gp.g * (gp.G + lk.G2 - (drop ? 1 : 0)));
@@ -1941,19 +1987,19 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
       u32* vs32 = nullptr;
       if (!split)
-        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1);
+        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1, drop);
       else if (long_items_per_thread == 6)
         radix_sort_long<unsigned short, 6>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, drop);
       else
         radix_sort_long<unsigned short, 8>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, drop);
       BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
       u32* vs = split ? reinterpret_cast<u32*>(vs16) : vs32;
       rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
       rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
       RrLong lg;
-      lg.w = ws; lg.wmask = w_bits >= 32 ? ~0u : (1u << w_bits) - 1u;
+      lg.w = ws; lg.wmask = (w_bits >= 32 ? ~0u : (1u << w_bits) - 1u) << drop; lg.lowmask = (1u << drop) - 1u;
       lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask; lg.dropped = drop;
       if (std::getenv("BWTC_HIP_DEBUG"))
         std::fprintf(stderr, "long keys: %d + %d bits (%d dropped), %d + %d grams of %d characters, character code at bit %d\n",
@@ -2027,7 +2073,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
     u32 m2 = 0; u64 h2 = 0;
-    rc = finish_list(n, m, short_len, rb, re, &res, &m2, &h2);
+    rc = finish_list(n, m, short_len, fin_low_len, rb, re, &res, &m2, &h2);
     if (rc) return rc;
     m = m2;
     if (m) { h = h2; keep_h = true; text_left = text_rounds; ranks_complete = false; }
@@ -2074,7 +2120,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 // The finisher passes over the list the long-key ranking left (k_finish), and -- when something is
 // still tied after them, or a group was too large for them -- the bridge into the doubling rounds.
 // On return *m_out entries (0: all done) wait in res / rb as a sorted list of depth *h_out.
-int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
+// low_len > 0: the list's slot words carry the bits of w the sort left out (k_finish, LOW): the first pass orders by them
+// and by the sixteen characters from low_len on -- the depth of the whole grams -- while `depth` is what the list's
+// groups are known to share.
+int BwtEngine::finish_list(u32 n, u32 m, u32 depth, u32 low_len, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
   hipStream_t st = stream;
   u32* cnt = d_small + kSmallFin;                      // [0] next list, [1] hard list
   FinList a{rb.v_free, rb.aglob_next, d_GRP, re.achr_out};
@@ -2083,7 +2132,21 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
   u32* hardS = rb.v_keys;
   BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
   u32 hard = 0, hard_depth = depth;
+  bool low_pending = low_len > 0;
+  // The window and the largest group settled here.  Small windows keep more workgroups on a CU (27 KiB of LDS instead
+  // of 54: the 256 MiB text block 23.1 ms with 1024 / 256 against 25.4 with 2048 / 1024), but every group above the
+  // bound goes to the text rounds, which cost some 9 us per thousand entries (1 GiB text: 1.76 M such entries with
+  // 256, +16 ms; with 512 it gains 4 ms).  So: 256 below 2^29 suffixes and 512 above, one step up for the stream's
+  // next blocks when more than n / 1024 entries went that way, one step back when fewer than n / 8192 did.
+  // BWTC_HIP_FIN_WINDOW / BWTC_HIP_FIN_GROUP fix both.
+  int window = fin_window, group = fin_max_group;
+  if (!fin_fixed) {
+    if (fin_group_now == 0) fin_group_now = n < (1u << 29) ? 256 : 512;
+    group = fin_group_now;
+    window = group <= 512 ? 1024 : 2048;
+  }
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
+    const u32 from = low_pending ? low_len : depth;      // where this pass reads the text
     ++stats.rounds;
     stats.active_sum += m;
     stats.finisher_entries += m;
@@ -2094,26 +2157,38 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, RankBuffers& rb, RrEmit& re,
     BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
     // (a workgroup settles the groups that start in the first kFinWin - G entries of its window: the smaller the largest
     // group it takes, the more of its lanes have work -- and the more entries go to the text rounds instead)
-#define BWTC_FINISH(G) hipLaunchKernelGGL(k_finish<G>, dim3(ceil_div(m, (u32)(kFinWin - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, depth, \
-                                          b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
-    if (fin_max_group <= 256) BWTC_FINISH(256); else if (fin_max_group <= 512) BWTC_FINISH(512); else BWTC_FINISH(1024);
+#define BWTC_FINISH(G, L, E) hipLaunchKernelGGL((k_finish<G, L, E>), dim3(ceil_div(m, (u32)(kFinTPB * E - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, from, \
+                                                b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
+#define BWTC_FINISH_L(G, E) do { if (low_pending) BWTC_FINISH(G, true, E); else BWTC_FINISH(G, false, E); } while (0)
+    if (window <= 1024) { if (group <= 256) BWTC_FINISH_L(256, 4); else BWTC_FINISH_L(512, 4); }
+    else if (group <= 256) BWTC_FINISH_L(256, 8);
+    else if (group <= 512) BWTC_FINISH_L(512, 8);
+    else BWTC_FINISH_L(1024, 8);
+#undef BWTC_FINISH_L
 #undef BWTC_FINISH
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 8, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
     if (std::getenv("BWTC_HIP_DEBUG"))
-      std::fprintf(stderr, "finisher pass %d: depth %u, %u entries -> %u still tied, %u hard\n", it, depth, m,
-                   h_small[kSmallFin], h_small[kSmallFin + 1]);
+      std::fprintf(stderr, "finisher pass %d: depth %u%s, %u entries -> %u still tied, %u hard\n", it, depth,
+                   low_pending ? " (+ the last gram's low bits)" : "", m, h_small[kSmallFin], h_small[kSmallFin + 1]);
     m = h_small[kSmallFin];
-    if (hard == 0 && h_small[kSmallFin + 1]) hard_depth = depth;
+    if (hard == 0 && h_small[kSmallFin + 1]) hard_depth = depth;       // (a hard group's members share `depth` characters, low bits or not)
     hard = h_small[kSmallFin + 1];
-    depth += kFinChars;
+    if (it == 0 && !fin_fixed) {
+      const int base = n < (1u << 29) ? 256 : 512;
+      if ((u64)hard * 1024 > (u64)n && fin_group_now < 1024) fin_group_now *= 2;
+      else if ((u64)hard * 8192 < (u64)n && fin_group_now > base) fin_group_now /= 2;
+    }
+    depth = from + (low_pending ? kFinChars - 1u : kFinChars);      // (the low bits take the place of the sixteenth character)
+    low_pending = false;
     std::swap(a, b);
   }
   *m_out = 0;
   if (m == 0 && hard == 0) return 0;
   // ---- what is still tied becomes a list the rounds understand: sorted by slot (groups contiguous,
   // a positional slot array), key = head slot | character << 56, value = suffix
-  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard);
+  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard,
+                            low_pending ? (1u << kFinLowShift) - 1u : 0xFFFFFFFFu);
   const u32 total = hard + m;
   if ((u64)total > cap) return -3;
   u64* hp_sorted = nullptr; u32* s_sorted = nullptr;

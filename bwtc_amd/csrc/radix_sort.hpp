@@ -484,7 +484,8 @@ static inline void radix_sort_keys_segmented(u32* k0, u32* k1, u64 n, int bit_lo
 template <typename V, int EL = 8>
 static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32* w1, u64 n, int kbits, int wbits,
                                    u32* table, u32* partial, hipStream_t st, u64** k_sorted, V** v_sorted,
-                                   u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1) {
+                                   u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1, int wlo = 0) {
+  // wlo: w's lowest bits that do NOT take part in the order (the sorted bits are [wlo, wlo + wbits))
   u64 *kin = k0, *kout = k1;
   V *vin = v0, *vout = v1;
   u32 *win = w0, *wout = w1;
@@ -492,11 +493,11 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
   Pass ps[24];
   int np = 0;
   int s = 0;
-  for (; s + kRadixBits <= wbits; s += kRadixBits) ps[np++] = Pass{1, s, (1u << kRadixBits) - 1u, 0};
+  for (; s + kRadixBits <= wbits; s += kRadixBits) ps[np++] = Pass{1, wlo + s, (1u << kRadixBits) - 1u, 0};
   int ks = 0;
   if (s < wbits) {
     const int r = wbits - s;                                     // w bits left: the bridge digit's low bits
-    ps[np++] = Pass{2, s, (1u << std::min(kRadixBits, r + kbits)) - 1u, r};
+    ps[np++] = Pass{2, wlo + s, (1u << std::min(kRadixBits, r + kbits)) - 1u, r};
     ks = std::min(kbits, kRadixBits - r);
   }
   for (; ks < kbits; ks += kRadixBits) ps[np++] = Pass{0, ks, (1u << std::min(kRadixBits, kbits - ks)) - 1u, 0};

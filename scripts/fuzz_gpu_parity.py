@@ -166,11 +166,12 @@ def main():
     # through the device sweeps.
     t0, n6 = time.time(), 0
     variants = [{}, {"BWTC_HIP_FIN_PASSES": "1"}, {"BWTC_HIP_TEXT_ROUNDS": "1"}, {"BWTC_HIP_FIN_PASSES": "0", "BWTC_HIP_TEXT_ROUNDS": "0"},
-                {"BWTC_HIP_LONG_G2": "1"}, {"BWTC_HIP_FINISHER": "0"}, {"BWTC_HIP_TEXT_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "2"}]
+                {"BWTC_HIP_LONG_G2": "1"}, {"BWTC_HIP_FINISHER": "0"}, {"BWTC_HIP_TEXT_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "2"},
+                {"BWTC_HIP_LONG_DROP": "0"}, {"BWTC_HIP_LONG_DROP": "2", "BWTC_HIP_FIN_GROUP": "256"}, {"BWTC_HIP_LONG_DROP": "1", "BWTC_HIP_FIN_PASSES": "0"}]
     while "6" in phases and time.time() - t0 < budget:
         var = variants[n6 % len(variants)]
         os.environ["BWTC_HIP_GRAM_MIN_N"] = "64"
-        for k in ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER"):
+        for k in ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_LONG_DROP", "BWTC_HIP_FIN_GROUP"):
             os.environ.pop(k, None)
         os.environ.update(var)
         with hip.Context(device=0, max_block_size=(4 << 20) + 64) as c6:
@@ -222,7 +223,7 @@ def main():
                         print("MISMATCH phase 6 prepr: size", n, "sigma", sigma, "options", opts, flush=True)
                         np.save(os.path.join(ROOT, "gpurun_out", "fuzz6_prepr_fail_%d.npy" % n6), d)
                 n6 += 1
-    for k in ("BWTC_HIP_GRAM_MIN_N", "BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER"):
+    for k in ("BWTC_HIP_GRAM_MIN_N", "BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_LONG_DROP", "BWTC_HIP_FIN_GROUP"):
         os.environ.pop(k, None)
     print("phase 6: %d blocks on the long-key route (and through the pre-stage)" % n6, flush=True)
     print("mismatches:", bad, flush=True)

@@ -346,9 +346,11 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0",
                                     # the last gram's low bits in the sort (default: three of them left out, nine passes
                                     # instead of ten), and more of them left out than pays
-                                    "BWTC_HIP_LONG_DROP=0", "BWTC_HIP_LONG_DROP=7", "BWTC_HIP_LONG_DROP=11,BWTC_HIP_TEXT_ROUNDS=1",
+                                    "BWTC_HIP_LONG_DROP=0", "BWTC_HIP_LONG_DROP=2", "BWTC_HIP_LONG_DROP=1,BWTC_HIP_TEXT_ROUNDS=1",
+                                    "BWTC_HIP_LONG_DROP=3,BWTC_HIP_FIN_PASSES=0", "BWTC_HIP_LONG_DROP=3,BWTC_HIP_FIN_PASSES=1,BWTC_HIP_TEXT_ROUNDS=0",
                                     # the finisher settling only the smaller groups (the others take the text rounds)
-                                    "BWTC_HIP_FIN_GROUP=256", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_LONG_DROP=0"])
+                                    "BWTC_HIP_FIN_GROUP=1024", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_LONG_DROP=0", "BWTC_HIP_FIN_WINDOW=1024,BWTC_HIP_FIN_GROUP=512",
+                                    "BWTC_HIP_FIN_WINDOW=2048,BWTC_HIP_FIN_GROUP=256"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
