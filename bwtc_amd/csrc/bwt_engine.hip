@@ -1406,7 +1406,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_GRAM_MIN_N")) gram_min_n = (u32)std::max(64, std::atoi(std::getenv("BWTC_HIP_GRAM_MIN_N")));   // tests: small blocks through the gram / long-key routes
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
-    if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS")));
+    if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
   }
@@ -2069,6 +2069,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   u32 m = res.m;
   bool keep_h = false;                     // the list is sorted to depth h as it stands (no doubling before the next step)
   int text_left = 0;                       // rounds that compare the text itself (finisher route, rank[] incomplete)
+  int text_extra = text_rounds_fixed ? 0 : 12;        // further ones, one at a time, while the list is short (not when BWTC_HIP_TEXT_ROUNDS says how many)
   bool ranks_complete = true;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
@@ -2110,7 +2111,14 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     rc = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text, carried);
     if (rc) return rc;
     m = res.m;
-    if (text) { h += res.text_chars; keep_h = true; --text_left; }
+    if (text) {
+      h += res.text_chars; keep_h = true; --text_left;
+      // Out of text rounds with a short list left: a few more cost tens of microseconds each, the doubling rounds
+      // cost the completion of rank[] for the whole block first (5 ms per 256 MiB, 16 ms for the 1 GiB text -- the
+      // block whose text rounds ended with 10 entries still tied paid it).  Long lists (deep repeats) go on to the
+      // doubling rounds as before: their depth doubles there and only creeps here.
+      if (text_left == 0 && m > 0 && (u64)m * 4096 < (u64)n && text_extra > 0) { text_left = 1; --text_extra; }
+    }
   }
   BWTC_HIP_TRY(hipGetLastError());
   BWTC_HIP_TRY(take_sticky_error());
@@ -2134,10 +2142,9 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, u32 low_len, RankBuffers& rb
   u32 hard = 0, hard_depth = depth;
   bool low_pending = low_len > 0;
   // The window and the largest group settled here.  Small windows keep more workgroups on a CU (27 KiB of LDS instead
-  // of 54: the 256 MiB text block 23.1 ms with 1024 / 256 against 25.4 with 2048 / 1024), but every group above the
-  // bound goes to the text rounds, which cost some 9 us per thousand entries (1 GiB text: 1.76 M such entries with
-  // 256, +16 ms; with 512 it gains 4 ms).  So: 256 below 2^29 suffixes and 512 above, one step up for the stream's
-  // next blocks when more than n / 1024 entries went that way, one step back when fewer than n / 8192 did.
+  // of 54: the 256 MiB text block 23.1 ms with 1024 / 256 against 25.4 with 2048 / 1024); every group above the bound
+  // goes to the text rounds.  So: 256 below 2^29 suffixes and 512 above, one step up for the stream's next blocks when
+  // more than n / 1024 entries went that way, one step back when fewer than n / 8192 did.
   // BWTC_HIP_FIN_WINDOW / BWTC_HIP_FIN_GROUP fix both.
   int window = fin_window, group = fin_max_group;
   if (!fin_fixed) {

@@ -408,6 +408,7 @@ struct BwtEngine {
   int fin_max_group = 1024;  // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
   int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
+  bool text_rounds_fixed = false;
   bool fin_active = false;   // this block takes the finisher route: finished suffixes also go to d_SA
   bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
