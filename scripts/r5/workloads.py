@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Round 5: the transform's rate on real inputs -- one JSON line per workload: rounds, R_eff, route, device ms.
+usage: workloads.py [MiB] [kind ...]      (BWTC_HIP_DEBUG=1 prints the sorter's own trace)
+kinds: those of scripts/r4/workloads.py, plus
+  pycorpus   the largest real text of the image: every .py file under the Python library directories
+             (302 MB: standard library, torch, transformers, ...), in sorted walk order, cut at the block size"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts", "r4"))
+from bwtc_amd import hip  # noqa: E402
+import workloads as r4  # noqa: E402
+
+PY_ROOTS = ("/usr/lib/python3", "/usr/lib/python3.10", "/usr/local/lib/python3.10")
+
+
+def py_corpus(limit):
+    """Every .py file of the image's Python library directories, each real file once, sorted walk order."""
+    path = os.environ.get("BWTC_CORPUS")
+    if path and os.path.exists(path):
+        with open(path, "rb") as f:
+            return np.frombuffer(f.read(limit), np.uint8), "BWTC_CORPUS=%s" % path
+    buf = bytearray()
+    seen = set()
+    files = 0
+    for root in PY_ROOTS:
+        for dirpath, dirnames, filenames in os.walk(root):
+            dirnames[:] = sorted(d for d in dirnames if d != "__pycache__")
+            for name in sorted(filenames):
+                if len(buf) >= limit:
+                    break
+                if not name.endswith(".py"):
+                    continue
+                p = os.path.join(dirpath, name)
+                rp = os.path.realpath(p)
+                if rp in seen:
+                    continue
+                seen.add(rp)
+                try:
+                    with open(p, "rb") as f:
+                        buf += f.read(limit - len(buf))
+                        files += 1
+                except OSError:
+                    pass
+    return np.frombuffer(bytes(buf[:limit]), np.uint8), "%d .py files of the image's Python libraries (%s), sorted walk order" % (files, ", ".join(PY_ROOTS))
+
+
+def gen(kind, n):
+    if kind == "pycorpus":
+        d, what = py_corpus(n)
+        if d.size < n:
+            d = np.tile(d, n // d.size + 1)[:n]
+            what += " (repeated to size)"
+        return d.copy(), what
+    return r4.gen(kind, n)
+
+
+def main():
+    args = sys.argv[1:]
+    mib = int(args[0]) if args and args[0].isdigit() else 256
+    kinds = [a for a in args if not a.isdigit()] or ["c3", "realtext", "pycorpus"]
+    n = mib << 20
+    reps = int(os.environ.get("REPS", "3"))
+    ctx = hip.Context(0, n)
+    d_in, d_out = ctx.dmalloc(n + 64), ctx.dmalloc(n + 64)
+    blk = ctx.host_alloc(n)
+    for kind in kinds:
+        data, what = gen(kind, n)
+        blk[:] = data
+        best = None
+        for rep in range(reps):
+            ctx.to_device_async(d_in, blk)
+            ctx.copy_wait()
+            ctx.bwt_block_device(d_in, d_out, n, 8)
+            st = ctx.stats()
+            if best is None or st.ms_total < best.ms_total:
+                best = hip.Stats.from_buffer_copy(bytes(st))
+        line = {"workload": kind, "what": what, "MiB": mib, "sigma": int(np.count_nonzero(np.bincount(data, minlength=256))),
+                "device_ms_bwt": round(best.ms_total, 2),
+                "MBps": round(n / 1e6 / (best.ms_total * 1e-3), 1), "rounds": best.rounds,
+                "R_eff": round(best.active_sum / best.n, 3), "sort_passes_per_suffix": round(best.sort_pass_items / best.n, 1),
+                "route": best.route, "alg_GB": round(best.alg_bytes / 1e9, 1),
+                "alg_frac_of_8TBps": round(best.alg_bytes / (best.ms_total * 1e-3) / 8e12, 3)}
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
