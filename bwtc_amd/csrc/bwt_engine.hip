@@ -23,7 +23,7 @@ namespace bwtc_hip {
 // ---------------------------------------------------------------------------------------
 constexpr int kLoadTPB = 256;
 constexpr int kLoadTile = kLoadTPB * 16;
-constexpr u32 kTextPad = 64;   // zero bytes guaranteed after T[n-1]
+constexpr u32 kTextPad = 128;  // zero bytes guaranteed after T[n-1] (a code key looks at up to 74 characters of a suffix)
 
 __global__ __launch_bounds__(kLoadTPB) void k_load_hist(const u8* __restrict__ src,
                                                         u8* __restrict__ T, u32 ncopy,
@@ -310,7 +310,6 @@ __device__ __forceinline__ u32 gram_code(const uint4* __restrict__ table, u32 v)
 // characters and the ranking behind it can emit the transform's bytes without going back to T.
 struct LongKey {
   u32* w; int G2;                // make: where the second words go, grams per word
-  int drop;                      // the sort leaves out the second word's lowest `drop` bits (see BwtEngine::long_drop)
   int first_r; u32 first_mask;   // a second word of fewer than eight bits: the sort's first digit is the bridge digit
                                  // (radix_sort_long), w under the key's lowest bits; first_r = w's bits, -1: the digit is w's
   int hi_shift;                  // key bits [hi_shift, hi_shift + 13): the upper bits of the suffix number
@@ -381,9 +380,241 @@ __global__ __launch_bounds__(256) void k_make_keys_gram(const u8* __restrict__ T
     if (lk.w) {
       const u32 w = s_w[j];
       lk.w[J0 + j] = w;
-      const u32 ws = w >> lk.drop;                    // the bits the sort orders by
-      if (plane) plane[J0 + j] = lk.first_r < 0 ? (u8)ws : (u8)((ws | ((u32)key << lk.first_r)) & lk.first_mask);   // the long sort's first digit
+      if (plane) plane[J0 + j] = lk.first_r < 0 ? (u8)w : (u8)((w | ((u32)key << lk.first_r)) & lk.first_mask);   // the long sort's first digit
     } else if (plane) plane[J0 + j] = (u8)s_key[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2c initial keys from an order-preserving prefix code ("code keys", round 5).
+//
+//     Dense gram codes pack a fixed number of characters into the key: 20 of the 64-token generator's 40
+//     symbols, but 12 of a real text's 170-210 -- and, worse, the same 12 of a string that occurs a
+//     million times as of one that occurs twice, so that the frequent strings' groups stay huge.  Here
+//     every character is written with a prefix code that depends on the character before it (an order-1
+//     model of the block, taken from a sample of its character pairs), and a suffix's key is the first
+//     kbits bits of its code string: frequent continuations cost few bits, so a frequent string gets MORE
+//     of its characters into the key and the groups the sort leaves are levelled out (256 MiB of the
+//     generator's text: 2.6 % of the suffixes tied after 72 key bits, against 21.5 % after 20 characters).
+//
+//     Order.  For every context the code is alphabetic (codewords in symbol order, prefix free: a
+//     weight-balanced binary tree over the symbols, k_code_build), so two suffixes that first differ at
+//     character j -- whose context, character j-1, they share -- have equal code strings up to that
+//     character's codeword and differ there in symbol order: the code strings compare as the suffixes do,
+//     and so do their first kbits bits (with ties).  A suffix's first character has no context inside the
+//     suffix: it takes the order-0 code (row 256 of the table).  The terminator and the padding behind it
+//     are symbol 0 (or share the smallest symbol's code, as in k_make_keys): the smallest continuation.
+//
+//     Depth.  Suffixes with equal keys share the key's COMPLETE codewords (the same bits decode the same
+//     way), k characters, a number that differs from key to key.  The item carries it as a 3-bit level
+//     (a lower bound: kCodeLevelDepth) in spare key bits; the ranking hands it on to the finisher, which
+//     compares the text from there.
+//
+//     All codewords of the block's text are one bit string (a character's codeword does not depend on
+//     which suffix it is read for), so a tile looks its characters' codewords up ONCE, scans their
+//     lengths, writes the bits into LDS, and every suffix key is 72 bits cut out of that string at the
+//     suffix's second character, behind its first character's order-0 codeword.
+// ---------------------------------------------------------------------------------------
+constexpr u32 kCodeRows = 257;                // contexts 0..255, and the order-0 row
+constexpr u32 kCodeOrder0 = 256;
+constexpr u32 kCodeMaxLen = 26;               // longest codeword k_code_build may make (27 code bits + 5 length bits per entry)
+constexpr u32 kCodeLA = 72;                   // characters a tile looks ahead: a key has at most 72 bits, a codeword at least one
+constexpr u32 kPairReplicas = 8;              // copies of the pair counters (hot pairs: one address per XCD-worth of workgroups)
+constexpr u32 kPairTile = 4096;
+// the level's depth: suffixes with equal keys of that level share at least so many characters
+__host__ __device__ __forceinline__ u32 code_level_depth(u32 level) { return (u32)((0x30201814100C0801ull >> (8u * level)) & 255ull); }
+__device__ __forceinline__ u32 code_level_of(u32 k) {
+  return k >= 48u ? 7u : k >= 32u ? 6u : k >= 24u ? 5u : k >= 20u ? 4u : k >= 16u ? 3u : k >= 12u ? 2u : k >= 8u ? 1u : 0u;
+}
+
+// Character pairs of a sample of the text: workgroup b counts the pairs of tile floor(b * ntiles / gridDim).
+// cnt[replica][a * 256 + b] over dense codes; pair (T[j-1], T[j]).
+__global__ __launch_bounds__(256) void k_pair_counts(const u8* __restrict__ T, const u8* __restrict__ lut, u32 n,
+                                                     u32* __restrict__ cnt) {
+  __shared__ u8 s_lut[256];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const u32 ntiles = (n + kPairTile - 1u) / kPairTile;
+  const u32 tile = (u32)(((u64)blockIdx.x * ntiles) / gridDim.x);
+  const u32 j0 = tile * kPairTile + 16u * threadIdx.x;
+  if (j0 >= n) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(T + j0);          // T is padded by more than a tile
+  const u32 w[4] = {v.x, v.y, v.z, v.w};
+  u32 prev = j0 ? s_lut[T[j0 - 1u]] : 0u;
+  u32* mine = cnt + (size_t)(blockIdx.x % kPairReplicas) * 65536u;
+#pragma unroll
+  for (u32 e = 0; e < 16u; ++e) {
+    const u32 c = s_lut[(w[e >> 2] >> (8u * (e & 3u))) & 255u];
+    if (j0 + e < n && j0 + e > 0u) atomicAdd(&mine[prev * 256u + c], 1u);
+    prev = c;
+  }
+}
+
+// One workgroup per context (row 256: all contexts together, the order-0 code): the alphabetic code of the
+// sigma symbols for the weights count + 1 (every symbol can follow every context: unseen pairs get long
+// codewords, not none).  Weight-balanced tree: an interval of symbols is cut where the two sides' weights
+// differ least; every symbol walks down from the root on its own (the cuts it computes are the ones its
+// neighbours compute).  codes[row * 256 + symbol] = length << 27 | bits.  Weights are scaled to sum below
+// 2^16 + sigma: no codeword is longer than kCodeMaxLen (checked: *err is raised otherwise).
+__global__ __launch_bounds__(256) void k_code_build(const u32* __restrict__ cnt, u32 sigma, u32* __restrict__ codes,
+                                                    u32* __restrict__ err) {
+  __shared__ u32 s_pre[257];
+  __shared__ u32 scr[256 / kWave + 1];
+  const u32 row = blockIdx.x, b = threadIdx.x;
+  u32 c = 0;
+  if (b < sigma) {
+    if (row < 256u) {
+      for (u32 r = 0; r < kPairReplicas; ++r) c += cnt[(size_t)r * 65536u + row * 256u + b];
+    } else {
+      for (u32 a = 0; a < sigma; ++a)
+        for (u32 r = 0; r < kPairReplicas; ++r) c += cnt[(size_t)r * 65536u + a * 256u + b];
+    }
+  }
+  u32 total;
+  (void)block_scan_excl_add<256>(c, scr, &total);
+  u32 sh = 0;
+  while ((total >> sh) >= 65536u) ++sh;
+  const u32 wt = b < sigma ? (c >> sh) + 1u : 0u;
+  u32 wtot;
+  const u32 ex = block_scan_excl_add<256>(wt, scr, &wtot);
+  s_pre[b] = ex;
+  if (b == 255u) s_pre[256] = wtot;
+  __syncthreads();
+  if (b >= sigma) { codes[row * 256u + b] = 0u; return; }
+  u32 lo = 0, hi = sigma, bits = 0, len = 0;
+  while (hi - lo > 1u && len <= 31u) {
+    const u64 mid2 = (u64)s_pre[lo] + (u64)s_pre[hi];
+    u32 a = lo + 1u, z = hi - 1u;                       // smallest cut in [lo+1, hi-1] with 2 pre[cut] >= mid2, else hi-1
+    while (a < z) { const u32 mdl = (a + z) >> 1; if (2ull * s_pre[mdl] >= mid2) z = mdl; else a = mdl + 1u; }
+    u32 cut = a;
+    if (cut > lo + 1u) {
+      const u64 da = 2ull * s_pre[cut] >= mid2 ? 2ull * s_pre[cut] - mid2 : mid2 - 2ull * s_pre[cut];
+      const u64 db = mid2 - 2ull * s_pre[cut - 1u];       // 2 pre[cut-1] < mid2
+      if (db <= da) cut = cut - 1u;
+    }
+    if (b < cut) { hi = cut; bits <<= 1; } else { lo = cut; bits = (bits << 1) | 1u; }
+    ++len;
+  }
+  if (len == 0u) len = 1u;                              // (an alphabet of one symbol)
+  if (len > kCodeMaxLen) atomicOr(err, 2u);
+  codes[row * 256u + b] = (len << 27) | bits;
+}
+
+// keys of a tile of 1024 suffixes (slots in descending suffix order as in k_make_keys); kbits = key bits in all
+// (8 .. 72: the low 32 go to the second word w, the rest to the key word)
+struct CodeKey {
+  const u32* codes;              // k_code_build's table
+  int kbits;                     // key bits in all (33 .. 72)
+  int hi_shift, chr_shift, lvl_shift;   // key word: the upper bits of the suffix number (split items), the predecessor's code, the level
+};
+__global__ __launch_bounds__(256) void k_make_keys_code(const u8* __restrict__ T, const u8* __restrict__ lut,
+                                                        u64* __restrict__ keys, u32* __restrict__ wout, u32 n,
+                                                        u8* __restrict__ plane, int idx_hi, CodeKey ck) {
+  constexpr u32 kTile = 1024;
+  constexpr u32 kPos = 1280;                            // codeword positions a tile can hold (five per thread)
+  __shared__ u8 s_lut[256];
+  __shared__ u8 s_code[kTile + kCodeLA + 24];
+  __shared__ u32 s_c0[256];                             // the order-0 row
+  __shared__ u32 s_bp[kPos + 8];                        // bit offset of every position's codeword
+  __shared__ u32 s_bits[(kPos * kCodeMaxLen) / 32 + 8];
+  __shared__ u64 s_key[kTile];
+  __shared__ u32 s_w[kTile];
+  __shared__ u32 scr[256 / kWave + 1];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  s_c0[threadIdx.x] = ck.codes[kCodeOrder0 * 256u + threadIdx.x];
+  for (u32 i = threadIdx.x; i < (kPos * kCodeMaxLen) / 32 + 8; i += 256u) s_bits[i] = 0u;
+  __syncthreads();
+  const u32 J0 = blockIdx.x * kTile;
+  if (J0 >= n) return;
+  const u32 cntw = min(kTile, n - J0);
+  const u32 i_base = n - J0 - cntw;
+  const u32 pre = i_base > 0 ? 1u : 0u;
+  const u32 span = cntw + kCodeLA + 2u;                 // positions 0 .. span-1 of the tile's stretch of T
+  stage_codes(T, s_lut, s_code, i_base - pre, span + pre);
+  __syncthreads();
+  const u8* s_c = s_code + pre;                          // s_c[t] = code of T[i_base + t]
+  // codewords of positions 1 .. span-1 (position t in the context of t-1), five consecutive ones per thread
+  u32 cw[5];
+  const u32 t0 = 1u + 5u * threadIdx.x;
+#pragma unroll
+  for (u32 e = 0; e < 5u; ++e) {
+    const u32 t = t0 + e;
+    cw[e] = t < span ? ck.codes[(u32)s_c[t - 1u] * 256u + (u32)s_c[t]] : 0u;
+  }
+  u32 lsum = 0;
+#pragma unroll
+  for (u32 e = 0; e < 5u; ++e) lsum += cw[e] >> 27;
+  u32 total;
+  u32 bp = block_scan_excl_add<256>(lsum, scr, &total);
+#pragma unroll
+  for (u32 e = 0; e < 5u; ++e) {
+    const u32 t = t0 + e;
+    const u32 len = cw[e] >> 27, code = cw[e] & 0x7FFFFFFu;
+    if (t <= kPos) s_bp[t] = bp;
+    if (len) {
+      const u32 word = bp >> 5, off = bp & 31u;
+      if (off + len <= 32u) atomicOr(&s_bits[word], code << (32u - off - len));
+      else {
+        const u32 r = off + len - 32u;                  // bits that spill into the next word
+        atomicOr(&s_bits[word], code >> r);
+        atomicOr(&s_bits[word + 1u], code << (32u - r));
+      }
+    }
+    bp += len;
+  }
+  if (threadIdx.x == 0) s_bp[0] = 0u;
+  __syncthreads();
+  const u32 o = 4u * threadIdx.x;
+  if (o < cntw) {
+    const u32 cnt = min(4u, cntw - o);
+    for (u32 s = 0; s < cnt; ++s) {
+      const u32 t = o + s;
+      const u32 first = s_c0[s_c[t]];
+      const u32 l0 = first >> 27;
+      const u32 need = (u32)ck.kbits - l0;              // bits taken from the string, from position t+1 on
+      const u32 start = s_bp[t + 1u];
+      const u32 wi = start >> 5, off = start & 31u;
+      const u64 a = ((u64)s_bits[wi] << 32) | (u64)s_bits[wi + 1u];
+      const u64 bq = ((u64)s_bits[wi + 2u] << 32) | (u64)s_bits[wi + 3u];
+      const u64 top = off ? (a << off) | (bq >> (64u - off)) : a;             // bits start .. start+63
+      const u64 nxt = off ? (bq << off) : bq;                                // bits start+64 .. (at least 32 valid ones)
+      // the first `need` bits (need <= 71) as a number
+      u64 x_hi, x_lo;                                     // x = x_hi * 2^32 + (x_lo & 0xFFFFFFFF), x_lo = its low 32 bits
+      if (need <= 64u) {
+        const u64 x = need ? top >> (64u - need) : 0ull;
+        x_hi = x >> 32; x_lo = x & 0xFFFFFFFFull;
+      } else {
+        const u32 extra = need - 64u;                     // 1 .. 7 bits of nxt
+        const u64 lowpart = nxt >> (64u - extra);
+        x_lo = ((top << extra) | lowpart) & 0xFFFFFFFFull;
+        x_hi = (top >> (32u - extra));                    // top's upper bits: x >> 32
+      }
+      // key = first codeword * 2^need + x
+      const u64 fc = (u64)(first & 0x7FFFFFFu);
+      u64 k_hi, k_lo;                                     // key >> 32, key & 0xFFFFFFFF
+      if (need >= 32u) { k_lo = x_lo; k_hi = x_hi | (fc << (need - 32u)); }
+      else { const u64 full = (fc << need) | ((x_hi << 32) | x_lo); k_lo = full & 0xFFFFFFFFull; k_hi = full >> 32; }
+      // complete codewords in the key: the first character, and the positions j > t whose codeword ends inside
+      const u32 lim = start + need;
+      u32 lo = t + 1u, hi = min(t + 1u + kCodeLA, span - 1u);   // s_bp[j + 1] <= lim for j < answer
+      while (lo < hi) { const u32 mdl = (lo + hi) >> 1; if (s_bp[mdl + 1u] <= lim) lo = mdl + 1u; else hi = mdl; }
+      const u32 k = 1u + (lo - (t + 1u));
+      const u32 i = i_base + t;
+      u64 key = k_hi;
+      key |= (u64)(i ? (u32)s_c[(int)t - 1] : 0u) << ck.chr_shift;
+      key |= (u64)code_level_of(k) << ck.lvl_shift;
+      s_key[cntw - 1u - t] = key;
+      s_w[cntw - 1u - t] = (u32)k_lo;
+    }
+  }
+  __syncthreads();
+  for (u32 j = threadIdx.x; j < cntw; j += 256u) {
+    u64 key = s_key[j];
+    if (idx_hi) key |= (u64)((n - 1u - (J0 + j)) >> 16) << ck.hi_shift;
+    keys[J0 + j] = key;
+    const u32 w = s_w[j];
+    wout[J0 + j] = w;
+    if (plane) plane[J0 + j] = (u8)w;
   }
 }
 
@@ -436,10 +667,10 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // loaded on their own.
 // LONG (initial ranking after the long-key sort, radix_sort_long): a suffix's order key is (key & kmask,
 // w & wmask); the upper bits of its number sit at hi_shift, its predecessor character's code at chr_shift.
-// wmask: the bits of w the sort ordered by; lowmask: its lowest bits, which the sort left out (long_drop) -- they ride
-// to the finisher in the list entry's slot word (bits 29..31; such blocks have fewer than 2^29 suffixes)
-struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int dropped; u32 lowmask; };
-constexpr u32 kFinLowShift = 29;
+// wmask: the bits of w the sort ordered by.  How many characters the members of a group are known to share: code keys
+// carry a 3-bit level at lvl_shift (code_level_depth); gram keys (lvl_shift < 0) all share `depth`.  It rides to the
+// finisher in the upper byte of the list entry's 16-bit character field.
+struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int lvl_shift; u32 depth; };
 
 template <typename K, bool INIT, bool SPLIT, bool LONG = false>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
@@ -472,8 +703,8 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
       const u32 p = wbase + e * kWave + lane;
       f.sfx[e] = p < m ? suffix_of(kraw[e], word[e], p) : 0u;
       f.chr[e] = LONG ? ((u32)((u64)kraw[e] >> lg.chr_shift) & lg.chr_mask) : sizeof(K) == 8 ? (u32)((u64)kraw[e] >> 56) : 0u;
-      if (LONG) {                                   // the bits of w the sort left out, above the character's code
-        f.chr[e] |= (wc[LONG ? e : 0] & lg.lowmask) << 8;
+      if (LONG) {                                   // the depth its group is known to share, above the character's code
+        f.chr[e] |= (lg.lvl_shift >= 0 ? code_level_depth((u32)((u64)kraw[e] >> lg.lvl_shift) & 7u) : lg.depth) << 8;
         wc[LONG ? e : 0] &= lg.wmask;
       }
       kc[e] = kraw[e] & kmask;
@@ -516,9 +747,12 @@ __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* _
       wdiff_n = wme != wn;
     }
     bool h = ok && (p == 0 || kc[e] != kp || wdiff_p);
-    if (INIT) h = h || (ok && p > 0 && (u64)ip + short_len >= (u64)n);
+    // (long items: a suffix is known to lie inside its key when it is no longer than the key's depth; equal keys
+    // have equal depths, so the slot before counts with this one's)
+    const u32 sl = LONG ? f.chr[e] >> 8 : short_len;
+    if (INIT) h = h || (ok && p > 0 && (u64)ip + sl >= (u64)n);
     bool hn = (p + 1 >= m) || kn != kc[e] || wdiff_n;         // is p+1 a head (or past the end)?
-    if (INIT) hn = hn || ((u64)ic + short_len >= (u64)n);
+    if (INIT) hn = hn || ((u64)ic + sl >= (u64)n);
     f.head[e] = __ballot(h);
     f.valid[e] = __ballot(ok);
     f.act[e] = __ballot(ok && (!h || !hn));
@@ -745,11 +979,12 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
       else if (MODE == 0) { if (rank) rank[s] = nr; }
       if (a) {
         const u32 q = qs[e];
-        aglob_out[q] = (MODE == 3 && LONG) ? g | ((f.chr[e] >> 8) << kFinLowShift) : g;
+        aglob_out[q] = g;
         if (MODE != 2) {
           aidx_out[q] = s;
           agrp_out[q] = MODE == 3 ? nr : grp;
-          if (EMIT) em.achr_out[q] = (u8)c;
+          if (MODE == 3) reinterpret_cast<unsigned short*>(em.achr_out)[q] = (unsigned short)(c | (f.chr[e] & 0xFF00u));   // character, known depth
+          else if (EMIT) em.achr_out[q] = (u8)c;
         }
       } else {
         if (SA) SA[g] = s;
@@ -766,32 +1001,39 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 
 
 // ---------------------------------------------------------------------------------------
-// Finisher (after the long-key sort): the suffixes that are still tied at depth h form small
-// groups -- a few tens of millions of suffixes in groups of two to a few hundred for a text
-// block, where prefix doubling would first have to complete rank[] for ALL suffixes (an ISA
-// scatter of the whole block) before it could look at rank[s+h].  Here a group is settled by
-// comparing its members' next kFinChars characters directly: the list entry of a suffix is
-// (suffix, slot, slot of its group's head, predecessor character), groups are contiguous in the
-// list; a workgroup stages the characters of the groups it owns in LDS and every member counts
-// the members below it and equal to it.  A member without equals is final: out[slot], SA[slot],
-// the LF powers.  The others form the next list (their sub-group's head slot = old head + members
-// below), appended with one atomic per workgroup (the order of groups in the list is free).
+// Finisher (after the long-key sort): the suffixes that are still tied form groups -- contiguous in
+// slot order -- whose members are known to share `depth` characters (a number every list entry
+// carries: code keys cover more characters of a frequent string than of a rare one).  Prefix doubling
+// would first have to complete rank[] for ALL suffixes (an ISA scatter of the whole block) before it
+// could look at rank[s+h]; here a group is settled by comparing its members' next kFinChars characters
+// directly.  The list entry of a suffix is (suffix, slot, slot of its group's head, predecessor
+// character | depth << 8).
 //
-// A workgroup looks at a window of kFinWin consecutive entries and owns the groups that START
-// in its first kFinStride entries and have at most kFinMaxGroup members (so they lie inside the
-// window).  Larger groups are nobody's: their entries go to the "hard" list, appended by the
-// workgroup whose stride range they lie in, and take the doubling rounds (bridge, below).
-// "Proper prefix sorts first": characters past the end of T compare as zero bytes, and of two
-// members that are equal under that rule and of which one reaches past the end, the shorter
-// (larger suffix number) is the smaller -- they are never equal.
+// A workgroup looks at a window of kFinWin consecutive entries and owns the groups that START in its
+// first kFinWin - kFinMaxGroup entries and have at most kFinMaxGroup members (so they lie inside the
+// window).  It reads the owned members' characters (the route's one random access: three aligned words
+// of T per member) and sorts the WINDOW by (group, characters) with a bitonic network in LDS -- round 4
+// let every member count the members below it, a loop over its group: fine for the generator's groups
+// of two or three, quadratic for a real text's (a line that occurs 24 times makes groups of 24 for
+// every one of its suffixes: 33 comparisons per member on average, and the pass was no faster than the
+// doubling rounds it replaced).  The network costs the same 55 steps whatever the groups look like.
+// A group's members sit in the window where the group did (entries that are not this workgroup's to
+// settle sort as groups of their own, in place), so a member's new slot is its group's head slot plus
+// its place inside the group.  A member whose characters nobody shares is final: out[slot], SA[slot],
+// the LF powers.  The others form the next list in their new order (sub-group head = first member with
+// the same characters), sixteen characters deeper, appended with one atomic per workgroup.
+//
+// Larger groups are nobody's: their entries go to the "hard" list, appended by the workgroup whose
+// stride range they lie in, and take the text rounds / doubling rounds (bridge, below).
+// "Proper prefix sorts first": characters past the end of T compare as zero bytes, and of two members
+// that are equal under that rule and of which one reaches past the end, the shorter (larger suffix
+// number) is the smaller -- they are never equal (the network's comparison knows).
 // ---------------------------------------------------------------------------------------
 constexpr int kFinTPB = 256;
-// kFinE (template argument E_ of k_finish): entries per thread, 8 or 4; kFinWin = kFinTPB * kFinE: the window in LDS
-// kFinMaxGroup (template argument of k_finish; BwtEngine::fin_max_group picks 256, 512 or 1024): the largest group settled here
 constexpr u32 kFinChars = 16;                       // characters compared per pass
 constexpr u32 kFinNone = 0xFFFFFFFFu;
 
-struct FinList { u32* S; u32* P; u32* H; u8* C; };
+struct FinList { u32* S; u32* P; u32* H; unsigned short* C; };
 
 // sixteen characters T[pos .. pos+16) as two big-endian words; bytes at or past n read as zero
 __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32 n, u64* c0, u64* c1) {
@@ -811,41 +1053,35 @@ __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32
   *c1 = __builtin_bswap64(hi);
 }
 
-// LOW (first pass after a long sort that left out w's lowest bits): those bits ride in the top of every entry's slot
-// word and are the comparison's first key -- they order the last gram's characters -- with fifteen characters
-// behind the WHOLE grams (h) below them; a member alone with its bits inside its group needs no characters at all.
-template <int kFinMaxGroup, bool LOW, int E_ = 8>
-__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n, u32 h,
+// hard_count[0]: entries of the hard list, [1]: the smallest depth among them
+template <int kFinMaxGroup, int E_ = 4>
+__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n,
                                                     FinList next, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP,
                                                     u32* __restrict__ hard_count, u32* __restrict__ SA, RrEmit em) {
-  constexpr int kFinE = E_;                                           // entries per thread: a window of 2048 (54 KiB of LDS, two workgroups per CU) or 1024
+  constexpr int kFinE = E_;                                           // entries per thread: a window of 1024 or 2048
   constexpr int kFinWin = kFinTPB * kFinE;
   static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
+  static_assert((kFinWin & (kFinWin - 1)) == 0 && kFinWin <= 2048, "the network sorts a power of two; positions take 11 bits");
   constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
-  __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // 32 KiB; later the reorder staging
-  __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
-  __shared__ u32 s_H[kFinWin];
+  __shared__ u64 s_k0[kFinWin], s_k1[kFinWin];                        // the characters, by position
+  __shared__ u32 s_gi[kFinWin];                                       // group (window position of its first member) << 16 | owned << 15 | entry
+  __shared__ u32 s_S[kFinWin], s_P[kFinWin], s_H[kFinWin];            // the entries as loaded
+  __shared__ unsigned short s_C[kFinWin];
   __shared__ unsigned short s_g[kFinWin + 2];                         // group size by start position; [kFinWin]: the group cut by the window's start
   __shared__ u32 scr[kFinTPB / kWave + 1];
   __shared__ u32 s_base;
-  u32* st_S = reinterpret_cast<u32*>(s_ch);                           // staging, by new position
-  u32* st_P = st_S + kFinWin;
-  u32* st_H = st_P + kFinWin;                                         // | final << 31
-  u8* st_C = reinterpret_cast<u8*>(st_H + kFinWin);
   const u32 tid = threadIdx.x;
   const u32 w0 = blockIdx.x * (u32)kFinStride;
   const u32 lane = lane_id();
 
   u32 S[kFinE], P[kFinE], H[kFinE], C[kFinE];
-  u32 LB[LOW ? kFinE : 1] = {};                       // LOW: the bits of w the sort left out
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
     const bool ok = q < m;
     S[e] = ok ? in.S[q] : 0u; P[e] = ok ? in.P[q] : 0u; H[e] = ok ? in.H[q] : kFinNone; C[e] = ok ? in.C[q] : 0u;
-    if (LOW) { LB[e] = P[e] >> kFinLowShift; P[e] &= (1u << kFinLowShift) - 1u; }
-    s_H[lp] = H[e];
+    s_S[lp] = S[e]; s_P[lp] = P[e]; s_H[lp] = H[e]; s_C[lp] = (unsigned short)C[e];
     s_g[lp] = 0xFFFFu;
   }
   if (tid < 2) s_g[kFinWin + tid] = 0xFFFFu;
@@ -865,98 +1101,35 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
   }
   __syncthreads();
   int A[kFinE];                   // group start (window position), or -1: not this workgroup's to settle
-  u32 G[kFinE];
   u32 hard_mask = 0;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
-    A[e] = -1; G[e] = 0;
+    A[e] = -1;
     if (q < m) {
       const int a = (int)lp - (int)(P[e] - H[e]);
       const u32 g = (P[e] - H[e] < (u32)kFinMaxGroup) ? s_g[a >= 0 ? a : kFinWin] : 0xFFFFu;
       if (g == 0xFFFFu) { if (lp < (u32)kFinStride) hard_mask |= 1u << e; }
-      else if (a >= 0 && a < kFinStride) { A[e] = a; G[e] = g; }
+      else if (a >= 0 && a < kFinStride) A[e] = a;
     }
   }
-  // characters of the members this workgroup settles (LOW: of those that share their bits with another member)
-  // Per group two flags per value of the bits, in the group's first window position (s_H is free by now): "seen" and
-  // "seen again" -- one or two LDS atomics per member instead of a walk over its group.
-  u32 need = 0xFFFFFFFFu;
-  if (LOW) {
-    __syncthreads();                                   // s_H's last readers (the group sizes) are done
-#pragma unroll
-    for (int e = 0; e < kFinE; ++e) s_H[tid + (u32)e * kFinTPB] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kFinE; ++e) {
-      if (A[e] >= 0) {
-        const u32 bit = 1u << LB[LOW ? e : 0];
-        if (atomicOr(&s_H[A[e]], bit) & bit) atomicOr(&s_H[A[e]], bit << 8);
-      }
-    }
-    __syncthreads();
-    need = 0;
-#pragma unroll
-    for (int e = 0; e < kFinE; ++e)
-      if (A[e] >= 0 && ((s_H[A[e]] >> (8u + LB[LOW ? e : 0])) & 1u)) need |= 1u << e;
-  }
+  // characters of the members this workgroup settles
   u64 c0[kFinE], c1[kFinE];
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     c0[e] = 0; c1[e] = 0;
-    if (A[e] >= 0 && ((need >> e) & 1u)) fin_chars(T, S[e] + h, n, &c0[e], &c1[e]);
-    if (LOW) {                                         // the bits above fifteen characters, as one 128-bit key
-      c1[e] = (c0[e] << 61) | ((c1[e] & ~0xFFull) >> 3);
-      c0[e] = ((u64)LB[LOW ? e : 0] << 61) | (c0[e] >> 3);
-    }
+    if (A[e] >= 0) fin_chars(T, S[e] + (C[e] >> 8), n, &c0[e], &c1[e]);
   }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    if (A[e] >= 0) {
-      const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 touch = ((u64)S[e] + h + (LOW ? kFinChars - 1u : kFinChars) > (u64)n) ? 0x80000000u : 0u;
-      s_ch[2u * lp] = c0[e]; s_ch[2u * lp + 1u] = c1[e];
-      s_S[lp] = S[e] | touch;
-    }
-  }
-  __syncthreads();
-  u32 R[kFinE], Q[kFinE];         // members below; equal members before this one | all equal members << 16
-#pragma unroll
-  for (int e = 0; e < kFinE; ++e) {
-    R[e] = 0; Q[e] = 0;
-    if (A[e] >= 0) {
-      const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 me = s_S[lp];
-      u32 below = 0, eq_before = 0, eq_all = 0;
-      for (u32 j = (u32)A[e]; j < (u32)A[e] + G[e]; ++j) {
-        const u64 d0 = s_ch[2u * j], d1 = s_ch[2u * j + 1u];
-        const u32 sj = s_S[j];
-        bool lt = d0 < c0[e] || (d0 == c0[e] && d1 < c1[e]);
-        bool eq = d0 == c0[e] && d1 == c1[e];
-        if (eq && ((sj | me) >> 31) && j != lp) { lt = (sj & 0x7FFFFFFFu) > S[e]; eq = false; }
-        below += lt ? 1u : 0u;
-        eq_all += eq ? 1u : 0u;
-        eq_before += (eq && j < lp) ? 1u : 0u;
-      }
-      R[e] = below; Q[e] = eq_before | (eq_all << 16);
-    }
-  }
-  __syncthreads();                 // every read of the characters is done: the bytes become the staging
-#pragma unroll
-  for (int e = 0; e < kFinE; ++e) st_P[tid + (u32)e * kFinTPB] = kFinNone;
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < kFinE; ++e) {
-    if (A[e] >= 0) {
-      const u32 np = (u32)A[e] + R[e] + (Q[e] & 0xFFFFu);
-      const u32 fin = (Q[e] >> 16) == 1u ? 0x80000000u : 0u;
-      st_S[np] = S[e];
-      st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
-      st_H[np] = (H[e] + R[e]) | fin;
-      st_C[np] = (u8)C[e];
-    }
+    const u32 lp = tid + (u32)e * kFinTPB;
+    s_k0[lp] = c0[e]; s_k1[lp] = c1[e];
+    // (0x4000: the member reaches past the end of T within the characters compared)
+    const u32 touch = (A[e] >= 0 && (u64)S[e] + (C[e] >> 8) + kFinChars > (u64)n) ? 0x4000u : 0u;
+    s_gi[lp] = A[e] >= 0 ? ((u32)A[e] << 16) | 0x8000u | touch | lp : (lp << 16) | lp;
   }
   // the hard entries of this workgroup's stride range, in any order
+  u32 hard_depth = 0xFFFFFFFFu;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const bool hd = (hard_mask >> e) & 1u;
@@ -970,18 +1143,91 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
         const u32 i = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
         hardS[i] = S[e];
         hardHP[i] = ((u64)H[e] << 32) | (u64)P[e];
+        hard_depth = min(hard_depth, C[e] >> 8);
       }
     }
   }
+  if (hard_depth != 0xFFFFFFFFu) atomicMin(hard_count + 1, hard_depth);
   __syncthreads();
-  // in position order: finals leave, the rest is compacted into the next list
+  // bitonic network over the window: ascending by (group, characters)
+  for (u32 k = 2; k <= (u32)kFinWin; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int c = 0; c < kFinE / 2; ++c) {
+        const u32 i = tid + (u32)c * kFinTPB;                       // comparator 0 .. kFinWin/2 - 1
+        const u32 a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+        const u32 b = a | j;
+        const bool up = (a & k) == 0u;
+        const u32 ga = s_gi[a], gb = s_gi[b];
+        const u64 a0 = s_k0[a], b0 = s_k0[b], a1 = s_k1[a], b1 = s_k1[b];
+        const u32 gra = ga >> 16, grb = gb >> 16;
+        bool gt = gra != grb ? gra > grb : a0 != b0 ? a0 > b0 : a1 > b1;
+        bool lt = gra != grb ? gra < grb : a0 != b0 ? a0 < b0 : a1 < b1;
+        if (!gt && !lt && ((ga | gb) & 0x4000u)) {
+          // "proper prefix sorts first": characters past the end compare as zero bytes, and of two members equal under
+          // that rule of which one reaches past the end the shorter -- the larger suffix number -- is the smaller (a
+          // member that does not reach the end has the smaller number of the two)
+          const u32 sa = s_S[ga & 0x7FFu], sb = s_S[gb & 0x7FFu];
+          gt = sa < sb; lt = sa > sb;
+        }
+        if (up ? gt : lt) {
+          s_gi[a] = gb; s_gi[b] = ga; s_k0[a] = b0; s_k0[b] = a0; s_k1[a] = b1; s_k1[b] = a1;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // in sorted order, kFinE consecutive positions per thread: run heads, finals, the next list
+  const u32 p0 = tid * (u32)kFinE;
+  u32 gi[kFinE + 2];
+  u64 k0[kFinE + 2], k1[kFinE + 2];
+#pragma unroll
+  for (int e = 0; e < kFinE + 2; ++e) {
+    const int p = (int)p0 + e - 1;
+    const bool in_w = p >= 0 && p < kFinWin;
+    gi[e] = in_w ? s_gi[p] : 0u; k0[e] = in_w ? s_k0[p] : 0ull; k1[e] = in_w ? s_k1[p] : 0ull;
+  }
+  bool head[kFinE + 1];
+  u32 hp_local = 0;
+#pragma unroll
+  for (int e = 0; e <= kFinE; ++e) {               // head[e]: position p0 + e starts a run (e == kFinE: the position after mine)
+    const int p = (int)p0 + e;
+    const bool same = p > 0 && p < kFinWin && (gi[e + 1] & 0x8000u) && (gi[e] & 0x8000u) && !((gi[e] | gi[e + 1]) & 0x4000u) &&
+                      (gi[e] >> 16) == (gi[e + 1] >> 16) && k0[e] == k0[e + 1] && k1[e] == k1[e + 1];
+    head[e] = !same;
+    if (e < kFinE && head[e]) hp_local = (u32)p;
+  }
+  u32 unused_max;
+  u32 hp_run = block_scan_incl_max<kFinTPB>(hp_local, scr, &unused_max);    // last head at or before my last position
+  // head position of each of my positions: the last head at or before it (before my first position: what the scan carried in)
+  u32 hp_prev;
+  {
+    // exclusive: the inclusive maximum of the thread before me
+    const u32 up = __shfl_up(hp_run, 1, kWave);
+    __shared__ u32 s_wlast[kFinTPB / kWave];
+    if (lane == kWave - 1) s_wlast[tid / kWave] = hp_run;
+    __syncthreads();
+    hp_prev = lane ? up : (tid / kWave ? s_wlast[tid / kWave - 1] : 0u);
+  }
   u32 oS[kFinE], oP[kFinE], oH[kFinE], oC[kFinE];
+  bool fin[kFinE], mine[kFinE];
   u32 left = 0;
+  u32 hp = hp_prev;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    const u32 lp = tid * (u32)kFinE + (u32)e;
-    oP[e] = st_P[lp]; oS[e] = st_S[lp]; oH[e] = st_H[lp]; oC[e] = st_C[lp];
-    if (oP[e] != kFinNone && !(oH[e] >> 31)) ++left;
+    const u32 p = p0 + (u32)e;
+    if (head[e]) hp = p;
+    const u32 g = gi[e + 1];
+    mine[e] = (g & 0x8000u) != 0u;
+    fin[e] = mine[e] && head[e] && head[e + 1];
+    const u32 lp = g & 0x7FFu, grp = g >> 16;
+    const u32 hh = s_H[lp];
+    oS[e] = s_S[lp];
+    oP[e] = hh + (p - grp);
+    oH[e] = hh + (hp - grp);
+    const u32 cc = s_C[lp];
+    oC[e] = (cc & 0xFFu) | (min(255u, (cc >> 8) + kFinChars) << 8);
+    if (mine[e] && !fin[e]) ++left;
   }
   u32 total;
   u32 at = block_scan_excl_add<kFinTPB>(left, scr, &total);
@@ -990,16 +1236,16 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
   at += s_base;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    if (oP[e] == kFinNone) continue;
-    if (oH[e] >> 31) {
+    if (!mine[e]) continue;
+    if (fin[e]) {
       const u32 slot = oP[e], sfx = oS[e];
       SA[slot] = sfx;
       if (sfx == 0u) *em.pidx = slot;
       if (slot < em.out_n) em.out[slot] = (u8)oC[e];
-      else *em.last_char = oC[e];
+      else *em.last_char = oC[e] & 0xFFu;
       lf_note(em, n, sfx, slot);
     } else {
-      next.S[at] = oS[e]; next.P[at] = oP[e]; next.H[at] = oH[e]; next.C[at] = (u8)oC[e];
+      next.S[at] = oS[e]; next.P[at] = oP[e]; next.H[at] = oH[e]; next.C[at] = (unsigned short)oC[e];
       ++at;
     }
   }
@@ -1010,11 +1256,16 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
 // (key = head slot | character << 56, value = suffix, positional slot array), and rank[] is completed
 // for everybody: rank[SA[slot]] = slot for the finished, the group's head slot for the others.
 __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __restrict__ hardS,
-                                                     u64* __restrict__ hardHP, u32 at, u32 slot_mask) {
+                                                     u64* __restrict__ hardHP, u32 at, u32* __restrict__ min_depth) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= m) return;
-  hardS[at + i] = in.S[i];
-  hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)(in.P[i] & slot_mask);      // (a list no finisher pass has seen may still carry w's low bits)
+  u32 d = 0xFFFFFFFFu;
+  if (i < m) {
+    hardS[at + i] = in.S[i];
+    hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)in.P[i];
+    d = in.C[i] >> 8;
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
+  if (lane_id() == 0 && d != 0xFFFFFFFFu) atomicMin(min_depth, d);       // the depth the rounds may start from
 }
 __global__ __launch_bounds__(256) void k_bridge_dress(const u64* __restrict__ hp, const u32* __restrict__ sfx, u32 m,
                                                       const u8* __restrict__ T, u64* __restrict__ key,
@@ -1289,7 +1540,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_pairs, off_codes, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -1308,8 +1559,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_G0 = take(cap * 4);
   a.off_G1 = take(cap * 4);
   a.off_GRP = take(cap * 4);
-  a.off_C0 = take(cap + 64);
-  a.off_C1 = take(cap + 64);
+  a.off_C0 = take(2 * cap + 64);       // carried characters; the finisher's lists keep 16 bits per entry (character, depth)
+  a.off_C1 = take(2 * cap + 64);
   a.off_P0 = take(cap + 64);
   a.off_P1 = take(cap + 64);
   a.off_W0 = take(cap * 4);
@@ -1325,6 +1576,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_ent = take(2u << 20);
   a.off_comp = take(huffman_compress_bound(cap));
   a.off_sweep = take(SweepWs::small_words() * 4);
+  a.off_pairs = take((u64)kPairReplicas * 65536 * 4);
+  a.off_codes = take((u64)kCodeRows * 256 * 4);
   a.total = o;
   return a;
 }
@@ -1374,6 +1627,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_ent = base + a.off_ent;
   d_comp = base + a.off_comp;
   d_sweep = reinterpret_cast<u32*>(base + a.off_sweep);
+  d_pairs = reinterpret_cast<u32*>(base + a.off_pairs);
+  d_codes = reinterpret_cast<u32*>(base + a.off_codes);
   {
     const char* e = std::getenv("BWTC_HIP_SORT");
     use_sweep = e && std::strcmp(e, "sweep") == 0;
@@ -1395,10 +1650,13 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     }
     long_keys = !(std::getenv("BWTC_HIP_LONG") && std::getenv("BWTC_HIP_LONG")[0] == '0');
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
-    if (std::getenv("BWTC_HIP_FIN_GROUP")) { fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP")); fin_fixed = true; }
-    if (std::getenv("BWTC_HIP_FIN_WINDOW")) { fin_window = std::atoi(std::getenv("BWTC_HIP_FIN_WINDOW")); fin_fixed = true; }
-    if (fin_fixed && fin_max_group >= fin_window) fin_max_group = fin_window / 2;
-    if (std::getenv("BWTC_HIP_LONG_DROP")) long_drop = std::max(0, std::atoi(std::getenv("BWTC_HIP_LONG_DROP")));
+    if (std::getenv("BWTC_HIP_FIN_GROUP")) fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP"));
+    if (std::getenv("BWTC_HIP_FIN_WINDOW")) fin_window = std::atoi(std::getenv("BWTC_HIP_FIN_WINDOW"));
+    fin_window = fin_window >= 2048 ? 2048 : 1024;
+    fin_max_group = fin_max_group >= 1024 ? 1024 : fin_max_group >= 512 ? 512 : 256;
+    if (fin_max_group >= fin_window) fin_max_group = fin_window / 2;
+    code_keys = !(std::getenv("BWTC_HIP_KEYS") && std::strcmp(std::getenv("BWTC_HIP_KEYS"), "grams") == 0);
+    if (std::getenv("BWTC_HIP_CODE_BITS")) code_bits = std::min(72, std::max(40, std::atoi(std::getenv("BWTC_HIP_CODE_BITS"))));
     finisher = !(std::getenv("BWTC_HIP_FINISHER") && std::getenv("BWTC_HIP_FINISHER")[0] == '0');
     gm_partition_lines = std::getenv("BWTC_HIP_GM_PARTITION") && std::strcmp(std::getenv("BWTC_HIP_GM_PARTITION"), "lines") == 0;
     wt_segmented = !(std::getenv("BWTC_HIP_SEG_STEPS") && std::getenv("BWTC_HIP_SEG_STEPS")[0] == '0');
@@ -1690,7 +1948,8 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   // how much stays active decides the route, so the counts are read before the apply kernel
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallCounts, counts, 12, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(wait());
-  if (h_small[kSmallError]) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
+  if (h_small[kSmallError] & 1u) { std::fprintf(stderr, "bwtc_hip: chained radix sort timed out\n"); return -3; }
+  if (h_small[kSmallError]) return -3;                  // (2: k_code_build -- suffix_sort retries the block with gram keys)
   const u32 m_next = h_small[kSmallCounts], groups = h_small[kSmallCounts + 1];
   {
     // reduce and apply read the list (key, suffix, slot; the second key word of long items); apply writes a
@@ -1715,7 +1974,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   // dominated by long repeats and the doubling rounds are the better tool.
   // (with the last gram's low bits left out of the sort -- long_drop -- the list also holds what those bits would have
   // told apart: the bound is three fifths then)
-  res->finish = lng && emit && finisher && (lgv.dropped ? (u64)m_next * 5 <= (u64)m * 3 : (u64)m_next * 2 <= m);
+  res->finish = lng && emit && finisher;
   if (res->finish) {
     sa_out = d_SA;
     fin_active = true;
@@ -1934,8 +2193,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     u64* ka = static_cast<u64*>(d_R1);
     u64* kb = static_cast<u64*>(d_R2);
     GramPlan gp;
-    rc = plan_grams(plan, n, d_lut, &gp);
-    if (rc) return rc;
+    const bool code_route = code_keys && finisher && !code_failed && long_keys && implied_idx && emit && key_plane && n >= gram_min_n;
+    if (!code_route) {
+      rc = plan_grams(plan, n, d_lut, &gp);
+      if (rc) return rc;
+    }
     if (gp.G > 0) {
       key_bits = gp.b * gp.G;
       short_len = (u32)(gp.g * gp.G);
@@ -1944,78 +2206,104 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // Keys of at most 48 bits leave room for the upper bits of the suffix number: the passes of
     // the initial sort then carry (u64 key, u16 low half) = 10 bytes per item instead of 12.
     const int split = (split_index && implied_idx && key_bits <= 48 && n <= (1u << 29)) ? 1 : 0;
-    // Long keys: the sort also orders by a second key word (the next G2 grams) and the items carry
-    // their predecessor character's code -- when the fields fit: key bits + 13 + code bits <= 64.
+    // Long keys: the sort also orders by a second key word and the items carry their predecessor character's code, so
+    // that the ranking behind the ONE long sort can emit the transform's bytes and the finisher takes what is tied.
+    // Two makers: the order-1 prefix code (k_make_keys_code, the default) and dense gram codes (round 4, BWTC_HIP_KEYS=grams).
     LongKey lk;
-    lk.w = nullptr; lk.G2 = 0; lk.drop = 0; lk.first_r = -1; lk.first_mask = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
-    // (without the split -- blocks above 512 MiB, keys above 48 bits -- the items carry whole 32-bit suffix numbers:
+    lk.w = nullptr; lk.G2 = 0; lk.first_r = -1; lk.first_mask = 0; lk.hi_shift = 48; lk.chr_shift = 0; lk.chr_mask = 0;
+    const bool long_ok = long_keys && implied_idx && emit && key_plane && n >= gram_min_n;
+    const bool coded = long_ok && code_keys && finisher && !code_failed;
+    auto upload_inverse_lut = [&]() -> int {
+      u8 inv[256];
+      std::memset(inv, 0, sizeof inv);
+      for (int c = 255; c >= 0; --c) if (hist[c] && !(c == 0 && lone_sentinel)) inv[plan.lut[c]] = (u8)c;
+      std::memcpy(h_small + kSmallInv, inv, 256);
+      BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallInv, h_small + kSmallInv, 256, hipMemcpyHostToDevice, st));
+      return 0;
+    };
+    // (without the split -- blocks above 512 MiB, gram keys above 48 bits -- the items carry whole 32-bit suffix numbers:
     // 16 bytes instead of 14, and the key only needs room for the character)
-    if (long_keys && gp.G > 0 && implied_idx && emit && key_plane && n >= gram_min_n) {
+    int w_bits = 0;
+    RrLong lg;
+    lg.w = nullptr; lg.wmask = ~0u; lg.hi_shift = 0; lg.chr_shift = 0; lg.chr_mask = 0; lg.lvl_shift = -1; lg.depth = 0;
+    int split_now = split;
+    if (coded) {
+      // the block's order-1 statistics from a sample of its character pairs, the alphabetic codes, the keys
+      split_now = (split_index && n <= (1u << 29)) ? 1 : 0;
+      key_bits = code_bits - 32;                        // the key word's share; the second word takes 32
+      w_bits = 32;
+      const int hi_bits = split_now ? 13 : 0;
+      CodeKey ck;
+      ck.codes = d_codes; ck.kbits = code_bits; ck.hi_shift = key_bits; ck.chr_shift = key_bits + hi_bits; ck.lvl_shift = ck.chr_shift + 8;
+      rc = upload_inverse_lut();
+      if (rc) return rc;
+      BWTC_HIP_TRY(hipMemsetAsync(d_pairs, 0, (size_t)kPairReplicas * 65536 * 4, st));
+      const u32 sample_tiles = std::min<u32>(ceil_div(n, kPairTile), 1024u);
+      hipLaunchKernelGGL(k_pair_counts, dim3(sample_tiles), dim3(256), 0, st, (const u8*)d_T, d_lut, n, d_pairs);
+      hipLaunchKernelGGL(k_code_build, dim3(kCodeRows), dim3(256), 0, st, (const u32*)d_pairs, plan.sigma, d_codes, d_small + kSmallError);
+      hipLaunchKernelGGL(k_make_keys_code, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u8*)d_T, d_lut, ka, d_W0, n, key_plane, split_now, ck);
+      lg.hi_shift = ck.hi_shift; lg.chr_shift = ck.chr_shift; lg.chr_mask = 0xFFu; lg.lvl_shift = ck.lvl_shift;
+      lk.w = d_W0;
+      short_len = 0;                                    // every item has its own (rr_masks)
+      h = 1;
+      stats.alg_bytes += (u64)sample_tiles * kPairTile + (u64)kPairReplicas * 65536 * 8;
+      if (std::getenv("BWTC_HIP_DEBUG"))
+        std::fprintf(stderr, "code keys: %d + %d bits, sigma %u, %u sampled tiles, character code at bit %d, level at bit %d\n",
+                     key_bits, w_bits, plan.sigma, sample_tiles, ck.chr_shift, ck.lvl_shift);
+    } else if (long_ok && gp.G > 0) {
       const int cb = std::max(1, bit_width_u64(plan.sigma - 1));
       int G2 = std::min(32 / gp.b, (64 - gp.g * gp.G) / gp.g);
       G2 = std::min(G2, long_grams_override > 0 ? long_grams_override : 2);
       const int hi_bits = split ? 13 : 0;
       if (G2 >= 1 && key_bits + hi_bits + cb <= 64) {
         lk.w = d_W0; lk.G2 = G2; lk.hi_shift = key_bits; lk.chr_shift = key_bits + hi_bits; lk.chr_mask = (1u << cb) - 1u;
-        u8 inv[256];
-        std::memset(inv, 0, sizeof inv);
-        for (int c = 255; c >= 0; --c) if (hist[c] && !(c == 0 && lone_sentinel)) inv[plan.lut[c]] = (u8)c;
-        std::memcpy(h_small + kSmallInv, inv, 256);
-        BWTC_HIP_TRY(hipMemcpyAsync(d_small + kSmallInv, h_small + kSmallInv, 256, hipMemcpyHostToDevice, st));
+        rc = upload_inverse_lut();
+        if (rc) return rc;
+        w_bits = gp.b * lk.G2;
+        if (w_bits < kRadixBits) { lk.first_r = w_bits; lk.first_mask = (1u << std::min(kRadixBits, w_bits + key_bits)) - 1u; }
+        short_len = (u32)(gp.g * (gp.G + lk.G2));
+        h = (u64)short_len;
+        hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
+                           (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split, lk);
+        lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask; lg.lvl_shift = -1; lg.depth = short_len;
+        if (std::getenv("BWTC_HIP_DEBUG"))
+          std::fprintf(stderr, "long keys: %d + %d bits, %d + %d grams of %d characters, character code at bit %d\n",
+                       key_bits, w_bits, gp.G, lk.G2, gp.g, lk.chr_shift);
       }
     }
     if (lk.w) {
-      // long_drop: the last gram's code goes into the sort without its lowest bits when that saves a pass (the codes
-      // are the grams' ranks, so a code's upper bits still order what they tell apart; what they do not is tied at the
-      // depth of the whole grams before it and left to the finisher, which reads the text from there)
-      // Only with the split index (blocks up to 512 MiB: above that the text no longer sits in the Infinity Cache and
-      // the finisher's reads cost more than the pass saves: 1 GiB text 127.8 ms against 117.4), and not while the
-      // stream's blocks keep coming back with long lists (drop_paused, below).
-      int drop = 0;
-      if (long_drop > 0 && long_drop <= 3 && long_drop < gp.b && split && n < (1u << kFinLowShift) && !drop_paused) {
-        const int all = key_bits + gp.b * lk.G2;
-        if ((all - long_drop + kRadixBits - 1) / kRadixBits < (all + kRadixBits - 1) / kRadixBits) drop = long_drop;
-      }
-      lk.drop = drop;
-      fin_low_len = drop ? (u32)(gp.g * (gp.G + lk.G2)) : 0u;
-      const int w_bits = gp.b * lk.G2 - drop;
-      if (w_bits < kRadixBits) { lk.first_r = w_bits; lk.first_mask = (1u << std::min(kRadixBits, w_bits + key_bits)) - 1u; }
-      short_len = (u32)(gp.g * (gp.G + lk.G2 - (drop ? 1 : 0)));
-      h = (u64)short_len;
-      hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
-                         (const uint4*)d_rank, ka, (u32*)nullptr, n, gp.g, gp.G, gp.b, plan.sigma, gp.top, key_plane, split, lk);
       u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
       u32* vs32 = nullptr;
-      if (!split)
-        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1, drop);
+      if (!split_now)
+        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1, 0);
       else if (long_items_per_thread == 6)
         radix_sort_long<unsigned short, 6>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, drop);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0);
       else
         radix_sort_long<unsigned short, 8>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, drop);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0);
       BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
-      u32* vs = split ? reinterpret_cast<u32*>(vs16) : vs32;
+      u32* vs = split_now ? reinterpret_cast<u32*>(vs16) : vs32;
       rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
       rb.v_keys = vs; rb.v_free = vs == d_V0 ? d_V1 : d_V0;
-      RrLong lg;
-      lg.w = ws; lg.wmask = (w_bits >= 32 ? ~0u : (1u << w_bits) - 1u) << drop; lg.lowmask = (1u << drop) - 1u;
-      lg.hi_shift = lk.hi_shift; lg.chr_shift = lk.chr_shift; lg.chr_mask = lk.chr_mask; lg.dropped = drop;
-      if (std::getenv("BWTC_HIP_DEBUG"))
-        std::fprintf(stderr, "long keys: %d + %d bits (%d dropped), %d + %d grams of %d characters, character code at bit %d\n",
-                     key_bits, w_bits, drop, gp.G, lk.G2, gp.g, lk.chr_shift);
-      rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, (u32)split, &lg);
+      lg.w = ws; lg.wmask = w_bits >= 32 ? ~0u : (1u << w_bits) - 1u;
+      rc = rank_step<u64, true>(ks, vs, n, n, short_len, (1ull << key_bits) - 1ull, rb, re, emit, h, &res, (u32)split_now, &lg);
+      if (rc == -3 && coded && (h_small[kSmallError] & 2u)) {
+        // a codeword came out longer than the table's fields hold (k_code_build): nothing has been emitted yet --
+        // this block again, with gram keys
+        if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "code keys: a codeword above %u bits, the block takes gram keys\n", kCodeMaxLen);
+        BWTC_HIP_TRY(hipMemsetAsync(d_small + kSmallError, 0, 4, st));
+        code_failed = true;
+        rc = suffix_sort(n, hist, lone_sentinel, em);
+        code_failed = false;
+        return rc;
+      }
       if (rc) return rc;
-      // what the dropped bits cost shows in the list the ranking leaves: the 256 MiB text block 31.8 % of the suffixes
-      // against 21.5 (and 24.8 ms against 26.2); past three eighths the finisher's extra entries outweigh the pass, so
-      // the next blocks of the stream sort all the bits again until a list comes back short enough
-      if (drop && (u64)res.m * 8 > (u64)n * 3) drop_paused = true;
-      else if (!drop && drop_paused && (u64)res.m * 4 < (u64)n) drop_paused = false;
       const int long_passes = (key_bits + w_bits + kRadixBits - 1) / kRadixBits;
       stats.sort_pass_items += (u64)n * (u64)long_passes;
-      stats.alg_bytes += (u64)n * (1 + 12 + 1)               // k_make_keys_gram: T read, key + second word + first plane written (the values are made up by the first pass)
-                         + sort_bytes(n, long_passes, split ? 14 : 16, 8, true);
-      stats.route |= 1u;
+      stats.alg_bytes += (u64)n * (1 + 12 + 1)               // the key maker: T read, key + second word + first plane written (the values are made up by the first pass)
+                         + sort_bytes(n, long_passes, split_now ? 14 : 16, 8, true);
+      stats.route |= coded ? 17u : 1u;
       key_bits = 0;                                      // counted
     } else if (gp.G > 0) {
       hipLaunchKernelGGL(k_make_keys_gram, dim3(ceil_div(n, 1024)), dim3(256), 0, st, d_T, d_lut,
@@ -2074,10 +2362,12 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
     u32 m2 = 0; u64 h2 = 0;
-    rc = finish_list(n, m, short_len, fin_low_len, rb, re, &res, &m2, &h2);
+    rc = finish_list(n, m, rb, re, &res, &m2, &h2);
     if (rc) return rc;
     m = m2;
-    if (m) { h = h2; keep_h = true; text_left = text_rounds; ranks_complete = false; }
+    // (text rounds -- a global sort per six characters -- are for what is left of a text; a long list is deep
+    // repeats, which only doubling gets through)
+    if (m) { h = h2; keep_h = true; text_left = (u64)m * 16 < (u64)n || text_rounds_fixed ? text_rounds : 0; ranks_complete = false; }
     lf_noted = true;
   }
   while (m > 0) {
@@ -2126,76 +2416,56 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 }
 
 // The finisher passes over the list the long-key ranking left (k_finish), and -- when something is
-// still tied after them, or a group was too large for them -- the bridge into the doubling rounds.
+// still tied after them, or a group was too large for them -- the bridge into the rounds.
 // On return *m_out entries (0: all done) wait in res / rb as a sorted list of depth *h_out.
-// low_len > 0: the list's slot words carry the bits of w the sort left out (k_finish, LOW): the first pass orders by them
-// and by the sixteen characters from low_len on -- the depth of the whole grams -- while `depth` is what the list's
-// groups are known to share.
-int BwtEngine::finish_list(u32 n, u32 m, u32 depth, u32 low_len, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
+// Every entry knows the depth its group shares (the upper byte of its character field); a pass adds
+// kFinChars to it.  Passes go on while the list shrinks: one that keeps more than three fifths of a
+// list that is still longer than n / 64 has met deep repeats (copies of whole files, not of lines),
+// which only doubling gets through.
+int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
   hipStream_t st = stream;
-  u32* cnt = d_small + kSmallFin;                      // [0] next list, [1] hard list
-  FinList a{rb.v_free, rb.aglob_next, d_GRP, re.achr_out};
-  FinList b{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, re.achr_out == d_C0 ? d_C1 : d_C0};
+  u32* cnt = d_small + kSmallFin;                      // [0] next list, [1] hard list, [2] hard list's smallest depth (adjacent: k_finish's hard_count)
+  FinList a{rb.v_free, rb.aglob_next, d_GRP, reinterpret_cast<unsigned short*>(re.achr_out)};
+  FinList b{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
   u64* hardHP = static_cast<u64*>(rb.rec_free);
   u32* hardS = rb.v_keys;
-  BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
-  u32 hard = 0, hard_depth = depth;
-  bool low_pending = low_len > 0;
-  // The window and the largest group settled here.  Small windows keep more workgroups on a CU (27 KiB of LDS instead
-  // of 54: the 256 MiB text block 23.1 ms with 1024 / 256 against 25.4 with 2048 / 1024); every group above the bound
-  // goes to the text rounds.  So: 256 below 2^29 suffixes and 512 above, one step up for the stream's next blocks when
-  // more than n / 1024 entries went that way, one step back when fewer than n / 8192 did.
-  // BWTC_HIP_FIN_WINDOW / BWTC_HIP_FIN_GROUP fix both.
-  int window = fin_window, group = fin_max_group;
-  if (!fin_fixed) {
-    if (fin_group_now == 0) fin_group_now = n < (1u << 29) ? 256 : 512;
-    group = fin_group_now;
-    window = group <= 512 ? 1024 : 2048;
-  }
+  h_small[kSmallFin] = 0; h_small[kSmallFin + 1] = 0; h_small[kSmallFin + 2] = 0xFFFFFFFFu; h_small[kSmallFin + 3] = 0xFFFFFFFFu;
+  BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 16, hipMemcpyHostToDevice, st));
+  u32 hard = 0;
+  const int window = fin_window, group = fin_max_group;
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
-    const u32 from = low_pending ? low_len : depth;      // where this pass reads the text
     ++stats.rounds;
     stats.active_sum += m;
     stats.finisher_entries += m;
     stats.route |= 2u;
-    // a window of entries is read by two workgroups, sixteen characters (three aligned words) per owned entry,
-    // a byte and a suffix per finished one
-    stats.alg_bytes += (u64)m * (2 * 13 + 24 + 5);
+    // a window of entries is read by the workgroups whose windows overlap there (4/3 on average), sixteen characters
+    // (three aligned words) per owned entry, a byte and a suffix per finished one, an entry per member that stays
+    stats.alg_bytes += (u64)m * (14 * 4 / 3 + 24 + 5);
     BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
-    // (a workgroup settles the groups that start in the first kFinWin - G entries of its window: the smaller the largest
-    // group it takes, the more of its lanes have work -- and the more entries go to the text rounds instead)
-#define BWTC_FINISH(G, L, E) hipLaunchKernelGGL((k_finish<G, L, E>), dim3(ceil_div(m, (u32)(kFinTPB * E - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, from, \
-                                                b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
-#define BWTC_FINISH_L(G, E) do { if (low_pending) BWTC_FINISH(G, true, E); else BWTC_FINISH(G, false, E); } while (0)
-    if (window <= 1024) { if (group <= 256) BWTC_FINISH_L(256, 4); else BWTC_FINISH_L(512, 4); }
-    else if (group <= 256) BWTC_FINISH_L(256, 8);
-    else if (group <= 512) BWTC_FINISH_L(512, 8);
-    else BWTC_FINISH_L(1024, 8);
-#undef BWTC_FINISH_L
+#define BWTC_FINISH(G, E) hipLaunchKernelGGL((k_finish<G, E>), dim3(ceil_div(m, (u32)(kFinTPB * E - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, \
+                                             b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
+    if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
+    else if (group <= 256) BWTC_FINISH(256, 8);
+    else if (group <= 512) BWTC_FINISH(512, 8);
+    else BWTC_FINISH(1024, 8);
 #undef BWTC_FINISH
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 8, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 12, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
+    const u32 m_was = m;
     if (std::getenv("BWTC_HIP_DEBUG"))
-      std::fprintf(stderr, "finisher pass %d: depth %u%s, %u entries -> %u still tied, %u hard\n", it, depth,
-                   low_pending ? " (+ the last gram's low bits)" : "", m, h_small[kSmallFin], h_small[kSmallFin + 1]);
+      std::fprintf(stderr, "finisher pass %d: %u entries -> %u still tied, %u hard (depth from %u)\n", it, m, h_small[kSmallFin],
+                   h_small[kSmallFin + 1], h_small[kSmallFin + 2]);
     m = h_small[kSmallFin];
-    if (hard == 0 && h_small[kSmallFin + 1]) hard_depth = depth;       // (a hard group's members share `depth` characters, low bits or not)
     hard = h_small[kSmallFin + 1];
-    if (it == 0 && !fin_fixed) {
-      const int base = n < (1u << 29) ? 256 : 512;
-      if ((u64)hard * 1024 > (u64)n && fin_group_now < 1024) fin_group_now *= 2;
-      else if ((u64)hard * 8192 < (u64)n && fin_group_now > base) fin_group_now /= 2;
-    }
-    depth = from + (low_pending ? kFinChars - 1u : kFinChars);      // (the low bits take the place of the sixteenth character)
-    low_pending = false;
     std::swap(a, b);
+    if (it >= 1 && (u64)m * 5 > (u64)m_was * 3 && (u64)m * 64 > (u64)n) break;     // deep repeats: on to the rounds
   }
   *m_out = 0;
   if (m == 0 && hard == 0) return 0;
   // ---- what is still tied becomes a list the rounds understand: sorted by slot (groups contiguous,
   // a positional slot array), key = head slot | character << 56, value = suffix
-  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard,
-                            low_pending ? (1u << kFinLowShift) - 1u : 0xFFFFFFFFu);
+  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard, cnt + 3);
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 2, cnt + 2, 8, hipMemcpyDeviceToHost, st));
   const u32 total = hard + m;
   if ((u64)total > cap) return -3;
   u64* hp_sorted = nullptr; u32* s_sorted = nullptr;
@@ -2204,12 +2474,14 @@ int BwtEngine::finish_list(u32 n, u32 m, u32 depth, u32 low_len, RankBuffers& rb
   u64* fkey = reinterpret_cast<u64*>(d_W0);              // d_W0 and d_W1 are neighbours in the arena: 8 * cap bytes
   hipLaunchKernelGGL(k_bridge_dress, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)hp_sorted, (const u32*)s_sorted,
                      total, (const u8*)d_T, fkey, d_G0);
+  BWTC_HIP_TRY(wait());
   res->m = total; res->groups = 0;
   res->ks = fkey; res->rec_other = d_R1;
   res->vs = s_sorted; res->v_other = s_sorted == d_V0 ? d_V1 : d_V0;
   rb.aglob_next = d_G0;
   *m_out = total;
-  *h_out = hard ? hard_depth : depth;                    // every group of the list shares at least that many characters
+  *h_out = std::min(h_small[kSmallFin + 2], h_small[kSmallFin + 3]);     // every group of the list shares at least that many characters
+  if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "finisher: %u entries (%u hard) go on to the rounds at depth %llu\n", total, hard, (unsigned long long)*h_out);
   return 0;
 }
 

@@ -401,22 +401,22 @@ struct BwtEngine {
   bool long_keys = true;     // BWTC_HIP_LONG=0: never the long-key initial sort
   int long_items_per_thread = 8;   // BWTC_HIP_LONG_E=6: tiles of 3072 items (three workgroups per CU instead of two)
   u32 gram_min_n = 1u << 22; // blocks below this keep the plain base-sigma key (BWTC_HIP_GRAM_MIN_N: tests)
+  bool code_failed = false;  // this block's code table could not be built: it is sorted again with gram keys
+  bool code_keys = true;     // BWTC_HIP_KEYS=grams: the long key is made of dense gram codes (round 4) instead of the order-1 prefix code
+  int code_bits = 72;        // BWTC_HIP_CODE_BITS=N (40..72): bits of a code key (the low 32 in the second word)
+  u32* d_pairs = nullptr;    // code keys: sampled character-pair counts (kPairReplicas x 65536 words), and the code table (257 x 256 words)
+  u32* d_codes = nullptr;
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
-  bool fin_fixed = false;    // the two below were given by the environment (else finish_list chooses, see there)
-  int fin_group_now = 0;     // finish_list's current choice of the largest group (0: not chosen yet)
-  int fin_window = 2048;     // BWTC_HIP_FIN_WINDOW=1024: entries a finisher workgroup looks at (then groups of up to 512 or 256)
-  int fin_max_group = 1024;  // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
-  int fin_max_passes = 4;    // BWTC_HIP_FIN_PASSES: finisher passes before what is still tied takes the doubling rounds
+  int fin_window = 1024;     // BWTC_HIP_FIN_WINDOW=2048: entries a finisher workgroup sorts
+  int fin_max_group = 256;   // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
+  int fin_max_passes = 8;    // BWTC_HIP_FIN_PASSES: finisher passes at most before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
   bool text_rounds_fixed = false;
   bool fin_active = false;   // this block takes the finisher route: finished suffixes also go to d_SA
   bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
-  int finish_list(u32 n, u32 m, u32 depth, u32 low_len, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
-  u32 fin_low_len = 0;       // this block: the depth of the long key's whole grams when the sort left out the last gram's low bits
-  int long_drop = 3;             // BWTC_HIP_LONG_DROP=N: the long sort leaves out the N lowest bits of the last gram's code when that saves a pass (0: never)
-  bool drop_paused = false;      // the last block's list was long with the bits dropped: keep them until a short list comes back
+  int finish_list(u32 n, u32 m, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
