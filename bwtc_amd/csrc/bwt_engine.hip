@@ -1011,17 +1011,14 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 //
 // A workgroup looks at a window of kFinWin consecutive entries and owns the groups that START in its
 // first kFinWin - kFinMaxGroup entries and have at most kFinMaxGroup members (so they lie inside the
-// window).  It reads the owned members' characters (the route's one random access: three aligned words
-// of T per member) and sorts the WINDOW by (group, characters) with a bitonic network in LDS -- round 4
-// let every member count the members below it, a loop over its group: fine for the generator's groups
-// of two or three, quadratic for a real text's (a line that occurs 24 times makes groups of 24 for
-// every one of its suffixes: 33 comparisons per member on average, and the pass was no faster than the
-// doubling rounds it replaced).  The network costs the same 55 steps whatever the groups look like.
-// A group's members sit in the window where the group did (entries that are not this workgroup's to
-// settle sort as groups of their own, in place), so a member's new slot is its group's head slot plus
-// its place inside the group.  A member whose characters nobody shares is final: out[slot], SA[slot],
-// the LF powers.  The others form the next list in their new order (sub-group head = first member with
-// the same characters), sixteen characters deeper, appended with one atomic per workgroup.
+// window).  It stages the owned members' characters in LDS (the route's one random access: three
+// aligned words of T per member) and every member counts the members of its group below it and equal
+// to it.  (Round 5 also measured a bitonic network over the window instead of that loop -- 55 steps
+// whatever the groups look like: 87 ps per entry on a real text whose groups average 34 members,
+// against about 25 for the loop, whose cost is the group's size; the network was dropped.)
+// A member without equals is final: out[slot], SA[slot], the LF powers.  The others form the next list
+// in their new order (sub-group head = old head + members below), sixteen characters deeper, appended
+// with one atomic per workgroup.
 //
 // Larger groups are nobody's: their entries go to the "hard" list, appended by the workgroup whose
 // stride range they lie in, and take the text rounds / doubling rounds (bridge, below).
@@ -1034,6 +1031,16 @@ constexpr u32 kFinChars = 16;                       // characters compared per p
 constexpr u32 kFinNone = 0xFFFFFFFFu;
 
 struct FinList { u32* S; u32* P; u32* H; unsigned short* C; };
+// A list lives in up to kFinRegions regions of its arrays (a pass appends what it leaves with one atomic per workgroup:
+// 300 000 workgroups on ONE counter were 3.4 ms of serialised atomics per pass over a real text, so workgroup b appends to
+// one of 16 regions, each with a counter of its own: chunks of 64 consecutive workgroups take the regions in turn -- the
+// workgroups on the chip at any moment spread over all of them, and a chunk leaves at most its 64 strides of entries plus
+// one group, so the regions' sizes add up to the list's plus half a per cent).  Windows never straddle regions (groups
+// do not: a workgroup's output goes to one region).
+constexpr u32 kFinRegions = 16;
+constexpr u32 kFinChunk = 64;
+struct FinRegions { u32 nreg; u32 wfirst[kFinRegions + 1]; u32 ebase[kFinRegions]; u32 ecount[kFinRegions]; };
+struct FinOut { u32 base[kFinRegions]; };                 // where each region of the list a pass leaves starts
 
 // sixteen characters T[pos .. pos+16) as two big-endian words; bytes at or past n read as zero
 __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32 n, u64* c0, u64* c1) {
@@ -1053,26 +1060,35 @@ __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32
   *c1 = __builtin_bswap64(hi);
 }
 
-// hard_count[0]: entries of the hard list, [1]: the smallest depth among them
+// hard_count[0]: entries of the hard list, [1]: the smallest depth among them.  Hard entries whose group shares fewer
+// than shal.floor characters go to a list of their own (shal.count[0], [1]: entries, smallest depth): the rounds work
+// at ONE depth for all their groups, the smallest, and a few groups of some exotic but repetitive string (bytes the
+// code's sample never saw: a depth of one or two characters) would drag a whole text's hard groups down to theirs.
+struct FinShallow { u32* S; u64* HP; u32* count; u32 floor; };
 template <int kFinMaxGroup, int E_ = 4>
-__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8* __restrict__ T, u32 n,
-                                                    FinList next, u32* __restrict__ next_count,
+__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, const u8* __restrict__ T, u32 n,
+                                                    FinList next, FinOut ob, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP,
-                                                    u32* __restrict__ hard_count, u32* __restrict__ SA, RrEmit em) {
+                                                    u32* __restrict__ hard_count, FinShallow shal, u32* __restrict__ SA, RrEmit em) {
   constexpr int kFinE = E_;                                           // entries per thread: a window of 1024 or 2048
   constexpr int kFinWin = kFinTPB * kFinE;
   static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
-  static_assert((kFinWin & (kFinWin - 1)) == 0 && kFinWin <= 2048, "the network sorts a power of two; positions take 11 bits");
   constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
-  __shared__ u64 s_k0[kFinWin], s_k1[kFinWin];                        // the characters, by position
-  __shared__ u32 s_gi[kFinWin];                                       // group (window position of its first member) << 16 | owned << 15 | entry
-  __shared__ u32 s_S[kFinWin], s_P[kFinWin], s_H[kFinWin];            // the entries as loaded
-  __shared__ unsigned short s_C[kFinWin];
+  __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // the characters; later the reorder staging
+  __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
+  __shared__ u32 s_H[kFinWin];
   __shared__ unsigned short s_g[kFinWin + 2];                         // group size by start position; [kFinWin]: the group cut by the window's start
   __shared__ u32 scr[kFinTPB / kWave + 1];
   __shared__ u32 s_base;
+  u32* st_S = reinterpret_cast<u32*>(s_ch);                           // staging, by new position
+  u32* st_P = st_S + kFinWin;
+  u32* st_H = st_P + kFinWin;                                         // | final << 31
+  unsigned short* st_C = reinterpret_cast<unsigned short*>(st_H + kFinWin);
   const u32 tid = threadIdx.x;
-  const u32 w0 = blockIdx.x * (u32)kFinStride;
+  u32 reg = 0;
+  while (reg + 1u < rg.nreg && blockIdx.x >= rg.wfirst[reg + 1u]) ++reg;
+  const u32 w0 = rg.ebase[reg] + (blockIdx.x - rg.wfirst[reg]) * (u32)kFinStride;
+  const u32 m = rg.ebase[reg] + rg.ecount[reg];                       // one past the region's last entry
   const u32 lane = lane_id();
 
   u32 S[kFinE], P[kFinE], H[kFinE], C[kFinE];
@@ -1081,7 +1097,7 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
     const bool ok = q < m;
     S[e] = ok ? in.S[q] : 0u; P[e] = ok ? in.P[q] : 0u; H[e] = ok ? in.H[q] : kFinNone; C[e] = ok ? in.C[q] : 0u;
-    s_S[lp] = S[e]; s_P[lp] = P[e]; s_H[lp] = H[e]; s_C[lp] = (unsigned short)C[e];
+    s_H[lp] = H[e];
     s_g[lp] = 0xFFFFu;
   }
   if (tid < 2) s_g[kFinWin + tid] = 0xFFFFu;
@@ -1101,19 +1117,20 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
   }
   __syncthreads();
   int A[kFinE];                   // group start (window position), or -1: not this workgroup's to settle
+  u32 G[kFinE];
   u32 hard_mask = 0;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
-    A[e] = -1;
+    A[e] = -1; G[e] = 0;
     if (q < m) {
       const int a = (int)lp - (int)(P[e] - H[e]);
       const u32 g = (P[e] - H[e] < (u32)kFinMaxGroup) ? s_g[a >= 0 ? a : kFinWin] : 0xFFFFu;
       if (g == 0xFFFFu) { if (lp < (u32)kFinStride) hard_mask |= 1u << e; }
-      else if (a >= 0 && a < kFinStride) A[e] = a;
+      else if (a >= 0 && a < kFinStride) { A[e] = a; G[e] = g; }
     }
   }
-  // characters of the members this workgroup settles
+  // characters of the members this workgroup settles, each from its own group's depth
   u64 c0[kFinE], c1[kFinE];
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
@@ -1122,122 +1139,110 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, u32 m, const u8*
   }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    const u32 lp = tid + (u32)e * kFinTPB;
-    s_k0[lp] = c0[e]; s_k1[lp] = c1[e];
-    // (0x4000: the member reaches past the end of T within the characters compared)
-    const u32 touch = (A[e] >= 0 && (u64)S[e] + (C[e] >> 8) + kFinChars > (u64)n) ? 0x4000u : 0u;
-    s_gi[lp] = A[e] >= 0 ? ((u32)A[e] << 16) | 0x8000u | touch | lp : (lp << 16) | lp;
-  }
-  // the hard entries of this workgroup's stride range, in any order
-  u32 hard_depth = 0xFFFFFFFFu;
-#pragma unroll
-  for (int e = 0; e < kFinE; ++e) {
-    const bool hd = (hard_mask >> e) & 1u;
-    const u64 bal = __ballot(hd);
-    if (bal) {
-      u32 base = 0;
-      const u32 first = (u32)__ffsll((unsigned long long)bal) - 1u;
-      if (lane == first) base = atomicAdd(hard_count, (u32)__popcll(bal));
-      base = __shfl(base, (int)first, kWave);
-      if (hd) {
-        const u32 i = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-        hardS[i] = S[e];
-        hardHP[i] = ((u64)H[e] << 32) | (u64)P[e];
-        hard_depth = min(hard_depth, C[e] >> 8);
-      }
+    if (A[e] >= 0) {
+      const u32 lp = tid + (u32)e * kFinTPB;
+      const u32 touch = ((u64)S[e] + (C[e] >> 8) + kFinChars > (u64)n) ? 0x80000000u : 0u;
+      s_ch[2u * lp] = c0[e]; s_ch[2u * lp + 1u] = c1[e];
+      s_S[lp] = S[e] | touch;
     }
   }
-  if (hard_depth != 0xFFFFFFFFu) atomicMin(hard_count + 1, hard_depth);
   __syncthreads();
-  // bitonic network over the window: ascending by (group, characters)
-  for (u32 k = 2; k <= (u32)kFinWin; k <<= 1) {
-    for (u32 j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int c = 0; c < kFinE / 2; ++c) {
-        const u32 i = tid + (u32)c * kFinTPB;                       // comparator 0 .. kFinWin/2 - 1
-        const u32 a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-        const u32 b = a | j;
-        const bool up = (a & k) == 0u;
-        const u32 ga = s_gi[a], gb = s_gi[b];
-        const u64 a0 = s_k0[a], b0 = s_k0[b], a1 = s_k1[a], b1 = s_k1[b];
-        const u32 gra = ga >> 16, grb = gb >> 16;
-        bool gt = gra != grb ? gra > grb : a0 != b0 ? a0 > b0 : a1 > b1;
-        bool lt = gra != grb ? gra < grb : a0 != b0 ? a0 < b0 : a1 < b1;
-        if (!gt && !lt && ((ga | gb) & 0x4000u)) {
-          // "proper prefix sorts first": characters past the end compare as zero bytes, and of two members equal under
-          // that rule of which one reaches past the end the shorter -- the larger suffix number -- is the smaller (a
-          // member that does not reach the end has the smaller number of the two)
-          const u32 sa = s_S[ga & 0x7FFu], sb = s_S[gb & 0x7FFu];
-          gt = sa < sb; lt = sa > sb;
-        }
-        if (up ? gt : lt) {
-          s_gi[a] = gb; s_gi[b] = ga; s_k0[a] = b0; s_k0[b] = a0; s_k1[a] = b1; s_k1[b] = a1;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // in sorted order, kFinE consecutive positions per thread: run heads, finals, the next list
-  const u32 p0 = tid * (u32)kFinE;
-  u32 gi[kFinE + 2];
-  u64 k0[kFinE + 2], k1[kFinE + 2];
-#pragma unroll
-  for (int e = 0; e < kFinE + 2; ++e) {
-    const int p = (int)p0 + e - 1;
-    const bool in_w = p >= 0 && p < kFinWin;
-    gi[e] = in_w ? s_gi[p] : 0u; k0[e] = in_w ? s_k0[p] : 0ull; k1[e] = in_w ? s_k1[p] : 0ull;
-  }
-  bool head[kFinE + 1];
-  u32 hp_local = 0;
-#pragma unroll
-  for (int e = 0; e <= kFinE; ++e) {               // head[e]: position p0 + e starts a run (e == kFinE: the position after mine)
-    const int p = (int)p0 + e;
-    const bool same = p > 0 && p < kFinWin && (gi[e + 1] & 0x8000u) && (gi[e] & 0x8000u) && !((gi[e] | gi[e + 1]) & 0x4000u) &&
-                      (gi[e] >> 16) == (gi[e + 1] >> 16) && k0[e] == k0[e + 1] && k1[e] == k1[e + 1];
-    head[e] = !same;
-    if (e < kFinE && head[e]) hp_local = (u32)p;
-  }
-  u32 unused_max;
-  u32 hp_run = block_scan_incl_max<kFinTPB>(hp_local, scr, &unused_max);    // last head at or before my last position
-  // head position of each of my positions: the last head at or before it (before my first position: what the scan carried in)
-  u32 hp_prev;
-  {
-    // exclusive: the inclusive maximum of the thread before me
-    const u32 up = __shfl_up(hp_run, 1, kWave);
-    __shared__ u32 s_wlast[kFinTPB / kWave];
-    if (lane == kWave - 1) s_wlast[tid / kWave] = hp_run;
-    __syncthreads();
-    hp_prev = lane ? up : (tid / kWave ? s_wlast[tid / kWave - 1] : 0u);
-  }
-  u32 oS[kFinE], oP[kFinE], oH[kFinE], oC[kFinE];
-  bool fin[kFinE], mine[kFinE];
-  u32 left = 0;
-  u32 hp = hp_prev;
+  // Every member counts the members of its group below it and equal to it (broadcast LDS reads: the lanes of a wave
+  // walk a few neighbouring groups).  "Proper prefix sorts first": characters past the end of T compare as zero bytes,
+  // and of two members equal under that rule of which one reaches past the end the shorter -- the larger suffix number
+  // -- is the smaller; they are never equal.
+  u32 R[kFinE], Q[kFinE];         // members below; equal members before this one | all equal members << 16
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    const u32 p = p0 + (u32)e;
-    if (head[e]) hp = p;
-    const u32 g = gi[e + 1];
-    mine[e] = (g & 0x8000u) != 0u;
-    fin[e] = mine[e] && head[e] && head[e + 1];
-    const u32 lp = g & 0x7FFu, grp = g >> 16;
-    const u32 hh = s_H[lp];
-    oS[e] = s_S[lp];
-    oP[e] = hh + (p - grp);
-    oH[e] = hh + (hp - grp);
-    const u32 cc = s_C[lp];
-    oC[e] = (cc & 0xFFu) | (min(255u, (cc >> 8) + kFinChars) << 8);
-    if (mine[e] && !fin[e]) ++left;
+    R[e] = 0; Q[e] = 0;
+    if (A[e] >= 0) {
+      const u32 lp = tid + (u32)e * kFinTPB;
+      const u32 me = s_S[lp];
+      u32 below = 0, eq_before = 0, eq_all = 0;
+      for (u32 j = (u32)A[e]; j < (u32)A[e] + G[e]; ++j) {
+        const u64 d0 = s_ch[2u * j], d1 = s_ch[2u * j + 1u];
+        const u32 sj = s_S[j];
+        bool lt = d0 < c0[e] || (d0 == c0[e] && d1 < c1[e]);
+        bool eq = d0 == c0[e] && d1 == c1[e];
+        if (eq && ((sj | me) >> 31) && j != lp) { lt = (sj & 0x7FFFFFFFu) > S[e]; eq = false; }
+        below += lt ? 1u : 0u;
+        eq_all += eq ? 1u : 0u;
+        eq_before += (eq && j < lp) ? 1u : 0u;
+      }
+      R[e] = below; Q[e] = eq_before | (eq_all << 16);
+    }
+  }
+  __syncthreads();                 // every read of the characters is done: the bytes become the staging
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) st_P[tid + (u32)e * kFinTPB] = kFinNone;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    if (A[e] >= 0) {
+      const u32 np = (u32)A[e] + R[e] + (Q[e] & 0xFFFFu);
+      const u32 fin = (Q[e] >> 16) == 1u ? 0x80000000u : 0u;
+      st_S[np] = S[e];
+      st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
+      st_H[np] = (H[e] + R[e]) | fin;
+      st_C[np] = (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kFinChars) << 8));
+    }
+  }
+  // the hard entries of this workgroup's stride range, in any order; one atomic per workgroup and list (a wave's own
+  // atomic per iteration was 600 000 on one address for a real text's 40 M hard entries)
+  u32 hard_depth = 0xFFFFFFFFu, shal_depth = 0xFFFFFFFFu;
+  {
+    u32 hm = 0, sm = 0;                                   // this thread's hard entries: of the hard list, of the shallow one
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) {
+      if ((hard_mask >> e) & 1u) { if ((C[e] >> 8) < shal.floor) sm |= 1u << e; else hm |= 1u << e; }
+    }
+    __shared__ u32 s_hbase[2];
+    u32 htot, stot;
+    u32 hat = block_scan_excl_add<kFinTPB>((u32)__popc(hm), scr, &htot);
+    u32 sat = block_scan_excl_add<kFinTPB>((u32)__popc(sm), scr, &stot);
+    if (tid == 0) { s_hbase[0] = htot ? atomicAdd(hard_count, htot) : 0u; s_hbase[1] = stot ? atomicAdd(shal.count, stot) : 0u; }
+    __syncthreads();
+    hat += s_hbase[0]; sat += s_hbase[1];
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) {
+      if ((hm >> e) & 1u) {
+        hardS[hat] = S[e]; hardHP[hat] = ((u64)H[e] << 32) | (u64)P[e]; ++hat;
+        hard_depth = min(hard_depth, C[e] >> 8);
+      } else if ((sm >> e) & 1u) {
+        shal.S[sat] = S[e]; shal.HP[sat] = ((u64)H[e] << 32) | (u64)P[e]; ++sat;
+        shal_depth = min(shal_depth, C[e] >> 8);
+      }
+    }
+  }
+  // (one atomic per wave that has something to say, and only when it lowers what is there)
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    hard_depth = min(hard_depth, (u32)__shfl_xor(hard_depth, o, kWave));
+    shal_depth = min(shal_depth, (u32)__shfl_xor(shal_depth, o, kWave));
+  }
+  if (lane == 0 && hard_depth != 0xFFFFFFFFu && hard_depth < __hip_atomic_load(hard_count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(hard_count + 1, hard_depth);
+  if (lane == 0 && shal_depth != 0xFFFFFFFFu && shal_depth < __hip_atomic_load(shal.count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(shal.count + 1, shal_depth);
+  __syncthreads();
+  // in position order: finals leave, the rest is compacted into the next list
+  u32 oS[kFinE], oP[kFinE], oH[kFinE], oC[kFinE];
+  u32 left = 0;
+#pragma unroll
+  for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid * (u32)kFinE + (u32)e;
+    oP[e] = st_P[lp]; oS[e] = st_S[lp]; oH[e] = st_H[lp]; oC[e] = st_C[lp];
+    if (oP[e] != kFinNone && !(oH[e] >> 31)) ++left;
   }
   u32 total;
   u32 at = block_scan_excl_add<kFinTPB>(left, scr, &total);
-  if (tid == 0) s_base = total ? atomicAdd(next_count, total) : 0u;
+  if (tid == 0) {
+    const u32 oreg = (blockIdx.x / kFinChunk) % kFinRegions;
+    s_base = ob.base[oreg] + (total ? atomicAdd(&next_count[oreg], total) : 0u);
+  }
   __syncthreads();
   at += s_base;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    if (!mine[e]) continue;
-    if (fin[e]) {
+    if (oP[e] == kFinNone) continue;
+    if (oH[e] >> 31) {
       const u32 slot = oP[e], sfx = oS[e];
       SA[slot] = sfx;
       if (sfx == 0u) *em.pidx = slot;
@@ -1265,7 +1270,8 @@ __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __r
     d = in.C[i] >> 8;
   }
   for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
-  if (lane_id() == 0 && d != 0xFFFFFFFFu) atomicMin(min_depth, d);       // the depth the rounds may start from
+  // the depth the rounds may start from (an atomic only where it lowers what is there: one per wave was 15 ms for 85 M entries)
+  if (lane_id() == 0 && d != 0xFFFFFFFFu && d < __hip_atomic_load(min_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(min_depth, d);
 }
 __global__ __launch_bounds__(256) void k_bridge_dress(const u64* __restrict__ hp, const u32* __restrict__ sfx, u32 m,
                                                       const u8* __restrict__ T, u64* __restrict__ key,
@@ -1293,6 +1299,16 @@ __global__ __launch_bounds__(256) void k_bridge_pairs_fix(const u32* __restrict_
   const u32 p = aglob[i];
   pair_s[p] = sfx[i];
   pair_r[p] = p;
+}
+
+// the same for a list that waits for its turn (its groups' head slots are its suffixes' ranks until then)
+__global__ __launch_bounds__(256) void k_bridge_pairs_fix_parked(const u32* __restrict__ sfx, const u64* __restrict__ hp, u32 m,
+                                                                 u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  const u64 x = hp[i];
+  pair_s[(u32)x] = sfx[i];
+  pair_r[(u32)x] = (u32)(x >> 32);
 }
 
 constexpr int kSimpleE = 4;   // independent items per thread in the latency-bound kernels
@@ -1540,7 +1556,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_pairs, off_codes, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_parkS, off_parkHP, off_pairs, off_codes, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -1554,17 +1570,19 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_rank = take(cap * 4);
   a.off_R1 = take(cap * 8);
   a.off_R2 = take(cap * 8);
-  a.off_V0 = take(cap * 4);
-  a.off_V1 = take(cap * 4);
-  a.off_G0 = take(cap * 4);
-  a.off_G1 = take(cap * 4);
-  a.off_GRP = take(cap * 4);
-  a.off_C0 = take(2 * cap + 64);       // carried characters; the finisher's lists keep 16 bits per entry (character, depth)
-  a.off_C1 = take(2 * cap + 64);
+  // (the finisher's lists live in regions sized for the most their workgroups can leave: up to 17 strides beyond the entries)
+  const u64 lcap = cap + cap / 128 + 65536;
+  a.off_V0 = take(lcap * 4);
+  a.off_V1 = take(lcap * 4);
+  a.off_G0 = take(lcap * 4);
+  a.off_G1 = take(lcap * 4);
+  a.off_GRP = take(lcap * 4);
+  a.off_C0 = take(2 * lcap + 64);      // carried characters; the finisher's lists keep 16 bits per entry (character, depth)
+  a.off_C1 = take(2 * lcap + 64);
   a.off_P0 = take(cap + 64);
   a.off_P1 = take(cap + 64);
-  a.off_W0 = take(cap * 4);
-  a.off_W1 = take(cap * 4);
+  a.off_W0 = take(lcap * 4);           // (W0 and W1 are neighbours: together also one region of 8 * cap bytes)
+  a.off_W1 = take(lcap * 4);
   a.off_table = take(radix_table_words(cap) * 4);
   a.off_partial = take(radix_partial_words(cap) * 4);
   const u64 rr_tiles = (cap + kRrTile - 1) / kRrTile + 1;
@@ -1576,6 +1594,8 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_ent = take(2u << 20);
   a.off_comp = take(huffman_compress_bound(cap));
   a.off_sweep = take(SweepWs::small_words() * 4);
+  a.off_parkS = take(cap * 4);          // finisher route: the hard list waits here while the shallow one takes its rounds
+  a.off_parkHP = take(cap * 8);
   a.off_pairs = take((u64)kPairReplicas * 65536 * 4);
   a.off_codes = take((u64)kCodeRows * 256 * 4);
   a.total = o;
@@ -1627,6 +1647,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_ent = base + a.off_ent;
   d_comp = base + a.off_comp;
   d_sweep = reinterpret_cast<u32*>(base + a.off_sweep);
+  d_parkS = reinterpret_cast<u32*>(base + a.off_parkS);
+  d_parkHP = reinterpret_cast<u64*>(base + a.off_parkHP);
   d_pairs = reinterpret_cast<u32*>(base + a.off_pairs);
   d_codes = reinterpret_cast<u32*>(base + a.off_codes);
   {
@@ -1664,6 +1686,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_GRAM_MIN_N")) gram_min_n = (u32)std::max(64, std::atoi(std::getenv("BWTC_HIP_GRAM_MIN_N")));   // tests: small blocks through the gram / long-key routes
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
+    if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
     if (hg && std::atoi(hg) > 0) huge_group_elements = (u64)std::atoi(hg) << 20;
@@ -1968,7 +1991,7 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
   res->carry = carry_next;
   const bool dense = !text && dense_route && m_next > 0 && (u64)m_next * 2 >= m && m >= kPairsMin && !use_sweep;
   u32* sa_out = (emit && !fin_active) ? nullptr : d_SA;   // finisher route: the bridge will want the finished suffixes' slots
-  u32* rank_arg = text ? nullptr : d_rank;                // text rounds: rank[] is neither complete nor needed
+  u32* rank_arg = (text && !ranks_live) ? nullptr : d_rank;   // text rounds before rank[] is completed: neither complete nor needed; after: kept exact
   // Long items of which at most half is still tied (a 256 MiB text block: 21 %, a 1 GiB one: 37 %): the finisher
   // settles the rest by direct comparison (suffix_sort); rank[] is not written at all.  Above that the list is
   // dominated by long repeats and the doubling rounds are the better tool.
@@ -2089,7 +2112,8 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
 // the base-sigma key.  The gram length is the longest whose universe fits kGramMaxU; the key takes
 // as few grams as cover the base-sigma key's characters, and is used when that saves a radix pass.
 static constexpr int kSmallGram = 526;
-static constexpr int kSmallFin = 528;     // finisher: entries of the next list, of the hard list
+static constexpr int kSmallFin = 528;     // finisher: counts and smallest depths of the hard and shallow lists (finish_list)
+static constexpr int kSmallFinNext = 540; // finisher: entries of the next list's kFinRegions regions
 int BwtEngine::plan_grams(const KeyPlan& plan, u32 n, const u8* d_lut, GramPlan* gp) {
   hipStream_t st = stream;
   gp->G = 0;
@@ -2177,7 +2201,6 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   RankBuffers rb;
   rb.aglob = nullptr;
   rb.aglob_next = d_G0;
-  u32* aglob_spare = d_G1;
   RankResult res;
   res.finish = false;
   u64 h = (u64)plan.k;                    // the next round compares rank[s + h]
@@ -2238,7 +2261,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       rc = upload_inverse_lut();
       if (rc) return rc;
       BWTC_HIP_TRY(hipMemsetAsync(d_pairs, 0, (size_t)kPairReplicas * 65536 * 4, st));
-      const u32 sample_tiles = std::min<u32>(ceil_div(n, kPairTile), 1024u);
+      const u32 sample_tiles = std::min<u32>(ceil_div(n, kPairTile), 512u);
       hipLaunchKernelGGL(k_pair_counts, dim3(sample_tiles), dim3(256), 0, st, (const u8*)d_T, d_lut, n, d_pairs);
       hipLaunchKernelGGL(k_code_build, dim3(kCodeRows), dim3(256), 0, st, (const u32*)d_pairs, plan.sigma, d_codes, d_small + kSmallError);
       hipLaunchKernelGGL(k_make_keys_code, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u8*)d_T, d_lut, ka, d_W0, n, key_plane, split_now, ck);
@@ -2354,85 +2377,118 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     stats.alg_bytes += (u64)n * (1 + (u64)(plan.wide ? 8 : 4) + 1) + sort_bytes(n, (key_bits + kRadixBits - 1) / kRadixBits, item, plan.wide ? 8 : 4, digit_planes);
   }
 
-  u32 m = res.m;
-  bool keep_h = false;                     // the list is sorted to depth h as it stands (no doubling before the next step)
-  int text_left = 0;                       // rounds that compare the text itself (finisher route, rank[] incomplete)
-  int text_extra = text_rounds_fixed ? 0 : 12;        // further ones, one at a time, while the list is short (not when BWTC_HIP_TEXT_ROUNDS says how many)
   bool ranks_complete = true;
+  // The rounds over the sorted list in res / rb, from depth h0 until nothing is tied.  text_rounds_now: rounds that compare
+  // the text itself first (finisher route: rank[] is not complete, and completing it costs an ISA scatter of the whole block).
+  auto run_rounds = [&](u32 m, u64 h0, int text_rounds_now, bool keep_first) -> int {
+    u64 h = h0;
+    bool keep_h = keep_first;                // the list is sorted to depth h as it stands (no doubling before the next step)
+    int text_left = text_rounds_now;
+    int text_extra = text_rounds_fixed ? 0 : 12;        // further ones, one at a time, while the list is short (not when BWTC_HIP_TEXT_ROUNDS says how many)
+    while (m > 0) {
+      if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
+      ++stats.rounds;
+      stats.active_sum += m;
+      const bool text = text_left > 0;
+      if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u%s: h=%llu m=%u groups=%u\n", stats.rounds, text ? " (text)" : "", (unsigned long long)h, m, res.groups);
+      if (!keep_h) h *= 2;
+      keep_h = false;
+      if (!text && !ranks_complete) {
+        // the doubling rounds start here: rank[] for everybody first (the finished from SA; the list's own
+        // ranks come from the ranking step below, before anything reads them; a parked list's are its groups' heads)
+        complete_ranks(n, res.vs, rb.aglob_next, m, res.rec_other == d_R2 ? (res.ks == (u64*)d_R1 ? (void*)d_W0 : d_R1) : d_R2, res.rec_other);
+        ranks_complete = true;
+        ranks_live = true;
+        bridged = true;
+        stats.route |= 8u;
+        stats.alg_bytes += (u64)n * (4 + 8);                // k_bridge_pairs_all (the partition and scatter count themselves)
+      }
+      // the list just sorted: positions are the active list's, aglob gives their global slots
+      rb.aglob = rb.aglob_next;
+      rb.aglob_next = rb.aglob == d_G0 ? d_G1 : d_G0;
+      { u8* t = re.achr_out; re.achr_out = achr_other; achr_other = t; }
+      rb.rec_keys = res.ks; rb.rec_free = res.rec_other;
+      rb.v_keys = res.vs; rb.v_free = res.v_other;
+      const u64* ks = res.ks;
+      const u32* vs = res.vs;
+      const bool carried = emit && res.carry;             // this list's keys hold the characters in bits 56..63
+      const int rc2 = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text, carried);
+      if (rc2) return rc2;
+      m = res.m;
+      if (text) {
+        h += res.text_chars; keep_h = true; --text_left;
+        // Out of text rounds with a short list left: a few more cost tens of microseconds each, the doubling rounds
+        // cost the completion of rank[] for the whole block first (5 ms per 256 MiB, 16 ms for the 1 GiB text -- the
+        // block whose text rounds ended with 10 entries still tied paid it).  Long lists (deep repeats) go on to the
+        // doubling rounds as before: their depth doubles there and only creeps here.
+        if (text_left == 0 && m > 0 && (u64)m * 4096 < (u64)n && text_extra > 0) { text_left = 1; --text_extra; }
+      }
+    }
+    return 0;
+  };
+  ranks_live = false;
+  parked = 0;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
-    u32 m2 = 0; u64 h2 = 0;
-    rc = finish_list(n, m, rb, re, &res, &m2, &h2);
+    u32 shallow = 0; u64 h_sh = 0, h_pk = 0;
+    rc = finish_list(n, res.m, rb, re, &shallow, &h_sh, &h_pk);
     if (rc) return rc;
-    m = m2;
-    // (text rounds -- a global sort per six characters -- are for what is left of a text; a long list is deep
-    // repeats, which only doubling gets through)
-    if (m) { h = h2; keep_h = true; text_left = (u64)m * 16 < (u64)n || text_rounds_fixed ? text_rounds : 0; ranks_complete = false; }
-    lf_noted = true;
-  }
-  while (m > 0) {
-    if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
-    ++stats.rounds;
-    stats.active_sum += m;
-    const bool text = text_left > 0;
-    if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u%s: h=%llu m=%u groups=%u\n", stats.rounds, text ? " (text)" : "", (unsigned long long)h, m, res.groups);
-    if (!keep_h) h *= 2;
-    keep_h = false;
-    if (!text && !ranks_complete) {
-      // the doubling rounds start here: rank[] for everybody first (the finished from SA; the list's own
-      // ranks come from the ranking step below, before anything reads them)
-      complete_ranks(n, res.vs, rb.aglob_next, m, res.rec_other == d_R2 ? (res.ks == (u64*)d_R1 ? (void*)d_W0 : d_R1) : d_R2, res.rec_other);
-      ranks_complete = true;
-      bridged = true;
-      stats.route |= 8u;
-      stats.alg_bytes += (u64)n * (4 + 8);                // k_bridge_pairs_all (the partition and scatter count themselves)
-      lf_noted = false;
+    lf_noted = true;                       // every suffix that becomes final notes its LF power (lf_note), in every route
+    ranks_complete = false;
+    // text rounds -- a global sort per six characters -- are for what is left of a text; a long list is deep repeats,
+    // which only doubling gets through
+    auto text_for = [&](u32 m) { return ((u64)m * 16 < (u64)n || text_rounds_fixed) ? text_rounds : 0; };
+    if (shallow) {
+      // the few hard groups of little depth first, to the end (the parked list's suffixes rank as their groups' heads meanwhile)
+      rc = dress_list(n, shallow, rb.v_keys, static_cast<u64*>(rb.rec_free), rb, &res);
+      if (rc) return rc;
+      rc = run_rounds(shallow, std::max<u64>(1, h_sh), text_for(shallow), true);
+      if (rc) return rc;
     }
-    // the list just sorted: positions are the active list's, aglob gives their global slots
-    rb.aglob = rb.aglob_next;
-    rb.aglob_next = aglob_spare;
-    aglob_spare = rb.aglob;
-    { u8* t = re.achr_out; re.achr_out = achr_other; achr_other = t; }
-    rb.rec_keys = res.ks; rb.rec_free = res.rec_other;
-    rb.v_keys = res.vs; rb.v_free = res.v_other;
-    const u64* ks = res.ks;
-    const u32* vs = res.vs;
-    const bool carried = emit && res.carry;             // this list's keys hold the characters in bits 56..63
-    rc = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text, carried);
+    if (parked) {
+      const u32 total = parked;
+      BWTC_HIP_TRY(hipMemcpyAsync(d_V0, d_parkS, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+      BWTC_HIP_TRY(hipMemcpyAsync(d_R1, d_parkHP, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
+      parked = 0;                          // (the list is in the rounds' hands now: complete_ranks takes it from them)
+      rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res);
+      if (rc) return rc;
+      rc = run_rounds(total, std::max<u64>(1, h_pk), text_for(total), true);
+      if (rc) return rc;
+    }
+  } else {
+    rc = run_rounds(res.m, h, 0, false);
     if (rc) return rc;
-    m = res.m;
-    if (text) {
-      h += res.text_chars; keep_h = true; --text_left;
-      // Out of text rounds with a short list left: a few more cost tens of microseconds each, the doubling rounds
-      // cost the completion of rank[] for the whole block first (5 ms per 256 MiB, 16 ms for the 1 GiB text -- the
-      // block whose text rounds ended with 10 entries still tied paid it).  Long lists (deep repeats) go on to the
-      // doubling rounds as before: their depth doubles there and only creeps here.
-      if (text_left == 0 && m > 0 && (u64)m * 4096 < (u64)n && text_extra > 0) { text_left = 1; --text_extra; }
-    }
   }
   BWTC_HIP_TRY(hipGetLastError());
   BWTC_HIP_TRY(take_sticky_error());
   return 0;
 }
 
-// The finisher passes over the list the long-key ranking left (k_finish), and -- when something is
-// still tied after them, or a group was too large for them -- the bridge into the rounds.
-// On return *m_out entries (0: all done) wait in res / rb as a sorted list of depth *h_out.
-// Every entry knows the depth its group shares (the upper byte of its character field); a pass adds
-// kFinChars to it.  Passes go on while the list shrinks: one that keeps more than three fifths of a
-// list that is still longer than n / 64 has met deep repeats (copies of whole files, not of lines),
-// which only doubling gets through.
-int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, RankResult* res, u32* m_out, u64* h_out) {
+// The finisher passes over the list the long-key ranking left (k_finish).  Every entry knows the depth
+// its group shares (the upper byte of its character field); a pass adds kFinChars to it.  Passes go on
+// while the list shrinks: one that keeps more than three fifths of a list that is still longer than
+// n / 64 has met deep repeats (copies of whole files, not of lines), which only doubling gets through.
+// What is left for the rounds, as raw lists (suffix; head slot << 32 | slot), unsorted:
+//   *shallow entries in (rb.v_keys, rb.rec_free): groups too large for a window that share fewer than
+//    fin_floor characters; they share at least *h_shallow
+//   `parked` entries in (d_parkS, d_parkHP): the other groups too large for a window, and what the last
+//    pass left tied; at least *h_parked characters
+int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, u32* shallow, u64* h_shallow, u64* h_parked) {
   hipStream_t st = stream;
-  u32* cnt = d_small + kSmallFin;                      // [0] next list, [1] hard list, [2] hard list's smallest depth (adjacent: k_finish's hard_count)
+  u32* cnt = d_small + kSmallFin;      // [1] hard list, [2] its smallest depth; [3] smallest depth of the last pass's leftovers; [4] shallow list, [5] its smallest depth
+  u32* ncnt = d_small + kSmallFinNext; // entries of the next list, region by region
   FinList a{rb.v_free, rb.aglob_next, d_GRP, reinterpret_cast<unsigned short*>(re.achr_out)};
   FinList b{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
-  u64* hardHP = static_cast<u64*>(rb.rec_free);
-  u32* hardS = rb.v_keys;
+  FinShallow shal{rb.v_keys, static_cast<u64*>(rb.rec_free), cnt + 4, fin_floor};
   h_small[kSmallFin] = 0; h_small[kSmallFin + 1] = 0; h_small[kSmallFin + 2] = 0xFFFFFFFFu; h_small[kSmallFin + 3] = 0xFFFFFFFFu;
-  BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 16, hipMemcpyHostToDevice, st));
+  h_small[kSmallFin + 4] = 0; h_small[kSmallFin + 5] = 0xFFFFFFFFu;
+  BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 24, hipMemcpyHostToDevice, st));
   u32 hard = 0;
   const int window = fin_window, group = fin_max_group;
+  const u32 stride = (u32)(window - group);
+  FinRegions rg;
+  std::memset(&rg, 0, sizeof rg);
+  rg.nreg = 1; rg.wfirst[0] = 0; rg.wfirst[1] = ceil_div(m, stride); rg.ebase[0] = 0; rg.ecount[0] = m;   // the ranking's list is one region
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
@@ -2441,47 +2497,95 @@ int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, RankResult
     // a window of entries is read by the workgroups whose windows overlap there (4/3 on average), sixteen characters
     // (three aligned words) per owned entry, a byte and a suffix per finished one, an entry per member that stays
     stats.alg_bytes += (u64)m * (14 * 4 / 3 + 24 + 5);
-    BWTC_HIP_TRY(hipMemsetAsync(cnt, 0, 4, st));
-#define BWTC_FINISH(G, E) hipLaunchKernelGGL((k_finish<G, E>), dim3(ceil_div(m, (u32)(kFinTPB * E - G))), dim3(kFinTPB), 0, st, a, m, (const u8*)d_T, n, \
-                                             b, cnt, hardS, hardHP, cnt + 1, d_SA, re)
+    BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, kFinRegions * 4, st));
+    const u32 grid = rg.wfirst[rg.nreg];
+    // the regions of the list this pass leaves: chunk c of 64 workgroups appends to region c mod 16 and leaves at most
+    // its workgroups' strides of entries and one group more
+    FinOut ob;
+    {
+      u32 room[kFinRegions] = {};
+      const u32 nchunks = ceil_div(grid, kFinChunk);
+      for (u32 c = 0; c < nchunks; ++c) {
+        const u32 wgs = std::min(kFinChunk, grid - c * kFinChunk);
+        room[c % kFinRegions] += wgs * stride + (u32)group;
+      }
+      u32 at = 0;
+      for (u32 r = 0; r < kFinRegions; ++r) { ob.base[r] = at; at += room[r]; }
+      if ((u64)at > cap + cap / 128 + 65536) return -3;
+    }
+#define BWTC_FINISH(G, E) hipLaunchKernelGGL((k_finish<G, E>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
+                                             b, ob, ncnt, d_parkS, d_parkHP, cnt + 1, shal, d_SA, re)
     if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
     else if (group <= 256) BWTC_FINISH(256, 8);
     else if (group <= 512) BWTC_FINISH(512, 8);
     else BWTC_FINISH(1024, 8);
 #undef BWTC_FINISH
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 12, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 24, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, kFinRegions * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
     const u32 m_was = m;
+    // what the pass left, region by region
+    {
+      FinRegions nx;
+      std::memset(&nx, 0, sizeof nx);
+      u32 total = 0;
+      for (u32 r = 0; r < kFinRegions; ++r) {
+        const u32 c = h_small[kSmallFinNext + r];
+        if (!c) continue;
+        nx.ebase[nx.nreg] = ob.base[r]; nx.ecount[nx.nreg] = c;
+        nx.wfirst[nx.nreg + 1] = nx.wfirst[nx.nreg] + ceil_div(c, stride);
+        ++nx.nreg;
+        total += c;
+      }
+      if (nx.nreg == 0) nx.nreg = 1;
+      rg = nx;
+      m = total;
+    }
     if (std::getenv("BWTC_HIP_DEBUG"))
-      std::fprintf(stderr, "finisher pass %d: %u entries -> %u still tied, %u hard (depth from %u)\n", it, m, h_small[kSmallFin],
-                   h_small[kSmallFin + 1], h_small[kSmallFin + 2]);
-    m = h_small[kSmallFin];
+      std::fprintf(stderr, "finisher pass %d: %u entries -> %u still tied; %u hard (depth from %u), %u shallow (from %u)\n", it, m_was, m,
+                   h_small[kSmallFin + 1], h_small[kSmallFin + 2], h_small[kSmallFin + 4], h_small[kSmallFin + 5]);
     hard = h_small[kSmallFin + 1];
     std::swap(a, b);
     if (it >= 1 && (u64)m * 5 > (u64)m_was * 3 && (u64)m * 64 > (u64)n) break;     // deep repeats: on to the rounds
   }
-  *m_out = 0;
-  if (m == 0 && hard == 0) return 0;
-  // ---- what is still tied becomes a list the rounds understand: sorted by slot (groups contiguous,
-  // a positional slot array), key = head slot | character << 56, value = suffix
-  if (m) hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(m, 256)), dim3(256), 0, st, a, m, hardS, hardHP, hard, cnt + 3);
-  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 2, cnt + 2, 8, hipMemcpyDeviceToHost, st));
-  const u32 total = hard + m;
-  if ((u64)total > cap) return -3;
+  if (m) {
+    u32 at = hard;
+    for (u32 r = 0; r < rg.nreg; ++r) {
+      if (!rg.ecount[r]) continue;
+      FinList part{a.S + rg.ebase[r], a.P + rg.ebase[r], a.H + rg.ebase[r], a.C + rg.ebase[r]};
+      hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], d_parkS, d_parkHP, at, cnt + 3);
+      at += rg.ecount[r];
+    }
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 3, cnt + 3, 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(wait());
+  }
+  if ((u64)hard + m > cap) return -3;
+  parked = hard + m;
+  *shallow = h_small[kSmallFin + 4];
+  *h_shallow = h_small[kSmallFin + 5];
+  *h_parked = std::min(h_small[kSmallFin + 2], h_small[kSmallFin + 3]);
+  if (std::getenv("BWTC_HIP_DEBUG") && (parked || *shallow))
+    std::fprintf(stderr, "finisher: %u entries (%u of groups too large) go on to the rounds at depth %llu, %u shallow ones at depth %llu\n",
+                 parked, hard, (unsigned long long)*h_parked, *shallow, (unsigned long long)*h_shallow);
+  return 0;
+}
+
+// A raw list becomes a list the rounds understand: sorted by slot (groups contiguous, a positional slot
+// array), key = head slot | character << 56, value = suffix.  S / HP must be one of (d_V0 | d_V1) and one
+// of (d_R1 | d_R2); d_W0 / d_W1 and d_G0 receive the list.
+int BwtEngine::dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res) {
+  hipStream_t st = stream;
+  u64* hp_other = HP == static_cast<u64*>(d_R1) ? static_cast<u64*>(d_R2) : static_cast<u64*>(d_R1);
+  u32* s_other = S == d_V0 ? d_V1 : d_V0;
   u64* hp_sorted = nullptr; u32* s_sorted = nullptr;
-  sort_pairs<u64>(hardHP, static_cast<u64*>(rb.rec_keys), hardS, rb.v_free, total, bit_width_u64(n ? n - 1 : 0),
-                  &hp_sorted, &s_sorted, false);
+  sort_pairs<u64>(HP, hp_other, S, s_other, total, bit_width_u64(n ? n - 1 : 0), &hp_sorted, &s_sorted, false);
   u64* fkey = reinterpret_cast<u64*>(d_W0);              // d_W0 and d_W1 are neighbours in the arena: 8 * cap bytes
   hipLaunchKernelGGL(k_bridge_dress, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)hp_sorted, (const u32*)s_sorted,
                      total, (const u8*)d_T, fkey, d_G0);
-  BWTC_HIP_TRY(wait());
   res->m = total; res->groups = 0;
   res->ks = fkey; res->rec_other = d_R1;
   res->vs = s_sorted; res->v_other = s_sorted == d_V0 ? d_V1 : d_V0;
   rb.aglob_next = d_G0;
-  *m_out = total;
-  *h_out = std::min(h_small[kSmallFin + 2], h_small[kSmallFin + 3]);     // every group of the list shares at least that many characters
-  if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "finisher: %u entries (%u hard) go on to the rounds at depth %llu\n", total, hard, (unsigned long long)*h_out);
   return 0;
 }
 
@@ -2492,6 +2596,7 @@ void BwtEngine::complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot,
   u32* pairs = static_cast<u32*>(pairs_region);
   hipLaunchKernelGGL(k_bridge_pairs_all, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u32*)d_SA, n, pairs, pairs + cap);
   if (m) hipLaunchKernelGGL(k_bridge_pairs_fix, dim3(ceil_div(m, 256)), dim3(256), 0, st, list_sfx, list_slot, m, pairs, pairs + cap);
+  if (parked) hipLaunchKernelGGL(k_bridge_pairs_fix_parked, dim3(ceil_div(parked, 256)), dim3(256), 0, st, (const u32*)d_parkS, (const u64*)d_parkHP, parked, pairs, pairs + cap);
   scatter_rank_pairs(pairs, static_cast<u32*>(tmp_region), n, n);
 }
 

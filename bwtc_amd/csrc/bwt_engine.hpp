@@ -406,6 +406,11 @@ struct BwtEngine {
   int code_bits = 72;        // BWTC_HIP_CODE_BITS=N (40..72): bits of a code key (the low 32 in the second word)
   u32* d_pairs = nullptr;    // code keys: sampled character-pair counts (kPairReplicas x 65536 words), and the code table (257 x 256 words)
   u32* d_codes = nullptr;
+  u32* d_parkS = nullptr;    // finisher route: the hard list (suffix; head slot << 32 | slot) while the shallow list takes its rounds
+  u64* d_parkHP = nullptr;
+  u32 parked = 0;            // this block: entries waiting there
+  bool ranks_live = false;   // this block: rank[] has been completed (every ranking step keeps it exact from then on)
+  u32 fin_floor = 12;        // BWTC_HIP_FIN_FLOOR: hard groups that share fewer characters take their rounds first, on their own
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
   int fin_window = 1024;     // BWTC_HIP_FIN_WINDOW=2048: entries a finisher workgroup sorts
   int fin_max_group = 256;   // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
@@ -416,7 +421,10 @@ struct BwtEngine {
   bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
-  int finish_list(u32 n, u32 m, RankBuffers& rb, struct RrEmit& re, RankResult* res, u32* m_out, u64* h_out);
+  // finisher passes; what they leave: *shallow entries in (rb.v_keys, rb.rec_free), `parked` entries in d_parkS / d_parkHP
+  int finish_list(u32 n, u32 m, RankBuffers& rb, struct RrEmit& re, u32* shallow, u64* h_shallow, u64* h_parked);
+  // a raw list (suffix; head slot << 32 | slot) in (S, HP) -> a sorted list the rounds understand, in res / rb
+  int dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);
