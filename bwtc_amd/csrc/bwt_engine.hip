@@ -672,6 +672,7 @@ __device__ __forceinline__ u32 lane_value(u32 v, int l) { return __shfl(v, l, kW
 // finisher in the upper byte of the list entry's 16-bit character field.
 struct RrLong { const u32* w; u32 wmask; int hi_shift; int chr_shift; u32 chr_mask; int lvl_shift; u32 depth; };
 
+
 template <typename K, bool INIT, bool SPLIT, bool LONG = false>
 __device__ __forceinline__ void rr_masks(const K* __restrict__ key, const u32* __restrict__ idx,
                                          u32 m, u32 n, u32 short_len, K kmask, u32 wbase, u32 lane,
@@ -1027,7 +1028,6 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 // number) is the smaller -- they are never equal (the network's comparison knows).
 // ---------------------------------------------------------------------------------------
 constexpr int kFinTPB = 256;
-constexpr u32 kFinChars = 16;                       // characters compared per pass
 constexpr u32 kFinNone = 0xFFFFFFFFu;
 
 struct FinList { u32* S; u32* P; u32* H; unsigned short* C; };
@@ -1060,22 +1060,43 @@ __device__ __forceinline__ void fin_chars(const u8* __restrict__ T, u32 pos, u32
   *c1 = __builtin_bswap64(hi);
 }
 
+// 8 NW characters T[pos .. pos + 8 NW) as NW big-endian words; bytes at or past n read as zero
+template <int NW>
+__device__ __forceinline__ void fin_chars_n(const u8* __restrict__ T, u32 pos, u32 n, u64 (&c)[NW]) {
+#pragma unroll
+  for (int q = 0; q < NW; ++q) c[q] = 0;
+  if (pos >= n) return;
+  const u64* a = reinterpret_cast<const u64*>(T + (pos & ~7u));      // T is 256-byte aligned and padded
+  const u32 sh = (pos & 7u) * 8u;
+  u64 w[NW + 1];
+#pragma unroll
+  for (int q = 0; q <= NW; ++q) w[q] = a[q];
+  const u32 left = n - pos;                                          // real bytes from pos on
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    u64 v = sh ? (w[q] >> sh) | (w[q + 1] << (64u - sh)) : w[q];     // bytes pos + 8 q .. + 7, first byte lowest
+    if (left < 8u * (u32)(q + 1)) v = left <= 8u * (u32)q ? 0ull : v & ((1ull << (8u * (left - 8u * (u32)q))) - 1ull);
+    c[q] = __builtin_bswap64(v);
+  }
+}
+
 // hard_count[0]: entries of the hard list, [1]: the smallest depth among them.  Hard entries whose group shares fewer
 // than shal.floor characters go to a list of their own (shal.count[0], [1]: entries, smallest depth): the rounds work
 // at ONE depth for all their groups, the smallest, and a few groups of some exotic but repetitive string (bytes the
 // code's sample never saw: a depth of one or two characters) would drag a whole text's hard groups down to theirs.
 struct FinShallow { u32* S; u64* HP; u32* count; u32 floor; };
-template <int kFinMaxGroup, int E_ = 4>
+template <int kFinMaxGroup, int E_ = 4, int NW = 2>
 __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, const u8* __restrict__ T, u32 n,
                                                     FinList next, FinOut ob, u32* __restrict__ next_count,
-                                                    u32* __restrict__ hardS, u64* __restrict__ hardHP,
+                                                    u32* __restrict__ hardS, u64* __restrict__ hardHP, unsigned short* __restrict__ hardC,
                                                     u32* __restrict__ hard_count, FinShallow shal, u32* __restrict__ SA, RrEmit em) {
   constexpr int kFinE = E_;                                           // entries per thread: a window of 1024 or 2048
   constexpr int kFinWin = kFinTPB * kFinE;
   static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
   constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
-  __shared__ __attribute__((aligned(16))) u64 s_ch[kFinWin * 2];      // the characters; later the reorder staging
-  __shared__ u32 s_S[kFinWin];                                        // suffix | reaches past the end << 31
+  constexpr u32 kChars = 8u * NW;                                     // characters compared by this pass
+  __shared__ __attribute__((aligned(16))) u64 s_ch[(kFinWin + 4) * NW];   // the characters (+ padding for the comparison loop's reads); later the reorder staging
+  __shared__ u32 s_S[kFinWin + 4];                                    // suffix | reaches past the end << 31
   __shared__ u32 s_H[kFinWin];
   __shared__ unsigned short s_g[kFinWin + 2];                         // group size by start position; [kFinWin]: the group cut by the window's start
   __shared__ u32 scr[kFinTPB / kWave + 1];
@@ -1131,18 +1152,20 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
     }
   }
   // characters of the members this workgroup settles, each from its own group's depth
-  u64 c0[kFinE], c1[kFinE];
+  u64 ch[kFinE][NW];
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    c0[e] = 0; c1[e] = 0;
-    if (A[e] >= 0) fin_chars(T, S[e] + (C[e] >> 8), n, &c0[e], &c1[e]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) ch[e][q] = 0;
+    if (A[e] >= 0) fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, ch[e]);
   }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     if (A[e] >= 0) {
       const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 touch = ((u64)S[e] + (C[e] >> 8) + kFinChars > (u64)n) ? 0x80000000u : 0u;
-      s_ch[2u * lp] = c0[e]; s_ch[2u * lp + 1u] = c1[e];
+      const u32 touch = ((u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 0x80000000u : 0u;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = ch[e][q];
       s_S[lp] = S[e] | touch;
     }
   }
@@ -1159,15 +1182,33 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
       const u32 lp = tid + (u32)e * kFinTPB;
       const u32 me = s_S[lp];
       u32 below = 0, eq_before = 0, eq_all = 0;
-      for (u32 j = (u32)A[e]; j < (u32)A[e] + G[e]; ++j) {
-        const u64 d0 = s_ch[2u * j], d1 = s_ch[2u * j + 1u];
-        const u32 sj = s_S[j];
-        bool lt = d0 < c0[e] || (d0 == c0[e] && d1 < c1[e]);
-        bool eq = d0 == c0[e] && d1 == c1[e];
-        if (eq && ((sj | me) >> 31) && j != lp) { lt = (sj & 0x7FFFFFFFu) > S[e]; eq = false; }
-        below += lt ? 1u : 0u;
-        eq_all += eq ? 1u : 0u;
-        eq_before += (eq && j < lp) ? 1u : 0u;
+      const u32 jend = (u32)A[e] + G[e];
+      // four members per step, their LDS reads issued together (one member per step was a chain of LDS latencies);
+      // positions past the group's end are read (inside the arrays: they are padded) and not counted
+      for (u32 j0 = (u32)A[e]; j0 < jend; j0 += 4u) {
+        u32 sj[4];
+        u64 dd[4][NW];
+#pragma unroll
+        for (u32 u = 0; u < 4u; ++u) {
+          sj[u] = s_S[j0 + u];
+#pragma unroll
+          for (int q = 0; q < NW; ++q) dd[u][q] = s_ch[(u32)NW * (j0 + u) + (u32)q];
+        }
+#pragma unroll
+        for (u32 u = 0; u < 4u; ++u) {
+          const u32 j = j0 + u;
+          bool lt = false, eq = true;
+#pragma unroll
+          for (int q = 0; q < NW; ++q) {
+            lt = lt || (eq && dd[u][q] < ch[e][q]);
+            eq = eq && dd[u][q] == ch[e][q];
+          }
+          if (eq && ((sj[u] | me) >> 31) && j != lp) { lt = (sj[u] & 0x7FFFFFFFu) > S[e]; eq = false; }
+          const bool in = j < jend;
+          below += (in && lt) ? 1u : 0u;
+          eq_all += (in && eq) ? 1u : 0u;
+          eq_before += (in && eq && j < lp) ? 1u : 0u;
+        }
       }
       R[e] = below; Q[e] = eq_before | (eq_all << 16);
     }
@@ -1184,7 +1225,7 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
       st_S[np] = S[e];
       st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
       st_H[np] = (H[e] + R[e]) | fin;
-      st_C[np] = (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kFinChars) << 8));
+      st_C[np] = (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kChars) << 8));
     }
   }
   // the hard entries of this workgroup's stride range, in any order; one atomic per workgroup and list (a wave's own
@@ -1206,7 +1247,7 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
 #pragma unroll
     for (int e = 0; e < kFinE; ++e) {
       if ((hm >> e) & 1u) {
-        hardS[hat] = S[e]; hardHP[hat] = ((u64)H[e] << 32) | (u64)P[e]; ++hat;
+        hardS[hat] = S[e]; hardHP[hat] = ((u64)H[e] << 32) | (u64)P[e]; hardC[hat] = (unsigned short)C[e]; ++hat;
         hard_depth = min(hard_depth, C[e] >> 8);
       } else if ((sm >> e) & 1u) {
         shal.S[sat] = S[e]; shal.HP[sat] = ((u64)H[e] << 32) | (u64)P[e]; ++sat;
@@ -1272,6 +1313,13 @@ __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __r
   for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
   // the depth the rounds may start from (an atomic only where it lowers what is there: one per wave was 15 ms for 85 M entries)
   if (lane_id() == 0 && d != 0xFFFFFFFFu && d < __hip_atomic_load(min_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(min_depth, d);
+}
+__global__ __launch_bounds__(256) void k_raw_to_park(const u32* __restrict__ S, const u32* __restrict__ P, const u32* __restrict__ H, u32 m,
+                                                     u32* __restrict__ parkS, u64* __restrict__ parkHP, u32 at) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  parkS[at + i] = S[i];
+  parkHP[at + i] = ((u64)H[i] << 32) | (u64)P[i];
 }
 __global__ __launch_bounds__(256) void k_bridge_dress(const u64* __restrict__ hp, const u32* __restrict__ sfx, u32 m,
                                                       const u8* __restrict__ T, u64* __restrict__ key,
@@ -1556,7 +1604,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_parkS, off_parkHP, off_pairs, off_codes, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_parkS, off_parkHP, off_hardS, off_hardHP, off_hardC, off_pairs, off_codes, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -1594,8 +1642,11 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_ent = take(2u << 20);
   a.off_comp = take(huffman_compress_bound(cap));
   a.off_sweep = take(SweepWs::small_words() * 4);
-  a.off_parkS = take(cap * 4);          // finisher route: the hard list waits here while the shallow one takes its rounds
+  a.off_parkS = take(cap * 4);          // finisher route: what waits for the rounds (the passes' leftovers, groups the code rounds gave up on)
   a.off_parkHP = take(cap * 8);
+  a.off_hardS = take(cap * 4);          // finisher route: the groups too large for a window, until their code round
+  a.off_hardHP = take(cap * 8);
+  a.off_hardC = take(cap * 2 + 64);
   a.off_pairs = take((u64)kPairReplicas * 65536 * 4);
   a.off_codes = take((u64)kCodeRows * 256 * 4);
   a.total = o;
@@ -1649,6 +1700,9 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_sweep = reinterpret_cast<u32*>(base + a.off_sweep);
   d_parkS = reinterpret_cast<u32*>(base + a.off_parkS);
   d_parkHP = reinterpret_cast<u64*>(base + a.off_parkHP);
+  d_hardS = reinterpret_cast<u32*>(base + a.off_hardS);
+  d_hardHP = reinterpret_cast<u64*>(base + a.off_hardHP);
+  d_hardC = reinterpret_cast<unsigned short*>(base + a.off_hardC);
   d_pairs = reinterpret_cast<u32*>(base + a.off_pairs);
   d_codes = reinterpret_cast<u32*>(base + a.off_codes);
   {
@@ -1686,6 +1740,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_GRAM_MIN_N")) gram_min_n = (u32)std::max(64, std::atoi(std::getenv("BWTC_HIP_GRAM_MIN_N")));   // tests: small blocks through the gram / long-key routes
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
+    if (std::getenv("BWTC_HIP_FIN_WORDS")) fin_words = std::min(4, std::max(2, std::atoi(std::getenv("BWTC_HIP_FIN_WORDS"))));
     if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
@@ -1948,7 +2003,7 @@ void BwtEngine::scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n) {
 template <typename K, bool INIT>
 int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask,
                          RankBuffers& rb, RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split,
-                         const RrLong* lg, bool text, bool carry_in) {
+                         const RrLong* lg, bool text, bool carry_in, bool raw_out) {
   hipStream_t st = stream;
   u32* counts = d_small + kSmallCounts;
   const u32 tiles = ceil_div(m, kRrTile);
@@ -2066,6 +2121,12 @@ int BwtEngine::rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len
     return 0;
   }
   u32* pairs = reinterpret_cast<u32*>(recA);
+  if (raw_out) {
+    // the list goes back to its owner as it is now grouped: suffix, slot, head slot (rb.v_free, rb.aglob_next, d_GRP)
+    BWTC_APPLY(3, (u32*)nullptr, (u32*)nullptr, rb.v_free);
+    res->carry = emit;
+    return 0;
+  }
   if (text) {
     // text round: rank[] is neither complete nor needed
     res->text_chars = (u32)std::min(6, (56 - b1 - 4) / 8);
@@ -2380,7 +2441,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   bool ranks_complete = true;
   // The rounds over the sorted list in res / rb, from depth h0 until nothing is tied.  text_rounds_now: rounds that compare
   // the text itself first (finisher route: rank[] is not complete, and completing it costs an ISA scatter of the whole block).
-  auto run_rounds = [&](u32 m, u64 h0, int text_rounds_now, bool keep_first) -> int {
+  // doubling == false: text rounds only; what they leave tied comes back raw in (rb.v_free, rb.aglob_next, d_GRP) --
+  // suffix, slot, head slot -- *left entries at depth *h_left.
+  u32 shallow_depth = 0xFFFFFFFFu;
+  auto run_rounds = [&](u32 m, u64 h0, int text_rounds_now, bool keep_first, bool doubling, u32* left, u64* h_left) -> int {
     u64 h = h0;
     bool keep_h = keep_first;                // the list is sorted to depth h as it stands (no doubling before the next step)
     int text_left = text_rounds_now;
@@ -2390,10 +2454,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       ++stats.rounds;
       stats.active_sum += m;
       const bool text = text_left > 0;
+      const bool raw = !text && !doubling;               // out of text rounds and not allowed to double: hand the list back
       if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u%s: h=%llu m=%u groups=%u\n", stats.rounds, text ? " (text)" : "", (unsigned long long)h, m, res.groups);
       if (!keep_h) h *= 2;
       keep_h = false;
-      if (!text && !ranks_complete) {
+      if (!text && !raw && !ranks_complete) {
         // the doubling rounds start here: rank[] for everybody first (the finished from SA; the list's own
         // ranks come from the ranking step below, before anything reads them; a parked list's are its groups' heads)
         complete_ranks(n, res.vs, rb.aglob_next, m, res.rec_other == d_R2 ? (res.ks == (u64*)d_R1 ? (void*)d_W0 : d_R1) : d_R2, res.rec_other);
@@ -2412,9 +2477,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       const u64* ks = res.ks;
       const u32* vs = res.vs;
       const bool carried = emit && res.carry;             // this list's keys hold the characters in bits 56..63
-      const int rc2 = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text, carried);
+      const int rc2 = rank_step<u64, false>(ks, vs, m, n, 0u, carried ? ((1ull << 56) - 1ull) : ~0ull, rb, re, emit, h, &res, 0u, nullptr, text || raw, carried, raw);
       if (rc2) return rc2;
       m = res.m;
+      if (raw) { *left = m; *h_left = h; return 0; }
       if (text) {
         h += res.text_chars; keep_h = true; --text_left;
         // Out of text rounds with a short list left: a few more cost tens of microseconds each, the doubling rounds
@@ -2424,39 +2490,72 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
         if (text_left == 0 && m > 0 && (u64)m * 4096 < (u64)n && text_extra > 0) { text_left = 1; --text_extra; }
       }
     }
+    if (left) { *left = 0; *h_left = h; }
     return 0;
   };
   ranks_live = false;
   parked = 0;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
-    u32 shallow = 0; u64 h_sh = 0, h_pk = 0;
-    rc = finish_list(n, res.m, rb, re, &shallow, &h_sh, &h_pk);
-    if (rc) return rc;
     lf_noted = true;                       // every suffix that becomes final notes its LF power (lf_note), in every route
     ranks_complete = false;
+    u32* cnt = d_small + kSmallFin;
+    h_small[kSmallFin + 3] = 0xFFFFFFFFu; h_small[kSmallFin + 4] = 0; h_small[kSmallFin + 5] = 0xFFFFFFFFu;
+    BWTC_HIP_TRY(hipMemcpyAsync(cnt + 3, h_small + kSmallFin + 3, 12, hipMemcpyHostToDevice, st));
+    // the ranking's list through the finisher
+    FinList la{rb.v_free, rb.aglob_next, d_GRP, reinterpret_cast<unsigned short*>(re.achr_out)};
+    FinList lb{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
+    FinShallow shal{rb.v_keys, static_cast<u64*>(rb.rec_free), cnt + 4, fin_floor};
+    FinOutcome fo;
+    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo);
+    if (rc) return rc;
+    const u32 shallow = h_small[kSmallFin + 4];
+    const u64 h_sh = h_small[kSmallFin + 5];
     // text rounds -- a global sort per six characters -- are for what is left of a text; a long list is deep repeats,
     // which only doubling gets through
     auto text_for = [&](u32 m) { return ((u64)m * 16 < (u64)n || text_rounds_fixed) ? text_rounds : 0; };
     if (shallow) {
-      // the few hard groups of little depth first, to the end (the parked list's suffixes rank as their groups' heads meanwhile)
+      // The few hard groups of little depth first, on their own: text rounds only (rank[] must not go live while
+      // finisher passes are still to come); what they leave tied joins the waiting list, at the depth they reached.
       rc = dress_list(n, shallow, rb.v_keys, static_cast<u64*>(rb.rec_free), rb, &res);
       if (rc) return rc;
-      rc = run_rounds(shallow, std::max<u64>(1, h_sh), text_for(shallow), true);
+      u32 left = 0; u64 h_left = 0;
+      rc = run_rounds(shallow, std::max<u64>(1, h_sh), std::max(text_rounds, 3), true, false, &left, &h_left);
       if (rc) return rc;
+      if (left) {
+        if ((u64)parked + left > cap) return -3;
+        hipLaunchKernelGGL(k_raw_to_park, dim3(ceil_div(left, 256)), dim3(256), 0, st, (const u32*)rb.v_free, (const u32*)rb.aglob_next,
+                           (const u32*)d_GRP, left, d_parkS, d_parkHP, parked);
+        parked += left;
+        shallow_depth = (u32)std::min<u64>(h_left, 0xFFFFFFFFull);
+        if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "shallow groups: %u entries still tied at depth %llu join the waiting list\n", left, (unsigned long long)h_left);
+      }
+    }
+    const u32 hard = fo.hard, hard_depth = fo.hard_depth;
+    if (hard) {
+      // the groups too large for a window wait for the rounds too
+      if ((u64)parked + hard > cap) return -3;
+      BWTC_HIP_TRY(hipMemcpyAsync(d_parkS + parked, d_hardS, (size_t)hard * 4, hipMemcpyDeviceToDevice, st));
+      BWTC_HIP_TRY(hipMemcpyAsync(d_parkHP + parked, d_hardHP, (size_t)hard * 8, hipMemcpyDeviceToDevice, st));
+      parked += hard;
     }
     if (parked) {
+      BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 3, cnt + 3, 4, hipMemcpyDeviceToHost, st));
+      BWTC_HIP_TRY(wait());
+      const u64 h_pk = std::min<u64>(std::min<u64>(h_small[kSmallFin + 3], hard ? hard_depth : 0xFFFFFFFFu), shallow_depth);
       const u32 total = parked;
+      if (std::getenv("BWTC_HIP_DEBUG"))
+        std::fprintf(stderr, "finisher: %u entries (%u of groups too large) go on to the rounds at depth %llu\n", total, hard, (unsigned long long)h_pk);
       BWTC_HIP_TRY(hipMemcpyAsync(d_V0, d_parkS, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
       BWTC_HIP_TRY(hipMemcpyAsync(d_R1, d_parkHP, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
       parked = 0;                          // (the list is in the rounds' hands now: complete_ranks takes it from them)
       rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res);
       if (rc) return rc;
-      rc = run_rounds(total, std::max<u64>(1, h_pk), text_for(total), true);
+      rc = run_rounds(total, std::max<u64>(1, h_pk), text_for(total), true, true, nullptr, nullptr);
       if (rc) return rc;
     }
   } else {
-    rc = run_rounds(res.m, h, 0, false);
+    rc = run_rounds(res.m, h, 0, false, true, nullptr, nullptr);
     if (rc) return rc;
   }
   BWTC_HIP_TRY(hipGetLastError());
@@ -2473,22 +2572,18 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 //    fin_floor characters; they share at least *h_shallow
 //   `parked` entries in (d_parkS, d_parkHP): the other groups too large for a window, and what the last
 //    pass left tied; at least *h_parked characters
-int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, u32* shallow, u64* h_shallow, u64* h_parked) {
+int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, FinShallow shal, FinOutcome* fo) {
   hipStream_t st = stream;
-  u32* cnt = d_small + kSmallFin;      // [1] hard list, [2] its smallest depth; [3] smallest depth of the last pass's leftovers; [4] shallow list, [5] its smallest depth
+  u32* cnt = d_small + kSmallFin;      // [1] hard list, [2] its smallest depth; [3] smallest depth of what waits for the rounds; [4] shallow list, [5] its smallest depth
   u32* ncnt = d_small + kSmallFinNext; // entries of the next list, region by region
-  FinList a{rb.v_free, rb.aglob_next, d_GRP, reinterpret_cast<unsigned short*>(re.achr_out)};
-  FinList b{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
-  FinShallow shal{rb.v_keys, static_cast<u64*>(rb.rec_free), cnt + 4, fin_floor};
-  h_small[kSmallFin] = 0; h_small[kSmallFin + 1] = 0; h_small[kSmallFin + 2] = 0xFFFFFFFFu; h_small[kSmallFin + 3] = 0xFFFFFFFFu;
-  h_small[kSmallFin + 4] = 0; h_small[kSmallFin + 5] = 0xFFFFFFFFu;
-  BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 24, hipMemcpyHostToDevice, st));
+  h_small[kSmallFin] = 0; h_small[kSmallFin + 1] = 0; h_small[kSmallFin + 2] = 0xFFFFFFFFu;
+  BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 12, hipMemcpyHostToDevice, st));
   u32 hard = 0;
   const int window = fin_window, group = fin_max_group;
   const u32 stride = (u32)(window - group);
   FinRegions rg;
   std::memset(&rg, 0, sizeof rg);
-  rg.nreg = 1; rg.wfirst[0] = 0; rg.wfirst[1] = ceil_div(m, stride); rg.ebase[0] = 0; rg.ecount[0] = m;   // the ranking's list is one region
+  rg.nreg = 1; rg.wfirst[0] = 0; rg.wfirst[1] = ceil_div(m, stride); rg.ebase[0] = 0; rg.ecount[0] = m;   // the list as given is one region
   for (int it = 0; it < fin_max_passes && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
@@ -2513,13 +2608,15 @@ int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, u32* shall
       for (u32 r = 0; r < kFinRegions; ++r) { ob.base[r] = at; at += room[r]; }
       if ((u64)at > cap + cap / 128 + 65536) return -3;
     }
-#define BWTC_FINISH(G, E) hipLaunchKernelGGL((k_finish<G, E>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
-                                             b, ob, ncnt, d_parkS, d_parkHP, cnt + 1, shal, d_SA, re)
+#define BWTC_FINISH_W(G, E, NW) hipLaunchKernelGGL((k_finish<G, E, NW>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
+                                             b, ob, ncnt, d_hardS, d_hardHP, d_hardC, cnt + 1, shal, d_SA, re)
+#define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); else BWTC_FINISH_W(G, E, 2); } while (0)
     if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
     else if (group <= 256) BWTC_FINISH(256, 8);
     else if (group <= 512) BWTC_FINISH(512, 8);
     else BWTC_FINISH(1024, 8);
 #undef BWTC_FINISH
+#undef BWTC_FINISH_W
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 24, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, kFinRegions * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
@@ -2547,26 +2644,21 @@ int BwtEngine::finish_list(u32 n, u32 m, RankBuffers& rb, RrEmit& re, u32* shall
     hard = h_small[kSmallFin + 1];
     std::swap(a, b);
     if (it >= 1 && (u64)m * 5 > (u64)m_was * 3 && (u64)m * 64 > (u64)n) break;     // deep repeats: on to the rounds
+    if (it >= 2 && (u64)m * 4 > (u64)m_was * 3) break;                             // a list that hardly shrinks any more: the rounds double, this creeps
   }
   if (m) {
-    u32 at = hard;
+    // what the last pass left tied waits for the rounds
+    if ((u64)parked + m > cap) return -3;
     for (u32 r = 0; r < rg.nreg; ++r) {
       if (!rg.ecount[r]) continue;
       FinList part{a.S + rg.ebase[r], a.P + rg.ebase[r], a.H + rg.ebase[r], a.C + rg.ebase[r]};
-      hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], d_parkS, d_parkHP, at, cnt + 3);
-      at += rg.ecount[r];
+      hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], d_parkS, d_parkHP, parked, cnt + 3);
+      parked += rg.ecount[r];
     }
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 3, cnt + 3, 4, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(wait());
   }
-  if ((u64)hard + m > cap) return -3;
-  parked = hard + m;
-  *shallow = h_small[kSmallFin + 4];
-  *h_shallow = h_small[kSmallFin + 5];
-  *h_parked = std::min(h_small[kSmallFin + 2], h_small[kSmallFin + 3]);
-  if (std::getenv("BWTC_HIP_DEBUG") && (parked || *shallow))
-    std::fprintf(stderr, "finisher: %u entries (%u of groups too large) go on to the rounds at depth %llu, %u shallow ones at depth %llu\n",
-                 parked, hard, (unsigned long long)*h_parked, *shallow, (unsigned long long)*h_shallow);
+  fo->hard = hard;
+  fo->hard_depth = h_small[kSmallFin + 2];
+  fo->left = m;
   return 0;
 }
 

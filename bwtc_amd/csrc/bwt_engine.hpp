@@ -37,6 +37,9 @@ namespace bwtc_hip {
 
 struct RrEmit;
 struct RrLong;
+struct FinList;
+struct FinShallow;
+struct FinOutcome { u32 hard = 0, hard_depth = 0xFFFFFFFFu, left = 0; };   // a finisher run: entries of groups too large (and their smallest depth), entries its last pass left tied
 
 // ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
 // Page-locked host bytes: the packed streams are copied from the device straight into the
@@ -388,7 +391,7 @@ struct BwtEngine {
   template <typename K, bool INIT>
   int rank_step(const K* ks, const u32* vs, u32 m, u32 n, u32 short_len, K kmask, RankBuffers& rb,
                 struct RrEmit re, bool emit, u64 h_next, RankResult* res, u32 split = 0,
-                const struct RrLong* lg = nullptr, bool text = false, bool carry_in = true);
+                const struct RrLong* lg = nullptr, bool text = false, bool carry_in = true, bool raw_out = false);
   bool dense_route = true;   // BWTC_HIP_DENSE=0: always the list-order route (random rank[s+h] gather)
   bool digit_planes = true;  // BWTC_HIP_PLANES=0: every histogram pass reads the keys
   int window_bits = 16;      // BWTC_HIP_WINDOW_BITS: rank[] is updated / read in windows of n >> window_bits suffixes
@@ -409,11 +412,15 @@ struct BwtEngine {
   u32* d_parkS = nullptr;    // finisher route: the hard list (suffix; head slot << 32 | slot) while the shallow list takes its rounds
   u64* d_parkHP = nullptr;
   u32 parked = 0;            // this block: entries waiting there
+  u32* d_hardS = nullptr;    // finisher route: the groups too large for a window (suffix; head slot << 32 | slot; character | depth << 8), until their code round
+  u64* d_hardHP = nullptr;
+  unsigned short* d_hardC = nullptr;
   bool ranks_live = false;   // this block: rank[] has been completed (every ranking step keeps it exact from then on)
   u32 fin_floor = 12;        // BWTC_HIP_FIN_FLOOR: hard groups that share fewer characters take their rounds first, on their own
   bool finisher = true;      // BWTC_HIP_FINISHER=0: after the long-key sort straight into the doubling rounds
   int fin_window = 1024;     // BWTC_HIP_FIN_WINDOW=2048: entries a finisher workgroup sorts
   int fin_max_group = 256;   // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
+  int fin_words = 2;         // BWTC_HIP_FIN_WORDS=2|3|4: 8-character words a finisher pass compares
   int fin_max_passes = 8;    // BWTC_HIP_FIN_PASSES: finisher passes at most before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
   bool text_rounds_fixed = false;
@@ -421,8 +428,9 @@ struct BwtEngine {
   bool bridged = false;      // this block: the finisher handed its rest to the doubling rounds (rank[] is complete)
   bool lf_noted = false;     // this block: the LF powers were noted as suffixes became final (rank[] is not complete)
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
-  // finisher passes; what they leave: *shallow entries in (rb.v_keys, rb.rec_free), `parked` entries in d_parkS / d_parkHP
-  int finish_list(u32 n, u32 m, RankBuffers& rb, struct RrEmit& re, u32* shallow, u64* h_shallow, u64* h_parked);
+  // finisher passes over list a (m entries, one region; b: spare list arrays): groups too large for a window go to
+  // d_hardS / d_hardHP / d_hardC, shallow ones to shal, what the last pass leaves tied is appended to d_parkS / d_parkHP (`parked`)
+  int finisher_passes(u32 n, u32 m, struct FinList a, struct FinList b, struct RrEmit& re, struct FinShallow shal, FinOutcome* fo);
   // a raw list (suffix; head slot << 32 | slot) in (S, HP) -> a sorted list the rounds understand, in res / rb
   int dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word

@@ -484,7 +484,8 @@ static inline void radix_sort_keys_segmented(u32* k0, u32* k1, u64 n, int bit_lo
 template <typename V, int EL = 8>
 static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32* w1, u64 n, int kbits, int wbits,
                                    u32* table, u32* partial, hipStream_t st, u64** k_sorted, V** v_sorted,
-                                   u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1, int wlo = 0) {
+                                   u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1, int wlo = 0,
+                                   bool values_given = false) {
   // wlo: w's lowest bits that do NOT take part in the order (the sorted bits are [wlo, wlo + wbits))
   u64 *kin = k0, *kout = k1;
   V *vin = v0, *vout = v1;
@@ -512,7 +513,7 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
       la.win = win; la.wout = wout; la.dmask = ps[p].dmask; la.bridge = ps[p].bridge;
       la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
       la.nbridge = last ? 0 : ps[p + 1].bridge;
-      const int vmode = p == 0 ? 3 : 0;
+      const int vmode = (p == 0 && !values_given) ? 3 : 0;     // values_given: v0 holds the items' values (else the first pass makes them up)
       const bool timed = probe && probe->begin(st);
 #define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la, SegArgs())
       if (ps[p].from_w == 2) { if (last) BWTC_SCATTER_L(false, 3); else BWTC_SCATTER_L(true, 3); }

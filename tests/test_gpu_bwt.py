@@ -344,13 +344,15 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_LONG=0", "BWTC_HIP_FINISHER=0", "BWTC_HIP_FIN_PASSES=0", "BWTC_HIP_FIN_PASSES=1",
                                     "BWTC_HIP_TEXT_ROUNDS=0", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_LONG_E=6", "BWTC_HIP_LONG_G2=1",
                                     "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0",
-                                    # the last gram's low bits in the sort (default: three of them left out, nine passes
-                                    # instead of ten), and more of them left out than pays
-                                    "BWTC_HIP_LONG_DROP=0", "BWTC_HIP_LONG_DROP=2", "BWTC_HIP_LONG_DROP=1,BWTC_HIP_TEXT_ROUNDS=1",
-                                    "BWTC_HIP_LONG_DROP=3,BWTC_HIP_FIN_PASSES=0", "BWTC_HIP_LONG_DROP=3,BWTC_HIP_FIN_PASSES=1,BWTC_HIP_TEXT_ROUNDS=0",
-                                    # the finisher settling only the smaller groups (the others take the text rounds)
-                                    "BWTC_HIP_FIN_GROUP=1024", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_LONG_DROP=0", "BWTC_HIP_FIN_WINDOW=1024,BWTC_HIP_FIN_GROUP=512",
-                                    "BWTC_HIP_FIN_WINDOW=2048,BWTC_HIP_FIN_GROUP=256"])
+                                    # round 5: the long key's two makers (order-1 prefix code, the default; dense gram codes),
+                                    # shorter code keys, the finisher's window / largest group / characters per pass, and the
+                                    # depth below which a hard group takes its rounds first (0: none does, 48: most do)
+                                    "BWTC_HIP_KEYS=grams", "BWTC_HIP_KEYS=grams,BWTC_HIP_FIN_PASSES=1", "BWTC_HIP_KEYS=grams,BWTC_HIP_LONG_G2=1,BWTC_HIP_TEXT_ROUNDS=0",
+                                    "BWTC_HIP_CODE_BITS=64", "BWTC_HIP_CODE_BITS=48,BWTC_HIP_FIN_PASSES=2", "BWTC_HIP_CODE_BITS=40,BWTC_HIP_TEXT_ROUNDS=1",
+                                    "BWTC_HIP_FIN_FLOOR=0", "BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_FLOOR=48,BWTC_HIP_TEXT_ROUNDS=0",
+                                    "BWTC_HIP_FIN_WORDS=3", "BWTC_HIP_FIN_WORDS=4,BWTC_HIP_FIN_GROUP=512",
+                                    "BWTC_HIP_FIN_GROUP=1024,BWTC_HIP_FIN_WINDOW=2048", "BWTC_HIP_FIN_GROUP=512", "BWTC_HIP_FIN_WINDOW=2048,BWTC_HIP_FIN_GROUP=256",
+                                    "BWTC_HIP_SPLIT_INDEX=0,BWTC_HIP_FIN_PASSES=1"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
@@ -420,7 +422,8 @@ def test_device_pointers_unaligned_and_aliased(hip_ctx, oracle):
         hip_ctx.dfree(out)
 
 
-@pytest.mark.parametrize("extra", ["", "BWTC_HIP_FIN_PASSES=1", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0"])
+@pytest.mark.parametrize("extra", ["", "BWTC_HIP_FIN_PASSES=1", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0",
+                                   "BWTC_HIP_KEYS=grams", "BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_CODE_BITS=48"])
 def test_long_key_route_on_small_structured_blocks(oracle, monkeypatch, extra):
     """The long-key route (long keys, ranking at the long key's depth, finisher, text rounds, late rank completion)
     on blocks small enough for the oracle but of every shape: BWTC_HIP_GRAM_MIN_N lets blocks of a few thousand bytes
@@ -437,12 +440,20 @@ def test_long_key_route_on_small_structured_blocks(oracle, monkeypatch, extra):
     with hip.Context(0, 1 << 20) as ctx:
         for it in range(120):
             n = int(rng.integers(300, 400000))
-            sigma = int(rng.integers(18, 64))
+            # alphabets of a generated text (18-64 symbols) and of a real one (150-230: round 5's code keys exist for those)
+            sigma = int(rng.integers(18, 64)) if it % 4 else int(rng.integers(150, 231))
             alphabet = rng.choice(np.arange(1 if it % 3 else 0, 256), sigma, replace=False).astype(np.uint8)
             words = [alphabet[rng.integers(0, sigma, int(rng.integers(1, 9)))] for _ in range(int(rng.integers(5, 200)))]
             d = np.concatenate([words[int(i)] for i in rng.integers(0, len(words), n // 3 + 8)])[:n].copy()
             n = d.size
             shape = it % 6
+            if it % 5 == 0 and n > 5000:
+                # an exotic but repetitive string: symbols that occur nowhere else (the code's sample gives their pairs the
+                # longest codewords: keys of one or two characters), in a run of thousands -- a hard group of little depth
+                rare = np.setdiff1d(np.arange(1, 256), alphabet)[:3].astype(np.uint8)
+                if rare.size == 3:
+                    a = int(rng.integers(0, n - 4000))
+                    d[a:a + 3000] = np.tile(rare, 1000)
             if shape == 1:                                    # planted repeats of many lengths
                 for _ in range(int(rng.integers(1, 30))):
                     ln = int(min(n // 3, rng.integers(1, 1 + int(rng.choice([40, 2000, 100000])))))
