@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GUIDE_COPY_GBS = 6290.0  # MI355X_MICROARCH.md: what a float4 copy kernel reaches (79 % of the spec peak)
 
 
 def _rss_gb():
@@ -231,8 +232,8 @@ def main():
                          "of 256 blocks and more, when the host has AVX-512 and 40 / 24 GB per rank; else 20, 16 below 40 GB)")
     ap.add_argument("--blocks", type=int, default=4, help="distinct input blocks, cycled")
     ap.add_argument("--workload", default="c3",
-                    help="extras only (the headline is c3): realtext, realtext_rep, dna, random, zeros, period9, reptext -- "
-                         "the inputs of scripts/r4/workloads.py instead of the C3 generator's blocks")
+                    help="extras only (the headline is c3): realtext, pycorpus, realtext_rep, dna, random, zeros, period9, reptext -- "
+                         "the inputs of scripts/r5/workloads.py instead of the C3 generator's blocks")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the one-thread CPU baseline (best and median reported)")
     ap.add_argument("--cpu-size-mib", type=int, default=0, help="CPU baseline block (0 = same as --size-mib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -293,7 +294,7 @@ def main():
     if args.workload == "c3":
         pool = [hip.synth_into("t", s, ctx.host_alloc(size)) for s in seeds]
     else:
-        sys.path.insert(0, os.path.join(ROOT, "scripts", "r4"))
+        sys.path.insert(0, os.path.join(ROOT, "scripts", "r5"))
         import workloads
         data, workload_what = workloads.gen(args.workload, size)
         pool = [ctx.host_alloc(size)]
@@ -495,23 +496,14 @@ def main():
         except (OSError, hip.BwtcHipError) as ex:
             corpus = {"path": cpath, "error": str(ex)}
 
-    # the spec peak beside what a plain device copy reaches on this box
+    # the spec peak beside what a streaming copy reaches on this box -- the library's own
+    # 16-byte-per-lane copy kernel through the C ABI (bwtc_hip_copy_probe), and the guide's figure for the same kind
+    # of kernel (6.29 TB/s).  (Until round 4 this was torch.Tensor.copy_ on uint8, which reaches 4.7 TB/s and flattered
+    # every fraction taken of it.)
     copy_gbs = None
     if rank == 0:
         try:
-            nb = 1 << 30
-            a = torch.empty(nb, dtype=torch.uint8, device=dev)
-            b = torch.empty(nb, dtype=torch.uint8, device=dev)
-            b.copy_(a)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = 5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9       # bytes read + bytes written
-            del a, b
+            copy_gbs = ctx.copy_probe(1 << 30, 5)
         except Exception:                                                    # never a reason to lose the bench line
             copy_gbs = None
 
@@ -554,7 +546,10 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "device_copy_GBps": round(copy_gbs, 1) if copy_gbs else None,
+                    "device_copy_kernel": "bwtc_hip_copy_probe: 1 GiB, one 16-byte item per thread, read + written bytes",
+                    "guide_copy_GBps": GUIDE_COPY_GBS,
                     "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                    "frac_of_guide_copy": round(achieved / GUIDE_COPY_GBS, 4),
                     "traffic": traffic,
                     "traffic_source": traffic_src,
                     "launches": kt["scatter_launches"],
@@ -571,6 +566,13 @@ def main():
                                         "own_frac": round(own_bytes / (bwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if own_bytes else None,
                                         "route": int(getattr(st, "route", 0))}}
         step_ms = 1e3 * elapsed / args.steps
+        # what binds the step: the host half binds it when records come back late (collect wait, fewer records finished
+        # than blocks begun), when the cgroup's CPU quota throttled the process for more than a tenth of the region, or
+        # when the process used 95 % of the CPUs it may use for the whole region
+        throttled_s = (thr1[2] - thr0[2]) if thr0 and thr1 else 0.0
+        cpu_per_step = (cpu1 - cpu0) / args.steps
+        cpu_saturated = cpu_per_step >= 0.95 * cores * (elapsed / args.steps)
+        quota_bound = throttled_s > 0.1 * elapsed
         gpu_ms = 1e3 * gpu_s / args.steps
         wait_ms = 1e3 * collect_s / args.steps
         blocks_done = max(1, max(b1 - b0, f1 - f0))
@@ -613,7 +615,7 @@ def main():
                                   " + 'H' run-length/Huffman coder on the GPU, record copied to the host" if coder == "H" else ""),
                        "coder": coder, "blocks_per_gpu_per_step": 1, "parallelism": "block farm, no collective",
                        "blocks_under_way": depth},
-            "single_block_ms": round(single_ms, 1), "h2d_ms": round(h2d_ms, 2),
+            "single_block_ms": round(single_ms, 1), "single_block_MBps": round(size / 1e6 / (single_ms * 1e-3), 1), "h2d_ms": round(h2d_ms, 2),
             "fill_ms": round(fill_ms, 1), "drain_ms": round(drain_ms, 1),
             "gpu_ms_per_step": round(gpu_ms, 2), "collect_wait_ms_per_step": round(wait_ms, 2),
             "issue_rate_MBps": round(total_mb / elapsed, 2),
@@ -625,7 +627,15 @@ def main():
             "host_staging_peak_gb_rank0": round(hip.host_staging_bytes()[1] / 1e9, 2),
             "host_rss_peak_gb_rank0": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6, 1),
             "host_rss_gb_rank0": rss,
-            "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps)),
+            "host_bound": bool(coder == "B" and (wait_ms > 0.1 * step_ms or finished < args.steps or quota_bound or cpu_saturated)),
+            "host_bound_why": ([w for w, c in (("collect wait above a tenth of a step", wait_ms > 0.1 * step_ms),
+                                               ("fewer records finished in the region than blocks begun", finished < args.steps),
+                                               ("cgroup CPU quota throttled the process for more than a tenth of the region", quota_bound),
+                                               ("the process used 95 % of its usable CPUs over the whole region", cpu_saturated)) if c]
+                               if coder == "B" else []),
+            # a region shorter than three block latencies mostly collects records that were begun before it
+            "region_over_block_latency": round(elapsed / block_latency, 2) if coder == "B" and block_latency else None,
+            "region_short": bool(coder == "B" and block_latency and elapsed < 3.0 * block_latency),
             "host_threads_per_rank": threads if coder == "B" else 0, "host_cpus_usable": cores,
             "host_cpus_of_rank0": _ranges(my_cpus), "numa_node_of_rank0": numa_node,
             "per_rank": [{"rank": r, "host_threads": per_rank["host_threads"][r], "numa_node": per_rank["numa_node"][r],

@@ -54,6 +54,14 @@ static int test_sort(bwtc_hip_ctx* ctx, K* keys, uint32_t* vals, uint64_t n, int
 static std::mutex& host_allocs_mu() { static std::mutex m; return m; }
 static std::map<void*, std::pair<int, uint64_t> >& host_allocs() { static std::map<void*, std::pair<int, uint64_t> > m; return m; }
 
+// bwtc_hip_copy_probe: a streaming copy, one 16-byte item per thread.  (Of the forms tried on MI355X -- grid-stride
+// loops with 4 or 8 loads in flight, contiguous chunks per workgroup, non-temporal accesses, hipMemcpy device to
+// device: 4.1-5.5 TB/s -- this plain one is the fastest, 6.2 TB/s: scripts/dev/copy_probe.cpp.)
+static __global__ __launch_bounds__(256) void k_copy_probe(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 extern "C" {
 
 int bwtc_hip_device_count(void) {
@@ -106,6 +114,34 @@ int bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, i
   ScatterProbe& p = ctx->eng.probe;
   if (out) { out->scatter_launches = p.total_launches; out->scatter_bytes = p.total_bytes; out->scatter_ms = p.total_ms; }
   if (reset) { p.total_launches = 0; p.total_bytes = 0; p.total_ms = 0.0; }
+  return 0;
+}
+
+int bwtc_hip_copy_probe(bwtc_hip_ctx* ctx, uint64_t bytes, int reps, double* gbps) {
+  if (!ctx || !gbps || bytes < 16 || reps < 1) return -1;
+  BWTC_HIP_TRY(hipSetDevice(ctx->eng.device));
+  void *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, bytes) != hipSuccess) return -2;
+  if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return -2; }
+  hipStream_t st = ctx->eng.stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  float ms = 0.f;
+  const uint64_t n16 = bytes / 16;
+  if (hipMemsetAsync(a, 1, bytes, st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = -3;
+  if (!rc) {
+    const dim3 grid((unsigned)((n16 + 255) / 256));
+    hipLaunchKernelGGL(k_copy_probe, grid, dim3(256), 0, st, (const uint4*)a, (uint4*)b, n16);      // warm
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy_probe, grid, dim3(256), 0, st, (const uint4*)a, (uint4*)b, n16);
+    (void)hipEventRecord(e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) rc = -3;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  if (rc) { (void)hipGetLastError(); return rc; }
+  *gbps = (double)reps * 2.0 * (double)(n16 * 16) / ((double)ms * 1e-3) / 1e9;
   return 0;
 }
 

@@ -63,6 +63,10 @@ void* bwtc_hip_stream(bwtc_hip_ctx* ctx);          /* hipStream_t of the context
 int  bwtc_hip_get_stats(bwtc_hip_ctx* ctx, bwtc_hip_stats* out);
 int  bwtc_hip_set_profiling(bwtc_hip_ctx* ctx, int on);
 int  bwtc_hip_get_kernel_timers(bwtc_hip_ctx* ctx, bwtc_hip_kernel_timers* out, int reset);
+/* What this GPU streams: a copy of `bytes` bytes (16 bytes per lane, the library's own kernel) repeated `reps`
+ * times on the context's stream, timed with HIP events; *gbps = bytes read + bytes written per second / 1e9.  The
+ * denominator bench.py quotes beside the spec peak (not part of the reference's interface: measurement only). */
+int  bwtc_hip_copy_probe(bwtc_hip_ctx* ctx, uint64_t bytes, int reps, double* gbps);
 
 /* Device buffers for callers of the *_device entry points that do not link the HIP runtime
  * themselves (allocation on the context's GPU; copies are synchronous). */

@@ -12,9 +12,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "scripts", "r4"))
 from bwtc_amd import hip  # noqa: E402
-import workloads as r4  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("workloads_r4", os.path.join(ROOT, "scripts", "r4", "workloads.py"))
+r4 = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(r4)
 
 PY_ROOTS = ("/usr/lib/python3", "/usr/lib/python3.10", "/usr/local/lib/python3.10")
 
