@@ -410,10 +410,13 @@ int bwtc_hip_wavelet_start(bwtc_hip_ctx* ctx, char coder) {
   // NEW stream starts from the fresh state: never the old stream's carried state under a new header
   ctx->eng.wavelet_state = 4;
   ctx->eng.wavelet_model = coder;
-  ctx->eng.stream_start_error = rc;
+  ctx->eng.stream_start_error = 0;                    // the caller has the code: the new stream starts clean
   return rc;
 }
-void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) { (void)bwtc_hip_wavelet_start(ctx, 'B'); }   // a failure is kept: the next _begin returns it
+void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) {      // no result of its own: a failure is kept, the next _begin / _prepare returns it
+  const int rc = bwtc_hip_wavelet_start(ctx, 'B');
+  if (ctx) ctx->eng.stream_start_error = rc;
+}
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx) { return ctx ? ctx->eng.max_inflight : 0u; }
 uint32_t bwtc_hip_wavelet_depth_needed(bwtc_hip_ctx* ctx) { return ctx && ctx->eng.pipeline ? ctx->eng.pipeline->depthNeeded() : 0u; }
 int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds, uint64_t* blocks) {
@@ -782,13 +785,17 @@ int bwtc_hip_pair_replace_device(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const u
   if (!ctx || !g || !d_src || !d_dst || !n_out || !replaced) return -1;
   return bwtc_hip::pair_replace_device(ctx->eng, g->g, d_src, n, d_dst, n_out, replaced);
 }
+int bwtc_hip_host_precompress(bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n, uint64_t* n_out);
 int bwtc_hip_precompress(bwtc_hip_ctx* ctx, bwtc_hip_grammar* g, const char* options, uint8_t* block, uint64_t n, uint64_t* n_out) {
   if (!ctx || !g || !block || !n_out) return -1;
   *n_out = n;
   if (!options || !options[0] || n < 3) return 0;
   BwtEngine& e = ctx->eng;
   BWTC_HIP_TRY(hipSetDevice(e.device));
-  if (n >= (1ull << 31) || n / 4096 + 2 > e.cap) return -1;
+  // The device passes index their tiles and output offsets with 32 bits: a precompressor block of 2 GiB and more (the
+  // reference's PairReplacer takes them up to 4 GiB: `compress --prepr p -m 2903` and above) takes the host's twin of
+  // the same two passes -- same bytes, same grammar.
+  if (n >= (1ull << 31) || n / 4096 + 2 > e.cap) return bwtc_hip_host_precompress(g, options, block, n, n_out);
   uint8_t *d_a = nullptr, *d_b = nullptr;
   BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_a), 2 * n + 64));
   if (hipMalloc(reinterpret_cast<void**>(&d_b), 2 * n + 64) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_a); return -2; }

@@ -404,10 +404,17 @@ bool postprocess(const Grammar& grammar, const byte* data, size_t n, std::vector
     }
     return true;
   };
+  // The grammar comes out of the stream: a damaged (or hostile) one can chain twenty rules whose right sides name
+  // the rule before four times each -- 4^20 bytes.  No rule of a sound grammar stands for more than the block it came
+  // from, and all of them together for little more than twice that (a rule is used where it saves bytes).
   const std::vector<Rule>& rules = grammar.rules();
+  size_t expanded = 0;
+  const size_t budget = 2 * cap + (static_cast<size_t>(1) << 20);
   for (size_t i = 0; i < rules.size(); ++i) {                     // in order: a right side only uses earlier variables
     std::vector<byte> full;
-    if (!expand(&rules[i].rhs[0], rules[i].rhs.size(), &full, static_cast<size_t>(-1))) return false;
+    if (!expand(&rules[i].rhs[0], rules[i].rhs.size(), &full, cap)) return false;
+    expanded += full.size();
+    if (expanded > budget) return false;
     if (rules[i].large) paired[rules[i].variable].swap(full); else plain[rules[i].variable & 0xff].swap(full);
   }
   return expand(data, n, out, out->size() + cap);

@@ -199,7 +199,7 @@ class Grammar:
         return bool(self.lib.bwtc_hip_grammar_is_special(self.h, int(c)))
 
     def write(self):
-        out = np.zeros(1 << 16, np.uint8)
+        out = np.zeros((1 << 17) + 8 * self.rules, np.uint8)      # a rule costs at most seven bytes, the freed symbols' table at most 64 KiB
         n = _u64(0)
         _check(self.lib.bwtc_hip_grammar_write(self.h, _ptr(out), out.size, ctypes.byref(n)), "bwtc_hip_grammar_write")
         return out[:n.value].copy()

@@ -473,7 +473,8 @@ class Grammar {
   uint32 numberOfSpecialSymbols() const { return bwtc_hip_grammar_special_symbols(m_g); }
   bool isSpecial(byte symbol) const { return bwtc_hip_grammar_is_special(m_g, symbol) != 0; }
   uint32 writeGrammar(OutStream* dst) const {                     // Grammar.cpp:309-320
-    std::vector<byte> raw(1 << 16);
+    // (a rule costs at most seven bytes, the freed symbols' table at most 64 KiB: forty rounds of `p` no longer overflow)
+    std::vector<byte> raw(((size_t)1 << 17) + 8 * (size_t)numberOfRules());
     uint64_t n = 0;
     hipFatal(bwtc_hip_grammar_write(m_g, &raw[0], raw.size(), &n), "bwtc_hip_grammar_write");
     dst->writeBlock(&raw[0], &raw[0] + n);

@@ -148,7 +148,11 @@ int main(int argc, char** argv) {
   bwtc::Compressor compressor(new bwtc::RawInStream(in_name), new bwtc::RawOutStream(out_name), prepr,
                               mem * 1000000, enc);                // compress.cpp:192-193
   size_t compressed;
-  if (!prepr.empty()) devices.clear();                            // the pre-stage runs block by block on one context
+  if (!prepr.empty() && !devices.empty()) {                       // the pre-stage runs block by block on one context
+    std::fprintf(stderr, "compress: --prepr runs on one device; -D %s is ignored, device %d takes every block\n",
+                 devices.size() > 1 ? "(the farm)" : "", device);
+    devices.clear();
+  }
   if (!devices.empty()) {
     compressed = compressor.compressFarmed(devices, starts < 1 ? 1 : starts > 256 ? 256 : starts, pipeline);
   } else {

@@ -413,3 +413,20 @@ def test_prepr_host_half_matches_the_oracle(name, data):
         assert back.size == data.size and (back == data).all(), (name, opts)
         ob = oracle_lib.oracle_postprocess(og, mine, data.size + 8)
         assert ob is not None and ob.size == data.size and (ob == data).all(), (name, opts)
+
+
+def test_postprocess_refuses_a_grammar_that_expands_beyond_the_block():
+    """A grammar is read from the stream: one whose rules stand for more than the block they came from (twenty chained
+    rules can stand for 4^20 bytes) must be refused before anything that size is allocated.  Here: the honest grammar
+    of a text that is one pair repeated, rule inside rule -- and a caller who says the block was tiny."""
+    from bwtc_amd import hip
+    data = np.frombuffer(b"ab" * (1 << 17), np.uint8)
+    g = hip.Grammar()
+    mine = g.host_precompress("pppppppp", data)
+    assert g.rules >= 6 and mine.size * 32 < data.size           # rule inside rule: every round halves the text
+    back = g.postprocess(mine, data.size + 8)
+    assert back.size == data.size and (back == data).all()
+    g2 = hip.Grammar()
+    g2.read(g.write())
+    with pytest.raises(hip.BwtcHipError):
+        g2.postprocess(mine, 1000)                               # the rules alone stand for more than 1000 bytes
