@@ -2759,6 +2759,7 @@ int BwtEngine::transform(const u8* d_src, u8* d_dst, u32 size, bool raw, u32* lf
   BWTC_HIP_TRY(wait());
   BWTC_HIP_TRY(hipGetLastError());
   BWTC_HIP_TRY(take_sticky_error());
+  if (radix_fault_take()) { std::fprintf(stderr, "bwtc_hip: a radix pass's digit table and its items disagreed (checked build)\n"); return -3; }
   for (u32 k = 0; k < n_lf; ++k) lf[k] = h_small[kSmallLf + k];
   probe.harvest();
   stats.n = n;

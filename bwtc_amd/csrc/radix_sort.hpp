@@ -32,6 +32,22 @@ constexpr int kRadixBins = 1 << kRadixBits;
 constexpr int kRadixTPB = BWTC_RADIX_TPB;         // 8 waves
 constexpr int kRadixWaves = kRadixTPB / kWave;
 
+// Checked builds (make EXTRA=-DBWTC_RADIX_CHECKED): the scatter trusts a table of bases that another kernel built from
+// another copy of the digit (a digit plane, a key maker's first plane); a disagreement between the two makes it store
+// past its bases -- in round 4 past the array, a memory fault.  Checked, an item whose destination lies outside the
+// output is not stored and raises this word instead; the transform's entry points then return -3.
+#ifdef BWTC_RADIX_CHECKED
+static __device__ u32 g_radix_fault;
+static inline int radix_fault_take() {
+  u32 v = 0, z = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_radix_fault), 4) != hipSuccess) return 1;
+  if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_radix_fault), &z, 4);
+  return v ? 1 : 0;
+}
+#else
+static inline int radix_fault_take() { return 0; }
+#endif
+
 template <typename K> struct RadixCfg;
 template <> struct RadixCfg<u32> { static constexpr int E = BWTC_RADIX_E32; };   // 8192 pairs, 64 KiB LDS
 template <> struct RadixCfg<u64> { static constexpr int E = BWTC_RADIX_E64; };    // 4096 pairs, 48 KiB LDS
@@ -286,6 +302,9 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_scatter(
     dst[e] = s_gofs[long_digit<K, LONG>(kk[e], ww[LONG ? e : 0], shift, la.dmask, la.bridge)] + tid + (u32)e * kRadixTPB;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
+#ifdef BWTC_RADIX_CHECKED
+    if (tid + (u32)e * kRadixTPB < tile_out && (u64)dst[e] >= n) { atomicOr(&g_radix_fault, 1u); continue; }
+#endif
     if (tid + (u32)e * kRadixTPB < tile_out) {
       // plain stores on purpose: the runs of neighbouring tiles are merged into full lines in
       // L2; non-temporal stores measured 30 % slower here, non-temporal loads no better
