@@ -1037,9 +1037,7 @@ struct FinList { u32* S; u32* P; u32* H; unsigned short* C; };
 // workgroups on the chip at any moment spread over all of them, and a chunk leaves at most its 64 strides of entries plus
 // one group, so the regions' sizes add up to the list's plus half a per cent).  Windows never straddle regions (groups
 // do not: a workgroup's output goes to one region).
-constexpr u32 kFinRegions = 16;
-constexpr u32 kFinChunk = 64;
-struct FinRegions { u32 nreg; u32 wfirst[kFinRegions + 1]; u32 ebase[kFinRegions]; u32 ecount[kFinRegions]; };
+constexpr u32 kFinChunk = 64;             // (kFinRegions, FinRegions: bwt_engine.hpp)
 struct FinOut { u32 base[kFinRegions]; };                 // where each region of the list a pass leaves starts
 
 // sixteen characters T[pos .. pos+16) as two big-endian words; bytes at or past n read as zero
@@ -1085,11 +1083,19 @@ __device__ __forceinline__ void fin_chars_n(const u8* __restrict__ T, u32 pos, u
 // at ONE depth for all their groups, the smallest, and a few groups of some exotic but repetitive string (bytes the
 // code's sample never saw: a depth of one or two characters) would drag a whole text's hard groups down to theirs.
 struct FinShallow { u32* S; u64* HP; u32* count; u32 floor; };
-template <int kFinMaxGroup, int E_ = 4, int NW = 2>
+// RANK (FinRank rk; NW == 2): the members' keys are not characters but ranks -- rank[s + at] (and rank[s + at2]), the
+// doubling step of Larsson and Sadakane done group by group in LDS instead of by a global sort of (group, rank): for the
+// many small groups of deep repeats (copies of whole files).  rank[] must not change while a pass reads it, so the
+// pass only NOTES every member's new rank (its slot when final, else its sub-group's head), by list position, and
+// k_rank_updates writes them afterwards.
+struct FinRank { const u32* rank; u32 at, at2; u32* us; u32* ur; };   // at2 == 0: one look-up
+template <int kFinMaxGroup, int E_ = 4, int NW = 2, bool RANK = false>
 __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, const u8* __restrict__ T, u32 n,
                                                     FinList next, FinOut ob, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP, unsigned short* __restrict__ hardC,
-                                                    u32* __restrict__ hard_count, FinShallow shal, u32* __restrict__ SA, RrEmit em) {
+                                                    u32* __restrict__ hard_count, FinShallow shal, u32* __restrict__ SA, RrEmit em,
+                                                    FinRank rk = FinRank()) {
+  static_assert(!RANK || NW == 2, "rank keys are two words");
   constexpr int kFinE = E_;                                           // entries per thread: a window of 1024 or 2048
   constexpr int kFinWin = kFinTPB * kFinE;
   static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
@@ -1157,13 +1163,19 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
   for (int e = 0; e < kFinE; ++e) {
 #pragma unroll
     for (int q = 0; q < NW; ++q) ch[e][q] = 0;
-    if (A[e] >= 0) fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, ch[e]);
+    if (A[e] >= 0) {
+      if (RANK) {
+        const u64 t1 = (u64)S[e] + rk.at, t2 = (u64)S[e] + rk.at2;
+        ch[e][0] = t1 < (u64)n ? (u64)rk.rank[t1] + 1ull : 0ull;            // (a suffix that ends before the look-up: the smallest key)
+        ch[e][NW - 1] = (rk.at2 && t2 < (u64)n) ? (u64)rk.rank[t2] + 1ull : 0ull;
+      } else fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, ch[e]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     if (A[e] >= 0) {
       const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 touch = ((u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 0x80000000u : 0u;
+      const u32 touch = (!RANK && (u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 0x80000000u : 0u;
 #pragma unroll
       for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = ch[e][q];
       s_S[lp] = S[e] | touch;
@@ -1211,6 +1223,12 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
         }
       }
       R[e] = below; Q[e] = eq_before | (eq_all << 16);
+      if (RANK) {                 // the member's new rank, noted by list position (kFinNone: it keeps the one it has)
+        const u32 nr = H[e] + below;                                // (a final member's slot is its sub-group's head)
+        const u32 q = w0 + lp;
+        rk.us[q] = nr != H[e] ? S[e] : kFinNone;
+        rk.ur[q] = nr;
+      }
     }
   }
   __syncthreads();                 // every read of the characters is done: the bytes become the staging
@@ -1225,7 +1243,7 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
       st_S[np] = S[e];
       st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
       st_H[np] = (H[e] + R[e]) | fin;
-      st_C[np] = (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kChars) << 8));
+      st_C[np] = RANK ? (unsigned short)C[e] : (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kChars) << 8));
     }
   }
   // the hard entries of this workgroup's stride range, in any order; one atomic per workgroup and list (a wave's own
@@ -1313,6 +1331,36 @@ __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __r
   for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
   // the depth the rounds may start from (an atomic only where it lowers what is there: one per wave was 15 ms for 85 M entries)
   if (lane_id() == 0 && d != 0xFFFFFFFFu && d < __hip_atomic_load(min_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(min_depth, d);
+}
+// rank[us[q]] = ur[q] for the list positions q of one region (k_finish<RANK>'s notes)
+__global__ __launch_bounds__(256) void k_rank_updates(const u32* __restrict__ us, const u32* __restrict__ ur, u32 base, u32 count,
+                                                      u32* __restrict__ rank) {
+  const u32 i0 = blockIdx.x * 1024u + threadIdx.x;
+  u32 s[4], r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const u32 i = i0 + (u32)e * 256u; s[e] = i < count ? us[base + i] : kFinNone; r[e] = i < count ? ur[base + i] : 0u; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) if (s[e] != kFinNone) rank[s[e]] = r[e];
+}
+// one region of a list, copied to the end of another list's arrays
+__global__ __launch_bounds__(256) void k_list_copy(FinList in, u32 m, FinList out, u32 at, u32* __restrict__ min_depth) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  u32 d = 0xFFFFFFFFu;
+  if (i < m) {
+    const unsigned short c = in.C[i];
+    out.S[at + i] = in.S[i]; out.P[at + i] = in.P[i]; out.H[at + i] = in.H[i]; out.C[at + i] = c;
+    d = c >> 8;
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
+  if (lane_id() == 0 && d != 0xFFFFFFFFu && d < __hip_atomic_load(min_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(min_depth, d);
+}
+// complete_ranks for a list that waits in finisher form: its suffixes rank as their groups' heads
+__global__ __launch_bounds__(256) void k_bridge_pairs_fix_list(FinList in, u32 m, u32* __restrict__ pair_s, u32* __restrict__ pair_r) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m) return;
+  const u32 p = in.P[i];
+  pair_s[p] = in.S[i];
+  pair_r[p] = in.H[i];
 }
 __global__ __launch_bounds__(256) void k_raw_to_park(const u32* __restrict__ S, const u32* __restrict__ P, const u32* __restrict__ H, u32 m,
                                                      u32* __restrict__ parkS, u64* __restrict__ parkHP, u32 at) {
@@ -1604,7 +1652,7 @@ static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 struct ArenaPlan {
   u64 off_T, off_out, off_in, off_SA, off_rank, off_R1, off_R2, off_V0, off_V1, off_G0, off_G1,
-      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_parkS, off_parkHP, off_hardS, off_hardHP, off_hardC, off_pairs, off_codes, total;
+      off_GRP, off_C0, off_C1, off_P0, off_P1, off_W0, off_W1, off_table, off_partial, off_aggA, off_aggB, off_aggC, off_agg_part, off_small, off_ent, off_comp, off_sweep, off_parkS, off_parkHP, off_hardS, off_hardHP, off_hardC, off_LP0, off_LH0, off_LH1, off_LC1, off_US, off_UR, off_pairs, off_codes, total;
 };
 
 static ArenaPlan plan_arena(u64 cap) {
@@ -1644,9 +1692,15 @@ static ArenaPlan plan_arena(u64 cap) {
   a.off_sweep = take(SweepWs::small_words() * 4);
   a.off_parkS = take(cap * 4);          // finisher route: what waits for the rounds (the passes' leftovers, groups the code rounds gave up on)
   a.off_parkHP = take(cap * 8);
-  a.off_hardS = take(cap * 4);          // finisher route: the groups too large for a window, until their code round
-  a.off_hardHP = take(cap * 8);
-  a.off_hardC = take(cap * 2 + 64);
+  a.off_hardS = take(lcap * 4);         // finisher route: the groups too large for a window, until they join the waiting list;
+  a.off_hardHP = take(lcap * 8);        //   then, with the arrays below, the two homes of the local list and its rank notes (k_finish<RANK>)
+  a.off_hardC = take(lcap * 2 + 64);
+  a.off_LP0 = take(lcap * 4);
+  a.off_LH0 = take(lcap * 4);
+  a.off_LH1 = take(lcap * 4);
+  a.off_LC1 = take(lcap * 2 + 64);
+  a.off_US = take(lcap * 4);
+  a.off_UR = take(lcap * 4);
   a.off_pairs = take((u64)kPairReplicas * 65536 * 4);
   a.off_codes = take((u64)kCodeRows * 256 * 4);
   a.total = o;
@@ -1703,6 +1757,12 @@ int BwtEngine::init(int dev, u32 max_block_size) {
   d_hardS = reinterpret_cast<u32*>(base + a.off_hardS);
   d_hardHP = reinterpret_cast<u64*>(base + a.off_hardHP);
   d_hardC = reinterpret_cast<unsigned short*>(base + a.off_hardC);
+  d_LP0 = reinterpret_cast<u32*>(base + a.off_LP0);
+  d_LH0 = reinterpret_cast<u32*>(base + a.off_LH0);
+  d_LH1 = reinterpret_cast<u32*>(base + a.off_LH1);
+  d_LC1 = reinterpret_cast<unsigned short*>(base + a.off_LC1);
+  d_US = reinterpret_cast<u32*>(base + a.off_US);
+  d_UR = reinterpret_cast<u32*>(base + a.off_UR);
   d_pairs = reinterpret_cast<u32*>(base + a.off_pairs);
   d_codes = reinterpret_cast<u32*>(base + a.off_codes);
   {
@@ -1741,6 +1801,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_FIN_WORDS")) fin_words = std::min(4, std::max(2, std::atoi(std::getenv("BWTC_HIP_FIN_WORDS"))));
+    local_rounds = !(std::getenv("BWTC_HIP_LOCAL_ROUNDS") && std::getenv("BWTC_HIP_LOCAL_ROUNDS")[0] == '0');
     if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
     const char* hg = std::getenv("BWTC_HIP_HUGE_MI");
@@ -2449,11 +2510,11 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     bool keep_h = keep_first;                // the list is sorted to depth h as it stands (no doubling before the next step)
     int text_left = text_rounds_now;
     int text_extra = text_rounds_fixed ? 0 : 12;        // further ones, one at a time, while the list is short (not when BWTC_HIP_TEXT_ROUNDS says how many)
-    while (m > 0) {
+    while (m > 0 || (doubling && local_m > 0)) {
       if (h >= (u64)n * 2 + 64) return -3;   // cannot happen: every group splits by then
       ++stats.rounds;
       stats.active_sum += m;
-      const bool text = text_left > 0;
+      const bool text = text_left > 0 && m > 0;
       const bool raw = !text && !doubling;               // out of text rounds and not allowed to double: hand the list back
       if (std::getenv("BWTC_HIP_DEBUG")) std::fprintf(stderr, "round %u%s: h=%llu m=%u groups=%u\n", stats.rounds, text ? " (text)" : "", (unsigned long long)h, m, res.groups);
       if (!keep_h) h *= 2;
@@ -2468,6 +2529,13 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
         stats.route |= 8u;
         stats.alg_bytes += (u64)n * (4 + 8);                // k_bridge_pairs_all (the partition and scatter count themselves)
       }
+      // what the local list's last pass noted reaches rank[] now: before this round's look-ups, after the last round's
+      if (!text && !raw) { const int rcu = local_updates(); if (rcu) return rcu; }
+      if (m == 0) {                                       // only the local list is left
+        const int rcl = local_pass(n, 0, re);
+        if (rcl) return rcl;
+        continue;
+      }
       // the list just sorted: positions are the active list's, aglob gives their global slots
       rb.aglob = rb.aglob_next;
       rb.aglob_next = rb.aglob == d_G0 ? d_G1 : d_G0;
@@ -2481,6 +2549,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       if (rc2) return rc2;
       m = res.m;
       if (raw) { *left = m; *h_left = h; return 0; }
+      // the local list's doubling step beside the global list's (both read the rank[] this round's ranking step left)
+      if (!text && doubling && local_m > 0) { const int rcl = local_pass(n, h, re); if (rcl) return rcl; }
       if (text) {
         h += res.text_chars; keep_h = true; --text_left;
         // Out of text rounds with a short list left: a few more cost tens of microseconds each, the doubling rounds
@@ -2495,19 +2565,20 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
   };
   ranks_live = false;
   parked = 0;
+  local_m = 0; local_pending = false;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
     lf_noted = true;                       // every suffix that becomes final notes its LF power (lf_note), in every route
     ranks_complete = false;
     u32* cnt = d_small + kSmallFin;
-    h_small[kSmallFin + 3] = 0xFFFFFFFFu; h_small[kSmallFin + 4] = 0; h_small[kSmallFin + 5] = 0xFFFFFFFFu;
-    BWTC_HIP_TRY(hipMemcpyAsync(cnt + 3, h_small + kSmallFin + 3, 12, hipMemcpyHostToDevice, st));
+    h_small[kSmallFin + 3] = 0xFFFFFFFFu; h_small[kSmallFin + 4] = 0; h_small[kSmallFin + 5] = 0xFFFFFFFFu; h_small[kSmallFin + 6] = 0xFFFFFFFFu;
+    BWTC_HIP_TRY(hipMemcpyAsync(cnt + 3, h_small + kSmallFin + 3, 16, hipMemcpyHostToDevice, st));
     // the ranking's list through the finisher
     FinList la{rb.v_free, rb.aglob_next, d_GRP, reinterpret_cast<unsigned short*>(re.achr_out)};
     FinList lb{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
     FinShallow shal{rb.v_keys, static_cast<u64*>(rb.rec_free), cnt + 4, fin_floor};
     FinOutcome fo;
-    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo);
+    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds);
     if (rc) return rc;
     const u32 shallow = h_small[kSmallFin + 4];
     const u64 h_sh = h_small[kSmallFin + 5];
@@ -2532,26 +2603,29 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       }
     }
     const u32 hard = fo.hard, hard_depth = fo.hard_depth;
-    if (hard) {
-      // the groups too large for a window wait for the rounds too
-      if ((u64)parked + hard > cap) return -3;
-      BWTC_HIP_TRY(hipMemcpyAsync(d_parkS + parked, d_hardS, (size_t)hard * 4, hipMemcpyDeviceToDevice, st));
-      BWTC_HIP_TRY(hipMemcpyAsync(d_parkHP + parked, d_hardHP, (size_t)hard * 8, hipMemcpyDeviceToDevice, st));
-      parked += hard;
-    }
-    if (parked) {
+    if (parked || local_m) {
       BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 3, cnt + 3, 4, hipMemcpyDeviceToHost, st));
       BWTC_HIP_TRY(wait());
-      const u64 h_pk = std::min<u64>(std::min<u64>(h_small[kSmallFin + 3], hard ? hard_depth : 0xFFFFFFFFu), shallow_depth);
+      u64 h_pk = std::min<u64>(std::min<u64>(h_small[kSmallFin + 3], hard ? hard_depth : 0xFFFFFFFFu), shallow_depth);
+      if (local_m) h_pk = std::min<u64>(h_pk, local_depth);       // every rank is at least as deep as the rounds' first look-up
       const u32 total = parked;
       if (std::getenv("BWTC_HIP_DEBUG"))
-        std::fprintf(stderr, "finisher: %u entries (%u of groups too large) go on to the rounds at depth %llu\n", total, hard, (unsigned long long)h_pk);
-      BWTC_HIP_TRY(hipMemcpyAsync(d_V0, d_parkS, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
-      BWTC_HIP_TRY(hipMemcpyAsync(d_R1, d_parkHP, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
-      parked = 0;                          // (the list is in the rounds' hands now: complete_ranks takes it from them)
-      rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res);
-      if (rc) return rc;
-      rc = run_rounds(total, std::max<u64>(1, h_pk), text_for(total), true, true, nullptr, nullptr);
+        std::fprintf(stderr, "finisher: %u entries (%u of groups too large) go on to the rounds at depth %llu; %u entries of small groups double beside them from depth %u\n",
+                     total, hard, (unsigned long long)h_pk, local_m, local_m ? local_depth : 0u);
+      if (total) {
+        BWTC_HIP_TRY(hipMemcpyAsync(d_V0, d_parkS, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+        BWTC_HIP_TRY(hipMemcpyAsync(d_R1, d_parkHP, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
+        parked = 0;                        // (the list is in the rounds' hands now: complete_ranks takes it from them)
+        rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res);
+        if (rc) return rc;
+      } else {
+        // no global list: the rounds still want free regions to complete rank[] in
+        res.m = 0; res.groups = 0;
+        res.ks = reinterpret_cast<u64*>(d_W0); res.rec_other = d_R1;
+        res.vs = d_V0; res.v_other = d_V1;
+        rb.aglob_next = d_G0;
+      }
+      rc = run_rounds(total, std::max<u64>(1, h_pk), local_m ? 0 : text_for(total), true, true, nullptr, nullptr);
       if (rc) return rc;
     }
   } else {
@@ -2572,13 +2646,15 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 //    fin_floor characters; they share at least *h_shallow
 //   `parked` entries in (d_parkS, d_parkHP): the other groups too large for a window, and what the last
 //    pass left tied; at least *h_parked characters
-int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, FinShallow shal, FinOutcome* fo) {
+int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, FinShallow shal, FinOutcome* fo, bool keep_local) {
   hipStream_t st = stream;
   u32* cnt = d_small + kSmallFin;      // [1] hard list, [2] its smallest depth; [3] smallest depth of what waits for the rounds; [4] shallow list, [5] its smallest depth
   u32* ncnt = d_small + kSmallFinNext; // entries of the next list, region by region
   h_small[kSmallFin] = 0; h_small[kSmallFin + 1] = 0; h_small[kSmallFin + 2] = 0xFFFFFFFFu;
   BWTC_HIP_TRY(hipMemcpyAsync(cnt, h_small + kSmallFin, 12, hipMemcpyHostToDevice, st));
   u32 hard = 0;
+  passes_done = 0;
+  const u32 park0 = parked;            // the groups too large for a window join the waiting list from here
   const int window = fin_window, group = fin_max_group;
   const u32 stride = (u32)(window - group);
   FinRegions rg;
@@ -2609,7 +2685,7 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
       if ((u64)at > cap + cap / 128 + 65536) return -3;
     }
 #define BWTC_FINISH_W(G, E, NW) hipLaunchKernelGGL((k_finish<G, E, NW>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
-                                             b, ob, ncnt, d_hardS, d_hardHP, d_hardC, cnt + 1, shal, d_SA, re)
+                                             b, ob, ncnt, d_parkS + park0, d_parkHP + park0, d_hardC, cnt + 1, shal, d_SA, re)
 #define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); else BWTC_FINISH_W(G, E, 2); } while (0)
     if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
     else if (group <= 256) BWTC_FINISH(256, 8);
@@ -2643,8 +2719,35 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
                    h_small[kSmallFin + 1], h_small[kSmallFin + 2], h_small[kSmallFin + 4], h_small[kSmallFin + 5]);
     hard = h_small[kSmallFin + 1];
     std::swap(a, b);
+    passes_done = it + 1;
     if (it >= 1 && (u64)m * 5 > (u64)m_was * 3 && (u64)m * 64 > (u64)n) break;     // deep repeats: on to the rounds
     if (it >= 2 && (u64)m * 4 > (u64)m_was * 3) break;                             // a list that hardly shrinks any more: the rounds double, this creeps
+  }
+  parked += hard;
+  if ((u64)parked > cap) return -3;
+  if (m && keep_local && passes_done >= 1 && (u64)m * 64 >= (u64)n) {        // (a pass has run: no group above the bound is left in the list)
+    // deep repeats in small groups: the doubling rounds take them group by group (local_pass), not through the global sort
+    FinList home{d_hardS, d_LP0, d_LH0, d_hardC};
+    u32 at = 0;
+    for (u32 r = 0; r < rg.nreg; ++r) {
+      if (!rg.ecount[r]) continue;
+      FinList part{a.S + rg.ebase[r], a.P + rg.ebase[r], a.H + rg.ebase[r], a.C + rg.ebase[r]};
+      hipLaunchKernelGGL(k_list_copy, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], home, at, cnt + 6);
+      at += rg.ecount[r];
+    }
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 6, cnt + 6, 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(wait());
+    local_depth = h_small[kSmallFin + 6];
+    // its smallest depth: every member has taken the same passes, from a level's depth
+    local_m = m;
+    std::memset(&local_rg, 0, sizeof local_rg);
+    local_rg.nreg = 1; local_rg.wfirst[1] = ceil_div(m, stride); local_rg.ecount[0] = m;
+    local_home = 0;
+    fo->left = 0;
+    fo->hard = hard;
+    fo->hard_depth = h_small[kSmallFin + 2];
+    fo->local = m;
+    return 0;
   }
   if (m) {
     // what the last pass left tied waits for the rounds
@@ -2659,6 +2762,94 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
   fo->hard = hard;
   fo->hard_depth = h_small[kSmallFin + 2];
   fo->left = m;
+  return 0;
+}
+
+// The local list: what the finisher's passes left of a block with deep repeats -- small groups (none above the
+// finisher's bound), many of them.  In the doubling rounds it is refined group by group in LDS (k_finish<RANK>)
+// beside the global list, which keeps the groups too large for that.
+FinList BwtEngine::local_list(int home) const {
+  const u64 lcap = cap + cap / 128 + 65536;
+  if (home == 0) return FinList{d_hardS, d_LP0, d_LH0, d_hardC};
+  return FinList{reinterpret_cast<u32*>(d_hardHP), reinterpret_cast<u32*>(d_hardHP) + lcap, d_LH1, d_LC1};
+}
+int BwtEngine::local_updates() {
+  if (!local_pending) return 0;
+  hipStream_t st = stream;
+  for (u32 r = 0; r < local_upd.nreg; ++r)
+    if (local_upd.ecount[r])
+      hipLaunchKernelGGL(k_rank_updates, dim3(ceil_div(local_upd.ecount[r], 1024)), dim3(256), 0, st, (const u32*)d_US, (const u32*)d_UR,
+                         local_upd.ebase[r], local_upd.ecount[r], d_rank);
+  local_pending = false;
+  return 0;
+}
+// One doubling step of the local list.  h_global: the depth the global list's groups are sorted to (0: there is no
+// global list); every rank[] entry is at least min(h_global, local_depth) deep, so a member looks up rank[s + local_depth]
+// and, that far behind it, a second rank: the step adds twice that depth.  A local list far ahead of the global one
+// (two of its steps and more) sits the round out.
+int BwtEngine::local_pass(u32 n, u64 h_global, RrEmit& re) {
+  hipStream_t st = stream;
+  if (local_m == 0) return 0;
+  if (h_global && (u64)local_depth >= 2 * h_global) return 0;
+  const u64 delta = h_global ? std::min<u64>(h_global, local_depth) : local_depth;
+  const u64 at = local_depth, at2 = (u64)local_depth + delta;
+  if (at2 + delta > 0xFFFFFFF0ull) return -3;
+  u32* cnt = d_small + kSmallFin;
+  u32* ncnt = d_small + kSmallFinNext;
+  const int window = fin_window, group = fin_max_group;   // the local list's groups are as large as the finisher's passes left them
+  const u32 stride = (u32)(window - group);
+  BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, kFinRegions * 4, st));
+  BWTC_HIP_TRY(hipMemsetAsync(cnt + 1, 0, 4, st));
+  const u32 grid = local_rg.wfirst[local_rg.nreg];
+  FinOut ob;
+  {
+    u32 room[kFinRegions] = {};
+    const u32 nchunks = ceil_div(grid, kFinChunk);
+    for (u32 c = 0; c < nchunks; ++c) {
+      const u32 wgs = std::min(kFinChunk, grid - c * kFinChunk);
+      room[c % kFinRegions] += wgs * stride + (u32)group;
+    }
+    u32 a2 = 0;
+    for (u32 r = 0; r < kFinRegions; ++r) { ob.base[r] = a2; a2 += room[r]; }
+    if ((u64)a2 > cap + cap / 128 + 65536) return -3;
+  }
+  FinShallow none{d_parkS, d_parkHP, cnt + 4, 0u};
+  FinRank rk{d_rank, (u32)at, (u32)at2, d_US, d_UR};
+#define BWTC_LOCAL(G, E) hipLaunchKernelGGL((k_finish<G, E, 2, true>), dim3(grid), dim3(kFinTPB), 0, st, local_list(local_home), local_rg, (const u8*)d_T, n, \
+                                            local_list(1 - local_home), ob, ncnt, d_parkS, d_parkHP, d_LC1 /* never written: no group is too large */, cnt + 1, none, d_SA, re, rk)
+  if (window <= 1024) { if (group <= 256) BWTC_LOCAL(256, 4); else BWTC_LOCAL(512, 4); }
+  else if (group <= 256) BWTC_LOCAL(256, 8);
+  else if (group <= 512) BWTC_LOCAL(512, 8);
+  else BWTC_LOCAL(1024, 8);
+#undef BWTC_LOCAL
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 1, cnt + 1, 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, kFinRegions * 4, hipMemcpyDeviceToHost, st));
+  BWTC_HIP_TRY(wait());
+  if (h_small[kSmallFin + 1]) return -3;                  // a group above the finisher's bound in a list that has none
+  stats.finisher_entries += local_m;
+  stats.active_sum += local_m;
+  stats.route |= 64u;
+  stats.alg_bytes += (u64)local_m * (14 * 4 / 3 + 8 + 8 + 5 + 8 + 4);
+  local_upd = local_rg;
+  local_pending = true;
+  FinRegions nx;
+  std::memset(&nx, 0, sizeof nx);
+  u32 total = 0;
+  for (u32 r = 0; r < kFinRegions; ++r) {
+    const u32 c = h_small[kSmallFinNext + r];
+    if (!c) continue;
+    nx.ebase[nx.nreg] = ob.base[r]; nx.ecount[nx.nreg] = c;
+    nx.wfirst[nx.nreg + 1] = nx.wfirst[nx.nreg] + ceil_div(c, stride);
+    ++nx.nreg;
+    total += c;
+  }
+  if (nx.nreg == 0) nx.nreg = 1;
+  if (std::getenv("BWTC_HIP_DEBUG"))
+    std::fprintf(stderr, "local pass: %u entries at depth %u (+ 2 x %llu) -> %u still tied\n", local_m, local_depth, (unsigned long long)delta, total);
+  local_rg = nx;
+  local_m = total;
+  local_home = 1 - local_home;
+  local_depth = (u32)std::min<u64>(at2 + delta, 0xFFFFFFF0ull);
   return 0;
 }
 
@@ -2688,6 +2879,12 @@ void BwtEngine::complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot,
   u32* pairs = static_cast<u32*>(pairs_region);
   hipLaunchKernelGGL(k_bridge_pairs_all, dim3(ceil_div(n, 1024)), dim3(256), 0, st, (const u32*)d_SA, n, pairs, pairs + cap);
   if (m) hipLaunchKernelGGL(k_bridge_pairs_fix, dim3(ceil_div(m, 256)), dim3(256), 0, st, list_sfx, list_slot, m, pairs, pairs + cap);
+  for (u32 r = 0; local_m && r < local_rg.nreg; ++r) {
+    if (!local_rg.ecount[r]) continue;
+    const FinList h = local_list(local_home);
+    FinList part{h.S + local_rg.ebase[r], h.P + local_rg.ebase[r], h.H + local_rg.ebase[r], h.C + local_rg.ebase[r]};
+    hipLaunchKernelGGL(k_bridge_pairs_fix_list, dim3(ceil_div(local_rg.ecount[r], 256)), dim3(256), 0, st, part, local_rg.ecount[r], pairs, pairs + cap);
+  }
   if (parked) hipLaunchKernelGGL(k_bridge_pairs_fix_parked, dim3(ceil_div(parked, 256)), dim3(256), 0, st, (const u32*)d_parkS, (const u64*)d_parkHP, parked, pairs, pairs + cap);
   scatter_rank_pairs(pairs, static_cast<u32*>(tmp_region), n, n);
 }

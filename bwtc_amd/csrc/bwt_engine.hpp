@@ -39,7 +39,10 @@ struct RrEmit;
 struct RrLong;
 struct FinList;
 struct FinShallow;
-struct FinOutcome { u32 hard = 0, hard_depth = 0xFFFFFFFFu, left = 0; };   // a finisher run: entries of groups too large (and their smallest depth), entries its last pass left tied
+struct FinOutcome { u32 hard = 0, hard_depth = 0xFFFFFFFFu, left = 0, local = 0; };
+// A finisher list lives in up to kFinRegions regions of its arrays (bwt_engine.hip, k_finish)
+constexpr u32 kFinRegions = 16;
+struct FinRegions { u32 nreg; u32 wfirst[kFinRegions + 1]; u32 ebase[kFinRegions]; u32 ecount[kFinRegions]; };   // a finisher run: entries of groups too large (and their smallest depth), entries its last pass left tied
 
 // ---- device side of the 'B' block pipeline (host side: wavelet_pipeline.hpp) ----------------
 // Page-locked host bytes: the packed streams are copied from the device straight into the
@@ -430,7 +433,18 @@ struct BwtEngine {
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
   // finisher passes over list a (m entries, one region; b: spare list arrays): groups too large for a window go to
   // d_hardS / d_hardHP / d_hardC, shallow ones to shal, what the last pass leaves tied is appended to d_parkS / d_parkHP (`parked`)
-  int finisher_passes(u32 n, u32 m, struct FinList a, struct FinList b, struct RrEmit& re, struct FinShallow shal, FinOutcome* fo);
+  int finisher_passes(u32 n, u32 m, struct FinList a, struct FinList b, struct RrEmit& re, struct FinShallow shal, FinOutcome* fo, bool keep_local = false);
+  // the local list (deep repeats in small groups, doubled group by group beside the global list: bwt_engine.hip, local_pass)
+  bool local_rounds = true;  // BWTC_HIP_LOCAL_ROUNDS=0: what the finisher's passes leave joins the waiting list, as in round 4
+  u32* d_LP0 = nullptr; u32* d_LH0 = nullptr; u32* d_LH1 = nullptr; unsigned short* d_LC1 = nullptr;
+  u32* d_US = nullptr; u32* d_UR = nullptr;          // k_finish<RANK>'s notes: suffix (or none), its new rank, by list position
+  u32 local_m = 0, local_depth = 0;
+  int local_home = 0, passes_done = 0;
+  bool local_pending = false;
+  FinRegions local_rg, local_upd;                    // where the local list lives now; where the last pass's notes lie
+  struct FinList local_list(int home) const;
+  int local_updates();
+  int local_pass(u32 n, u64 h_global, struct RrEmit& re);
   // a raw list (suffix; head slot << 32 | slot) in (S, HP) -> a sorted list the rounds understand, in res / rb
   int dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word

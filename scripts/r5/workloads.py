@@ -79,16 +79,26 @@ def main():
         for rep in range(reps):
             ctx.to_device_async(d_in, blk)
             ctx.copy_wait()
-            ctx.bwt_block_device(d_in, d_out, n, 8)
+            lf, freqs = ctx.bwt_block_device(d_in, d_out, n, 8)
             st = ctx.stats()
             if best is None or st.ms_total < best.ms_total:
                 best = hip.Stats.from_buffer_copy(bytes(st))
+        verified = None
+        if os.environ.get("VERIFY") == "1":
+            # the GPU inverse (which checks every LF power against its own walk) gives the block back; freqs is its histogram
+            ctx.inverse_bwt_block_device(d_out, d_in, n, lf)
+            back = ctx.to_host(d_in, n)
+            verified = bool((back == data).all() and (freqs == np.bincount(data, minlength=256)).all())
+            if not verified:
+                raise SystemExit("%s: the inverse transform does not give the block back" % kind)
         line = {"workload": kind, "what": what, "MiB": mib, "sigma": int(np.count_nonzero(np.bincount(data, minlength=256))),
                 "device_ms_bwt": round(best.ms_total, 2),
                 "MBps": round(n / 1e6 / (best.ms_total * 1e-3), 1), "rounds": best.rounds,
                 "R_eff": round(best.active_sum / best.n, 3), "sort_passes_per_suffix": round(best.sort_pass_items / best.n, 1),
                 "route": best.route, "alg_GB": round(best.alg_bytes / 1e9, 1),
                 "alg_frac_of_8TBps": round(best.alg_bytes / (best.ms_total * 1e-3) / 8e12, 3)}
+        if verified is not None:
+            line["inverse_gives_the_block_back"] = verified
         print(json.dumps(line), flush=True)
 
 

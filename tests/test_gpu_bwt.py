@@ -352,7 +352,10 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_FIN_FLOOR=0", "BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_FLOOR=48,BWTC_HIP_TEXT_ROUNDS=0",
                                     "BWTC_HIP_FIN_WORDS=3", "BWTC_HIP_FIN_WORDS=4,BWTC_HIP_FIN_GROUP=512",
                                     "BWTC_HIP_FIN_GROUP=1024,BWTC_HIP_FIN_WINDOW=2048", "BWTC_HIP_FIN_GROUP=512", "BWTC_HIP_FIN_WINDOW=2048,BWTC_HIP_FIN_GROUP=256",
-                                    "BWTC_HIP_SPLIT_INDEX=0,BWTC_HIP_FIN_PASSES=1"])
+                                    "BWTC_HIP_SPLIT_INDEX=0,BWTC_HIP_FIN_PASSES=1",
+                                    # what the finisher's passes leave of deep repeats: doubled group by group in LDS beside
+                                    # the global list (the default), or joined to the global list as in round 4
+                                    "BWTC_HIP_LOCAL_ROUNDS=0", "BWTC_HIP_LOCAL_ROUNDS=0,BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_FIN_WORDS=3"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
@@ -503,3 +506,28 @@ def test_long_keys_with_a_second_word_of_less_than_one_digit(oracle, monkeypatch
             a = ctx.bwt_block(d, sp)
             b = oracle.oracle_bwt_block(d, sp)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), (extra, it, n, sigma, sp)
+
+
+def test_deep_repeats_take_the_local_rounds(oracle):
+    """Copies of whole files: after the finisher's passes most of what is tied sits in small groups that share thousands
+    of characters.  Those double group by group in LDS (k_finish<RANK>, route bit 64) beside the global list of the
+    groups too large for that; both read one rank[] and both must see each other's refinements.  16 MiB: the block's
+    first 3 MiB twice more, a 40 KB stretch 60 times (groups of 60: local), a 300-byte stretch 2000 times (groups of 2000:
+    global) -- against the reference's sorter."""
+    from bwtc_amd import hip
+    size = 16 << 20
+    d = synth.gen_text(size, 77)
+    d[5 << 20:8 << 20] = d[:3 << 20]
+    d[11 << 20:14 << 20] = d[:3 << 20]
+    for k in range(60):
+        d[(9 << 20) + 40000 * k:(9 << 20) + 40000 * (k + 1)] = d[1234567:1234567 + 40000]
+    for k in range(2000):
+        d[(15 << 20) + 300 * k:(15 << 20) + 300 * (k + 1)] = d[7654321:7654321 + 300]
+    want = oracle.ref_bwt_block(d, 8) if oracle.ref() is not None else oracle.oracle_bwt_block(d, 8)
+    with hip.Context(0, size) as ctx:
+        got = ctx.bwt_block(d, 8)
+        st = ctx.stats()
+        assert st.route & 64, st.route
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        back = ctx.inverse_bwt_block(got[0], got[1])
+        assert (back == d).all()
