@@ -267,10 +267,19 @@ def main():
     # rate and 20 absorb the spread of the host half)
     deep = stream_blocks >= 256 and has_avx512() and os.environ.get("BWTC_HIP_MODELS") == "host"
     auto_depth = 128 if deep and mem_per_rank >= 40 else 96 if deep and mem_per_rank >= 24 else 24 if mem_per_rank >= 48 else 20 if mem_per_rank >= 40 else 16
+    # A rank of a full node may get less than the 40 GB and 16 CPUs the 'B' pipeline likes (8 ranks: 320 GB, 128 CPUs):
+    # the run then goes on with what there is -- fewer blocks under way (a block under way holds about 1.5 GB of
+    # page-locked staging and records), fewer worker threads -- and says so in the line (`degraded`).
+    degraded = []
+    if coder == "B" and mem_per_rank < 40:
+        auto_depth = max(4, min(auto_depth, int((mem_per_rank - 4.0) / 1.5)))
+        degraded.append("%.0f GB of host memory per rank (40 wanted): %d blocks under way" % (mem_per_rank, auto_depth))
     depth = (args.depth if args.depth > 0 else auto_depth) if coder == "B" else 1
     os.environ.setdefault("BWTC_HIP_WAVELET_DEPTH", str(depth))
     cores = usable_cpus()
     threads = max(1, min(64, cores // max(world, 1)))      # the GPU-feeding thread sleeps in its waits
+    if coder == "B" and cores // max(world_hint, 1) < 16:
+        degraded.append("%d usable CPUs per rank (16 wanted): the host half will bind the step" % (cores // max(world_hint, 1)))
     if os.environ.get("BWTC_BENCH_THREADS"):
         threads = max(1, int(os.environ["BWTC_BENCH_THREADS"]))
     ctx = hip.Context(gpu, size)
@@ -389,6 +398,7 @@ def main():
         depth = max(8, min(depth_default, depth_measured))
         while len(pending) > depth:
             collect()
+        ctx.wavelet_set_depth(depth)                     # staging beyond the need goes back to the system (what 8 ranks hold is 8 x this)
     fill_ms = 1e3 * (time.perf_counter() - t0)
     rss = {"before_first_block": rss0, "after_fill": _rss_gb()}
     ctx.reset_kernel_timers()
@@ -668,6 +678,7 @@ def main():
         if coder == "B" and cores // max(world, 1) < 16:
             out["warning"] = ("only %d host threads per rank: the 'B' coder's host half needs about 16 per GPU "
                               "to keep up with the device half" % threads)
+        out["degraded"] = degraded
         if corpus is not None:
             out["corpus"] = corpus
         if args.cpu_c4 and world == 1:

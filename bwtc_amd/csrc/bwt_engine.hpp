@@ -200,6 +200,11 @@ class PinnedPool {
     running_ = false;
   }
   void clear() { stop(); std::lock_guard<std::mutex> g(mu_); free_.clear(); made_ = 0; }
+  // the stream needs fewer buffers than were made: the spare ones above `keep` go back to the system
+  void trim(size_t keep) {
+    std::lock_guard<std::mutex> g(mu_);
+    while (free_.size() > keep) { free_.pop_back(); if (made_) --made_; }
+  }
  private:
   std::mutex mu_;
   std::condition_variable cv_;

@@ -418,6 +418,17 @@ void bwtc_hip_wavelet_reset(bwtc_hip_ctx* ctx) {      // no result of its own: a
   if (ctx) ctx->eng.stream_start_error = rc;
 }
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx) { return ctx ? ctx->eng.max_inflight : 0u; }
+int bwtc_hip_wavelet_set_depth(bwtc_hip_ctx* ctx, uint32_t depth) {
+  if (!ctx || depth == 0) return -1;
+  BwtEngine& e = ctx->eng;
+  if (e.jobs.size() > depth) return -6;                     // more blocks under way than the new depth allows: collect first
+  e.max_inflight = depth;
+  // page-locked staging follows the need: what the pools hold beyond the blocks that can still be begun goes back
+  const size_t spare = depth + 2 > e.jobs.size() ? depth + 2 - e.jobs.size() : 0;
+  e.codes_pool.trim(spare);
+  e.w_pool.trim(spare);
+  return 0;
+}
 uint32_t bwtc_hip_wavelet_depth_needed(bwtc_hip_ctx* ctx) { return ctx && ctx->eng.pipeline ? ctx->eng.pipeline->depthNeeded() : 0u; }
 int bwtc_hip_wavelet_host_clock(bwtc_hip_ctx* ctx, double* model_seconds, double* coder_seconds, uint64_t* blocks) {
   if (!ctx) return -1;
@@ -450,8 +461,12 @@ int bwtc_hip_host_cpu_slice(int numa_node, uint32_t rank, uint32_t ranks, uint32
     // "0-15,128-143" -> the node's CPUs; kept only if some of them are ours
     char path[96];
     std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", numa_node);
+    // BWTC_HIP_NODE<k>_CPULIST=<file>: a made-up topology (tests of the farm's slicing on boxes with one node)
+    char var[48];
+    std::snprintf(var, sizeof var, "BWTC_HIP_NODE%d_CPULIST", numa_node);
+    const char* fake = std::getenv(var);
     std::vector<uint32_t> on_node;
-    if (FILE* f = std::fopen(path, "r")) {
+    if (FILE* f = std::fopen(fake ? fake : path, "r")) {
       unsigned a = 0, b = 0;
       for (;;) {
         if (std::fscanf(f, "%u", &a) != 1) break;

@@ -43,7 +43,7 @@ EXPORTS = [
     "bwtc_hip_wavelet_section_stats", "bwtc_hip_transform_and_encode_wavelet", "bwtc_hip_wavelet_encode",
     "bwtc_hip_wavelet_encode_device", "bwtc_hip_wavelet_encode_device_begin", "bwtc_hip_wavelet_encode_end",
     "bwtc_hip_wavelet_encode_device_prepare", "bwtc_hip_wavelet_encode_queue",
-    "bwtc_hip_wavelet_depth", "bwtc_hip_numa_node", "bwtc_hip_host_cpu_slice", "bwtc_hip_set_worker_cpus", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
+    "bwtc_hip_wavelet_depth", "bwtc_hip_wavelet_set_depth", "bwtc_hip_numa_node", "bwtc_hip_host_cpu_slice", "bwtc_hip_set_worker_cpus", "bwtc_hip_wavelet_reset", "bwtc_hip_wavelet_start", "bwtc_hip_host_wavelet_sections", "bwtc_hip_host_wavelet_streams", "bwtc_hip_host_wavelet_streams_lanes", "bwtc_hip_host_huffman_lengths", "bwtc_hip_host_huffman_codes", "bwtc_hip_host_serialize_shape",
     "bwtc_hip_host_sections", "bwtc_hip_host_bwtblock_header", "bwtc_hip_synth", "bwtc_hip_suffix_array",
     "bwtc_hip_test_sort_u32", "bwtc_hip_test_sort_u64", "bwtc_hip_test_scan_u32",
     "bwtc_hip_wavelet_depth_needed", "bwtc_hip_grammar_create", "bwtc_hip_grammar_destroy", "bwtc_hip_grammar_rules", "bwtc_hip_grammar_special_symbols",
@@ -121,6 +121,7 @@ def load():
     L.bwtc_hip_wavelet_encode_queue.argtypes = [_vp, _u64, _u32, ctypes.POINTER(_u32)]
     L.bwtc_hip_wavelet_depth.restype = ctypes.c_uint32
     L.bwtc_hip_wavelet_depth.argtypes = [_vp]
+    L.bwtc_hip_wavelet_set_depth.argtypes = [_vp, ctypes.c_uint32]
     L.bwtc_hip_wavelet_depth_needed.restype = ctypes.c_uint32
     L.bwtc_hip_wavelet_depth_needed.argtypes = [_vp]
     L.bwtc_hip_wavelet_reset.restype = None
@@ -333,6 +334,10 @@ class Context:
         _check(self.lib.bwtc_hip_wavelet_host_clock(self.handle, ctypes.byref(m), ctypes.byref(c), ctypes.byref(b)),
                "bwtc_hip_wavelet_host_clock")
         return m.value, c.value, b.value
+
+    def wavelet_set_depth(self, depth):
+        """Blocks that may be under way from now on; staging buffers beyond that go back to the system."""
+        _check(self.lib.bwtc_hip_wavelet_set_depth(self.handle, int(depth)), "bwtc_hip_wavelet_set_depth")
 
     def wavelet_depth_needed(self):
         """Blocks to keep under way for the rate shown so far (0 until four blocks have finished)."""

@@ -233,6 +233,11 @@ int bwtc_hip_wavelet_encode_queue(bwtc_hip_ctx* ctx, uint64_t ticket, uint32_t s
                                   uint32_t* state_out);
 /* Blocks that may be between _begin and _end at once on this context. */
 uint32_t bwtc_hip_wavelet_depth(bwtc_hip_ctx* ctx);
+/* Lowers (or raises) the number of blocks that may be under way, and gives the page-locked staging buffers the
+ * stream no longer needs back to the system: a stream's first blocks run at the default depth, the depth it has
+ * shown to need (bwtc_hip_wavelet_depth_needed) is usually half of it, and eight ranks of a node each hold what
+ * they keep.  -6: more blocks are under way than `depth` allows (collect some first). */
+int bwtc_hip_wavelet_set_depth(bwtc_hip_ctx* ctx, uint32_t depth);
 /* Blocks the caller has to keep between _begin and _end for the rate the stream has shown so far: the mean time
  * from a block's _begin to its finished record over the mean time between two _begins, a quarter more, plus two.
  * 0 until four blocks have finished.  A caller that keeps fewer in flight waits in _end; more only hold memory

@@ -29,6 +29,8 @@ def main():
     # host CPUs of this rank's workers: every rank reports the same NUMA node here (a made-up one
     # for half of the ranks when FARM_TWO_NODES is set), the slices must not overlap
     node = farm.rank % 2 if os.environ.get("FARM_TWO_NODES") else -1
+    if os.environ.get("FARM_NODE_OF_RANK"):            # a made-up topology: "0,0,0,0,1,1,1,1"
+        node = int(os.environ["FARM_NODE_OF_RANK"].split(",")[farm.rank])
     cpus = farm.cpu_slice(node)
     os.sched_setaffinity(0, cpus or os.sched_getaffinity(0))
     res = {"rank": farm.rank, "world": farm.world, "mine": mine, "elapsed": elapsed,

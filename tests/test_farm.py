@@ -80,6 +80,44 @@ def test_gloo_farm_ranks_get_disjoint_cpu_slices(tmp_path, world, two_nodes):
             assert len(r["cpus"]) >= 1
 
 
+def test_gloo_farm_eight_ranks_on_a_made_up_two_node_topology(tmp_path):
+    """The scaling row's shape without its hardware: 8 ranks, GPUs 0-3 on NUMA node 0 and 4-7 on node 1 (a made-up
+    topology: BWTC_HIP_NODE<k>_CPULIST files give each node half of this box's CPUs).  Every rank's slice lies on its
+    GPU's node, the four ranks of a node split it without overlap and within one CPU of evenly, nobody is left without
+    a CPU -- and the farm's other collectives (barrier, max, gather in block order) work at world size 8."""
+    usable = sorted(os.sched_getaffinity(0))
+    if len(usable) < 8:
+        pytest.skip("fewer than 8 CPUs")
+    half = len(usable) // 2
+    lists = [usable[:half], usable[half:]]
+    for k, cpus in enumerate(lists):
+        (tmp_path / ("node%d" % k)).write_text(",".join(str(c) for c in cpus) + "\n")
+    out = str(tmp_path / "res")
+    port = _free_port()
+    world, n_blocks = 8, 19
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FARM_NODE_OF_RANK="0,0,0,0,1,1,1,1",
+                   BWTC_HIP_NODE0_CPULIST=str(tmp_path / "node0"), BWTC_HIP_NODE1_CPULIST=str(tmp_path / "node1"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "farm_worker.py"), out, str(n_blocks)], env=env))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+    seen = []
+    for r in res:
+        node = 0 if r["rank"] < 4 else 1
+        assert r["node"] == node
+        assert r["cpus"] and set(r["cpus"]) <= set(lists[node]), (r["rank"], r["cpus"])
+        assert r["mine"] == list(range(r["rank"], n_blocks, world))
+        seen += r["cpus"]
+    assert len(seen) == len(set(seen)), "a CPU was handed to two ranks"
+    for node in (0, 1):
+        sizes = [len(r["cpus"]) for r in res if (r["rank"] >= 4) == bool(node)]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == len(lists[node])
+    assert res[0]["ordered"] == [("block %d" % i)[:7] for i in range(n_blocks)]      # (the worker keeps seven characters)
+
+
 def test_frame_stream_matches_oracle_framing(oracle):
     import numpy as np
     from bwtc_amd.farm import frame_stream
