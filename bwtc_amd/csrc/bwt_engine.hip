@@ -1283,18 +1283,20 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
   __syncthreads();
   // in position order: finals leave, the rest is compacted into the next list
   u32 oS[kFinE], oP[kFinE], oH[kFinE], oC[kFinE];
-  u32 left = 0;
+  u32 left = 0, heads = 0;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid * (u32)kFinE + (u32)e;
     oP[e] = st_P[lp]; oS[e] = st_S[lp]; oH[e] = st_H[lp]; oC[e] = st_C[lp];
-    if (oP[e] != kFinNone && !(oH[e] >> 31)) ++left;
+    if (oP[e] != kFinNone && !(oH[e] >> 31)) { ++left; if (oP[e] == oH[e]) ++heads; }
   }
-  u32 total;
+  u32 total, total_heads;
+  (void)block_scan_excl_add<kFinTPB>(heads, scr, &total_heads);
   u32 at = block_scan_excl_add<kFinTPB>(left, scr, &total);
   if (tid == 0) {
     const u32 oreg = (blockIdx.x / kFinChunk) % kFinRegions;
     s_base = ob.base[oreg] + (total ? atomicAdd(&next_count[oreg], total) : 0u);
+    if (total_heads) atomicAdd(&next_count[kFinRegions], total_heads);      // groups of the list this pass leaves
   }
   __syncthreads();
   at += s_base;
@@ -1319,14 +1321,25 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
 // last pass's leftovers appended) is sorted by slot and dressed up as a list the rounds understand
 // (key = head slot | character << 56, value = suffix, positional slot array), and rank[] is completed
 // for everybody: rank[SA[slot]] = slot for the finished, the group's head slot for the others.
+// (entries of little depth -- a list no pass has looked at -- go to the shallow list instead: one atomic per entry, they are few;
+// their places in the waiting list stay empty: suffix kFinNone, dropped when the list is dressed)
 __global__ __launch_bounds__(256) void k_fin_to_hard(FinList in, u32 m, u32* __restrict__ hardS,
-                                                     u64* __restrict__ hardHP, u32 at, u32* __restrict__ min_depth) {
+                                                     u64* __restrict__ hardHP, u32 at, u32* __restrict__ min_depth, FinShallow shal) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   u32 d = 0xFFFFFFFFu;
   if (i < m) {
-    hardS[at + i] = in.S[i];
-    hardHP[at + i] = ((u64)in.H[i] << 32) | (u64)in.P[i];
-    d = in.C[i] >> 8;
+    const u32 dep = in.C[i] >> 8;
+    const u64 hp = ((u64)in.H[i] << 32) | (u64)in.P[i];
+    if (dep < shal.floor) {
+      const u32 j = atomicAdd(shal.count, 1u);
+      shal.S[j] = in.S[i]; shal.HP[j] = hp;
+      atomicMin(shal.count + 1, dep);
+      hardS[at + i] = kFinNone; hardHP[at + i] = ~0ull;
+    } else {
+      hardS[at + i] = in.S[i];
+      hardHP[at + i] = hp;
+      d = dep;
+    }
   }
   for (int o = kWave / 2; o > 0; o >>= 1) d = min(d, (u32)__shfl_xor(d, o, kWave));
   // the depth the rounds may start from (an atomic only where it lowers what is there: one per wave was 15 ms for 85 M entries)
@@ -2564,7 +2577,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     return 0;
   };
   ranks_live = false;
-  parked = 0;
+  parked = 0; park_holes = 0;
   local_m = 0; local_pending = false;
   if (res.finish) {
     if (re.lf_n == 0 && em->n_lf > 1) return -3;
@@ -2578,7 +2591,10 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     FinList lb{d_W0, d_W1, rb.aglob_next == d_G0 ? d_G1 : d_G0, reinterpret_cast<unsigned short*>(re.achr_out == d_C0 ? d_C1 : d_C0)};
     FinShallow shal{rb.v_keys, static_cast<u64*>(rb.rec_free), cnt + 4, fin_floor};
     FinOutcome fo;
-    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds);
+    // Groups of hundreds of members on average (a period, one text many times over) are not the finisher's: its loop
+    // costs a group's size per member.  The list then goes to the rounds as it is (shallow groups apart).
+    const bool giant = res.groups > 0 && (u64)res.m > (u64)res.groups * 64;
+    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds, giant ? 0 : fin_max_passes);
     if (rc) return rc;
     const u32 shallow = h_small[kSmallFin + 4];
     const u64 h_sh = h_small[kSmallFin + 5];
@@ -2616,7 +2632,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
         BWTC_HIP_TRY(hipMemcpyAsync(d_V0, d_parkS, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
         BWTC_HIP_TRY(hipMemcpyAsync(d_R1, d_parkHP, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
         parked = 0;                        // (the list is in the rounds' hands now: complete_ranks takes it from them)
-        rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res);
+        rc = dress_list(n, total, d_V0, static_cast<u64*>(d_R1), rb, &res, park_holes);
         if (rc) return rc;
       } else {
         // no global list: the rounds still want free regions to complete rank[] in
@@ -2625,7 +2641,8 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
         res.vs = d_V0; res.v_other = d_V1;
         rb.aglob_next = d_G0;
       }
-      rc = run_rounds(total, std::max<u64>(1, h_pk), local_m ? 0 : text_for(total), true, true, nullptr, nullptr);
+      const u32 listed = total ? res.m : 0u;             // (the waiting list without its holes)
+      rc = run_rounds(listed, std::max<u64>(1, h_pk), local_m ? 0 : text_for(listed), true, true, nullptr, nullptr);
       if (rc) return rc;
     }
   } else {
@@ -2646,7 +2663,7 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
 //    fin_floor characters; they share at least *h_shallow
 //   `parked` entries in (d_parkS, d_parkHP): the other groups too large for a window, and what the last
 //    pass left tied; at least *h_parked characters
-int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, FinShallow shal, FinOutcome* fo, bool keep_local) {
+int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, FinShallow shal, FinOutcome* fo, bool keep_local, int max_passes) {
   hipStream_t st = stream;
   u32* cnt = d_small + kSmallFin;      // [1] hard list, [2] its smallest depth; [3] smallest depth of what waits for the rounds; [4] shallow list, [5] its smallest depth
   u32* ncnt = d_small + kSmallFinNext; // entries of the next list, region by region
@@ -2660,7 +2677,8 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
   FinRegions rg;
   std::memset(&rg, 0, sizeof rg);
   rg.nreg = 1; rg.wfirst[0] = 0; rg.wfirst[1] = ceil_div(m, stride); rg.ebase[0] = 0; rg.ecount[0] = m;   // the list as given is one region
-  for (int it = 0; it < fin_max_passes && m > 0; ++it) {
+  u32 groups_left = 0;
+  for (int it = 0; it < std::min(fin_max_passes, max_passes) && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
     stats.finisher_entries += m;
@@ -2668,7 +2686,7 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
     // a window of entries is read by the workgroups whose windows overlap there (4/3 on average), sixteen characters
     // (three aligned words) per owned entry, a byte and a suffix per finished one, an entry per member that stays
     stats.alg_bytes += (u64)m * (14 * 4 / 3 + 24 + 5);
-    BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, kFinRegions * 4, st));
+    BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, (kFinRegions + 1) * 4, st));
     const u32 grid = rg.wfirst[rg.nreg];
     // the regions of the list this pass leaves: chunk c of 64 workgroups appends to region c mod 16 and leaves at most
     // its workgroups' strides of entries and one group more
@@ -2694,9 +2712,10 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
 #undef BWTC_FINISH
 #undef BWTC_FINISH_W
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 24, hipMemcpyDeviceToHost, st));
-    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, kFinRegions * 4, hipMemcpyDeviceToHost, st));
+    BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, (kFinRegions + 1) * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());
     const u32 m_was = m;
+    groups_left = h_small[kSmallFinNext + kFinRegions];
     // what the pass left, region by region
     {
       FinRegions nx;
@@ -2725,7 +2744,9 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
   }
   parked += hard;
   if ((u64)parked > cap) return -3;
-  if (m && keep_local && passes_done >= 1 && (u64)m * 64 >= (u64)n) {        // (a pass has run: no group above the bound is left in the list)
+  // (a pass has run: no group above the bound is left in the list; and its groups are small -- the comparison loop costs a
+  // group's size per member: a block that is one text 256 times over has groups of 256 throughout and is the global rounds')
+  if (m && keep_local && passes_done >= 1 && (u64)m * 64 >= (u64)n && (u64)groups_left * 24 >= (u64)m) {
     // deep repeats in small groups: the doubling rounds take them group by group (local_pass), not through the global sort
     FinList home{d_hardS, d_LP0, d_LH0, d_hardC};
     u32 at = 0;
@@ -2755,8 +2776,16 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
     for (u32 r = 0; r < rg.nreg; ++r) {
       if (!rg.ecount[r]) continue;
       FinList part{a.S + rg.ebase[r], a.P + rg.ebase[r], a.H + rg.ebase[r], a.C + rg.ebase[r]};
-      hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], d_parkS, d_parkHP, parked, cnt + 3);
+      hipLaunchKernelGGL(k_fin_to_hard, dim3(ceil_div(rg.ecount[r], 256)), dim3(256), 0, st, part, rg.ecount[r], d_parkS, d_parkHP, parked, cnt + 3,
+                         passes_done ? FinShallow{shal.S, shal.HP, shal.count, 0u} : shal);
       parked += rg.ecount[r];
+    }
+    if (!passes_done) {
+      // a list no pass has looked at: its shallow entries went to the shallow list and left holes behind
+      const u32 before = h_small[kSmallFin + 4];
+      BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 4, cnt + 4, 8, hipMemcpyDeviceToHost, st));
+      BWTC_HIP_TRY(wait());
+      park_holes += h_small[kSmallFin + 4] - before;
     }
   }
   fo->hard = hard;
@@ -2856,13 +2885,14 @@ int BwtEngine::local_pass(u32 n, u64 h_global, RrEmit& re) {
 // A raw list becomes a list the rounds understand: sorted by slot (groups contiguous, a positional slot
 // array), key = head slot | character << 56, value = suffix.  S / HP must be one of (d_V0 | d_V1) and one
 // of (d_R1 | d_R2); d_W0 / d_W1 and d_G0 receive the list.
-int BwtEngine::dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res) {
+int BwtEngine::dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res, u32 holes) {
   hipStream_t st = stream;
   u64* hp_other = HP == static_cast<u64*>(d_R1) ? static_cast<u64*>(d_R2) : static_cast<u64*>(d_R1);
   u32* s_other = S == d_V0 ? d_V1 : d_V0;
   u64* hp_sorted = nullptr; u32* s_sorted = nullptr;
   sort_pairs<u64>(HP, hp_other, S, s_other, total, bit_width_u64(n ? n - 1 : 0), &hp_sorted, &s_sorted, false);
   u64* fkey = reinterpret_cast<u64*>(d_W0);              // d_W0 and d_W1 are neighbours in the arena: 8 * cap bytes
+  total -= holes;                                        // (entries that left for the shallow list: all ones, sorted to the end)
   hipLaunchKernelGGL(k_bridge_dress, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const u64*)hp_sorted, (const u32*)s_sorted,
                      total, (const u8*)d_T, fkey, d_G0);
   res->m = total; res->groups = 0;

@@ -420,6 +420,7 @@ struct BwtEngine {
   u32* d_parkS = nullptr;    // finisher route: the hard list (suffix; head slot << 32 | slot) while the shallow list takes its rounds
   u64* d_parkHP = nullptr;
   u32 parked = 0;            // this block: entries waiting there
+  u32 park_holes = 0;        //   of which empty (all ones: they sort to the list's end)
   u32* d_hardS = nullptr;    // finisher route: the groups too large for a window (suffix; head slot << 32 | slot; character | depth << 8), until their code round
   u64* d_hardHP = nullptr;
   unsigned short* d_hardC = nullptr;
@@ -438,7 +439,7 @@ struct BwtEngine {
   void complete_ranks(u32 n, const u32* list_sfx, const u32* list_slot, u32 m, void* pairs_region, void* tmp_region);
   // finisher passes over list a (m entries, one region; b: spare list arrays): groups too large for a window go to
   // d_hardS / d_hardHP / d_hardC, shallow ones to shal, what the last pass leaves tied is appended to d_parkS / d_parkHP (`parked`)
-  int finisher_passes(u32 n, u32 m, struct FinList a, struct FinList b, struct RrEmit& re, struct FinShallow shal, FinOutcome* fo, bool keep_local = false);
+  int finisher_passes(u32 n, u32 m, struct FinList a, struct FinList b, struct RrEmit& re, struct FinShallow shal, FinOutcome* fo, bool keep_local = false, int max_passes = 1 << 30);
   // the local list (deep repeats in small groups, doubled group by group beside the global list: bwt_engine.hip, local_pass)
   bool local_rounds = true;  // BWTC_HIP_LOCAL_ROUNDS=0: what the finisher's passes leave joins the waiting list, as in round 4
   u32* d_LP0 = nullptr; u32* d_LH0 = nullptr; u32* d_LH1 = nullptr; unsigned short* d_LC1 = nullptr;
@@ -451,7 +452,7 @@ struct BwtEngine {
   int local_updates();
   int local_pass(u32 n, u64 h_global, struct RrEmit& re);
   // a raw list (suffix; head slot << 32 | slot) in (S, HP) -> a sorted list the rounds understand, in res / rb
-  int dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res);
+  int dress_list(u32 n, u32 total, u32* S, u64* HP, RankBuffers& rb, RankResult* res, u32 holes = 0);
   int long_grams_override = 0;   // BWTC_HIP_LONG_G2=N: N grams in the second key word
   void scatter_rank_pairs(u32* pairs, u32* tmp, u32 m, u32 n);
   int load_text(const u8* d_src, u32 ncopy, u32 n, bool reverse, u32* hist_T);

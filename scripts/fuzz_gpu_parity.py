@@ -38,6 +38,10 @@ def packed(v):
             return bytes(b)
 
 
+FUZZ6_KEYS = ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_FIN_GROUP", "BWTC_HIP_KEYS",
+              "BWTC_HIP_CODE_BITS", "BWTC_HIP_FIN_FLOOR", "BWTC_HIP_LOCAL_ROUNDS", "BWTC_HIP_FIN_WINDOW", "BWTC_HIP_FIN_WORDS")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
@@ -165,26 +169,36 @@ def main():
     # rank completion; every few blocks a new context with one of the route's pieces cut short.  Also `--prepr`
     # through the device sweeps.
     t0, n6 = time.time(), 0
+    # (round 5: code keys are the default; gram keys, shorter code keys, the shallow floor, the local rounds off, the
+    # finisher's window / group / width as variants)
     variants = [{}, {"BWTC_HIP_FIN_PASSES": "1"}, {"BWTC_HIP_TEXT_ROUNDS": "1"}, {"BWTC_HIP_FIN_PASSES": "0", "BWTC_HIP_TEXT_ROUNDS": "0"},
-                {"BWTC_HIP_LONG_G2": "1"}, {"BWTC_HIP_FINISHER": "0"}, {"BWTC_HIP_TEXT_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "2"},
-                {"BWTC_HIP_LONG_DROP": "0"}, {"BWTC_HIP_LONG_DROP": "2", "BWTC_HIP_FIN_GROUP": "256"}, {"BWTC_HIP_LONG_DROP": "1", "BWTC_HIP_FIN_PASSES": "0"}]
+                {"BWTC_HIP_KEYS": "grams", "BWTC_HIP_LONG_G2": "1"}, {"BWTC_HIP_FINISHER": "0"}, {"BWTC_HIP_TEXT_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "2"},
+                {"BWTC_HIP_KEYS": "grams"}, {"BWTC_HIP_CODE_BITS": "48", "BWTC_HIP_FIN_GROUP": "512"}, {"BWTC_HIP_FIN_FLOOR": "48", "BWTC_HIP_FIN_PASSES": "1"},
+                {"BWTC_HIP_LOCAL_ROUNDS": "0"}, {"BWTC_HIP_FIN_WINDOW": "2048", "BWTC_HIP_FIN_GROUP": "1024", "BWTC_HIP_FIN_WORDS": "3"},
+                {"BWTC_HIP_FIN_FLOOR": "0"}, {"BWTC_HIP_CODE_BITS": "64", "BWTC_HIP_TEXT_ROUNDS": "0"}]
     while "6" in phases and time.time() - t0 < budget:
         var = variants[n6 % len(variants)]
         os.environ["BWTC_HIP_GRAM_MIN_N"] = "64"
-        for k in ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_LONG_DROP", "BWTC_HIP_FIN_GROUP"):
+        for k in FUZZ6_KEYS:
             os.environ.pop(k, None)
         os.environ.update(var)
         with hip.Context(device=0, max_block_size=(4 << 20) + 64) as c6:
             for _ in range(12):
                 n = int(rng.integers(200, int(rng.choice([3000, 60000, 900000, 4000000]))))
-                sigma = int(rng.integers(5, 70))
+                sigma = int(rng.integers(5, 70)) if rng.random() < 0.7 else int(rng.integers(120, 240))
                 alphabet = rng.choice(np.arange(0 if rng.random() < 0.3 else 1, 256), sigma, replace=False).astype(np.uint8)
                 words = [alphabet[rng.integers(0, sigma, int(rng.integers(1, 12)))] for _ in range(int(rng.integers(2, 300)))]
                 d = np.concatenate([words[int(i)] for i in rng.integers(0, len(words), n // 2 + 8)])[:n].copy()
                 n = d.size
                 for _ in range(int(rng.integers(0, 12))):
-                    what = int(rng.integers(0, 4))
-                    if what == 0:                              # a planted repeat
+                    what = int(rng.integers(0, 5))
+                    if what == 4:                              # an exotic but repetitive string: symbols from outside the alphabet, a short period, long
+                        rare = np.setdiff1d(np.arange(1, 256), alphabet)[:int(rng.integers(1, 4))].astype(np.uint8)
+                        if rare.size and n > 600:
+                            a = int(rng.integers(0, n - 500))
+                            ln = int(min(n - a, rng.integers(300, 20000)))
+                            d[a:a + ln] = np.tile(rare, ln // rare.size + 1)[:ln]
+                    elif what == 0:                            # a planted repeat
                         ln = int(min(n // 3, rng.integers(1, 1 + int(rng.choice([30, 1500, 200000])))))
                         a, b = int(rng.integers(0, n - ln)), int(rng.integers(0, n - ln))
                         d[b:b + ln] = d[a:a + ln].copy()
@@ -223,7 +237,7 @@ def main():
                         print("MISMATCH phase 6 prepr: size", n, "sigma", sigma, "options", opts, flush=True)
                         np.save(os.path.join(ROOT, "gpurun_out", "fuzz6_prepr_fail_%d.npy" % n6), d)
                 n6 += 1
-    for k in ("BWTC_HIP_GRAM_MIN_N", "BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_LONG_DROP", "BWTC_HIP_FIN_GROUP"):
+    for k in ("BWTC_HIP_GRAM_MIN_N",) + FUZZ6_KEYS:
         os.environ.pop(k, None)
     print("phase 6: %d blocks on the long-key route (and through the pre-stage)" % n6, flush=True)
     print("mismatches:", bad, flush=True)
