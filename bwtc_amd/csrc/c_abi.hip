@@ -1,5 +1,6 @@
 // extern "C" surface of libbwtc_hip.so (include/bwtc_hip.h).
 #include "bwt_engine.hpp"
+#include "gpu_lanes.hpp"
 #include "prepr_host.hpp"
 #include <new>
 #include "radix_sort.hpp"
@@ -755,6 +756,61 @@ int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, ui
   return test_sort<u64>(ctx, keys, vals, n, nbits);
 }
 
+// Test hook of the GPU lane engine (gpu_lanes.hpp): k chains of w-elements, chain j = elements [bounds[j], bounds[j+1]),
+// each coded from a fresh BitEncoder -- on GPU lanes (mode 0) or by the host's runChainW (mode 1).  The chains' bytes
+// (flush included) come back one after the other in `out`, offsets[j] .. offsets[j+1].
+int bwtc_hip_test_gpu_lanes(bwtc_hip_ctx* ctx, const uint16_t* w, uint64_t n, const uint64_t* bounds, uint32_t k, int mode,
+                            uint8_t* out, uint64_t out_cap, uint64_t* offsets) {
+  if (!ctx || !w || !bounds || !out || !offsets || k == 0 || bounds[k] > n) return -1;
+  BWTC_HIP_TRY(hipSetDevice(ctx->eng.device));
+  std::vector<std::vector<uint8_t> > outs(k);
+  struct Src : bwtc::wavelet::ChainSource {
+    const uint16_t* w; const uint64_t* bounds; uint32_t k; std::vector<std::vector<uint8_t> >* outs; std::atomic<uint32_t> at{0}, finished{0};
+    bool next(bwtc::wavelet::ChainDesc* d) {
+      const uint32_t j = at.fetch_add(1);
+      if (j >= k) return false;
+      d->codes = nullptr; d->prob = nullptr; d->w = w; d->begin = bounds[j]; d->end = bounds[j + 1]; d->out = &(*outs)[j];
+      d->cookie = this;
+      return true;
+    }
+    void done(void*) { ++finished; }
+  } src;
+  src.w = w; src.bounds = bounds; src.k = k; src.outs = &outs;
+  int rc = 0;
+  if (mode == 0) {
+    uint16_t* d_w = nullptr;
+    BWTC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_w), n * 2 + 256));
+    if (hipMemcpy(d_w, w, n * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_w); return -3; }
+    const uint16_t* dw = d_w;
+    bwtc_hip::GpuLaneStats st;
+    rc = bwtc_hip::runCoderLanesGpu(src, ctx->eng.device, [dw](void*) { return dw; }, &st);
+    (void)hipFree(d_w);
+    if (std::getenv("BWTC_HIP_DEBUG"))
+      std::fprintf(stderr, "gpu lanes: %llu chains on lanes, %llu on the host, %llu elements, %llu slices, %llu bytes; %.1f ns per lane step\n", (unsigned long long)st.chains.load(),
+                   (unsigned long long)st.host_chains.load(), (unsigned long long)st.elements.load(), (unsigned long long)st.slices.load(), (unsigned long long)st.bytes.load(),
+                   st.slice_steps.load() ? (double)st.slice_ns.load() / (double)st.slice_steps.load() : 0.0);
+  } else {
+    bwtc::wavelet::ChainDesc d;
+    while (src.next(&d)) {
+      bwtc::wavelet::CoderChain c;
+      c.start(d.begin, d.end, d.out);
+      bwtc::wavelet::runChainW(c, d.w, c.e);
+      c.finish();
+      src.done(d.cookie);
+    }
+  }
+  if (rc) return rc;
+  if (src.finished.load() != k) return -3;
+  uint64_t at = 0;
+  for (uint32_t j = 0; j < k; ++j) {
+    offsets[j] = at;
+    if (at + outs[j].size() > out_cap) return -1;
+    std::memcpy(out + at, outs[j].data(), outs[j].size());
+    at += outs[j].size();
+  }
+  offsets[k] = at;
+  return 0;
+}
 int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n) {
   if (!ctx || !data) return -1;
   BwtEngine& e = ctx->eng;

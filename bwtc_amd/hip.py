@@ -34,7 +34,7 @@ class KernelTimers(ctypes.Structure):
 EXPORTS = [
     "bwtc_hip_device_count", "bwtc_hip_version", "bwtc_hip_workspace_bytes", "bwtc_hip_create",
     "bwtc_hip_destroy", "bwtc_hip_stream", "bwtc_hip_get_stats", "bwtc_hip_set_profiling",
-    "bwtc_hip_get_kernel_timers", "bwtc_hip_copy_probe", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
+    "bwtc_hip_get_kernel_timers", "bwtc_hip_copy_probe", "bwtc_hip_test_gpu_lanes", "bwtc_hip_malloc", "bwtc_hip_free", "bwtc_hip_memcpy_to_device",
     "bwtc_hip_memcpy_to_host", "bwtc_hip_host_alloc", "bwtc_hip_host_free",
     "bwtc_hip_memcpy_to_device_async", "bwtc_hip_copy_wait", "bwtc_hip_wavelet_host_clock", "bwtc_hip_wavelet_host_progress", "bwtc_hip_wavelet_latency", "bwtc_hip_host_staging_bytes", "bwtc_hip_host_usable_cpus", "bwtc_hip_n_lf", "bwtc_hip_bwt",
     "bwtc_hip_bwt_block", "bwtc_hip_bwt_block_device", "bwtc_hip_inverse_bwt_block",
@@ -76,6 +76,7 @@ def load():
     L.bwtc_hip_get_stats.argtypes = [_vp, ctypes.POINTER(Stats)]
     L.bwtc_hip_set_profiling.argtypes = [_vp, ctypes.c_int]
     L.bwtc_hip_get_kernel_timers.argtypes = [_vp, ctypes.POINTER(KernelTimers), ctypes.c_int]
+    L.bwtc_hip_test_gpu_lanes.argtypes = [_vp, _vp, _u64, _vp, _u32, ctypes.c_int, _vp, _u64, _vp]
     L.bwtc_hip_copy_probe.argtypes = [_vp, _u64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     L.bwtc_hip_malloc.restype = _vp
     L.bwtc_hip_malloc.argtypes = [_vp, _u64]
@@ -281,6 +282,17 @@ class Context:
                "bwtc_hip_get_kernel_timers")
         return {"scatter_launches": int(k.scatter_launches), "scatter_bytes": int(k.scatter_bytes),
                 "scatter_ms": float(k.scatter_ms)}
+
+    def test_gpu_lanes(self, w, bounds, mode=0):
+        """Chains of w-elements through the GPU lane engine (mode 0) or the host's scalar coder (mode 1): list of byte strings."""
+        w = np.ascontiguousarray(w, np.uint16)
+        b = np.ascontiguousarray(bounds, np.uint64)
+        k = b.size - 1
+        out = np.zeros(int(w.size) * 4 + 16 * k + 64, np.uint8)
+        off = np.zeros(k + 1, np.uint64)
+        _check(self.lib.bwtc_hip_test_gpu_lanes(self.handle, _ptr(w), w.size, _ptr(b), k, mode, _ptr(out), out.size, _ptr(off)),
+               "bwtc_hip_test_gpu_lanes")
+        return [out[int(off[j]):int(off[j + 1])].tobytes() for j in range(k)]
 
     def copy_probe(self, nbytes=1 << 30, reps=5):
         """GB/s (read + written) of the library's own 16-byte-per-lane copy kernel on this GPU (bwtc_hip_copy_probe)."""

@@ -353,6 +353,11 @@ int bwtc_hip_suffix_array(bwtc_hip_ctx* ctx, const uint8_t* T, uint32_t length, 
 int bwtc_hip_test_sort_u32(bwtc_hip_ctx* ctx, uint32_t* keys, uint32_t* vals, uint64_t n, int nbits);
 int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t n, int nbits);
 int bwtc_hip_test_scan_u32(bwtc_hip_ctx* ctx, uint32_t* data, uint64_t n);
+/* Test hook: k range-coder chains over w-elements (w = bit << 15 | probability of the coded bit), chain j = elements
+ * [bounds[j], bounds[j+1]), on the GPU lane engine (mode 0; BitEncoder, BitCoders.cpp:59-113, one lane per chain) or by the
+ * host's scalar loop (mode 1); bytes of chain j = out[offsets[j] .. offsets[j+1]). */
+int bwtc_hip_test_gpu_lanes(bwtc_hip_ctx* ctx, const uint16_t* w, uint64_t n, const uint64_t* bounds, uint32_t k, int mode,
+                            uint8_t* out, uint64_t out_cap, uint64_t* offsets);
 
 /* ---- pair-replacing pre-stage, `--prepr p...` ------------------------------------------
  * Replaces preprocessors/PairReplacer.cpp (analyseData :53-63, decideReplacements :402-484,
