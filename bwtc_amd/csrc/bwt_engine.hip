@@ -1785,6 +1785,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     wavelet_on_host = w && std::strcmp(w, "host") == 0;
     const char* gmv = std::getenv("BWTC_HIP_MODELS");
     device_models = !(gmv && std::strcmp(gmv, "host") == 0);
+    models_side_stream = !(std::getenv("BWTC_HIP_MODELS_STREAM") && std::getenv("BWTC_HIP_MODELS_STREAM")[0] == '0');
     const char* d = std::getenv("BWTC_HIP_WAVELET_DEPTH");
     if (d && std::atoi(d) > 0) max_inflight = (unsigned)std::atoi(d);
     dense_route = !(std::getenv("BWTC_HIP_DENSE") && std::getenv("BWTC_HIP_DENSE")[0] == '0');
@@ -1934,6 +1935,9 @@ void BwtEngine::release() {
   if (d_gm_w) { (void)hipFree(d_gm_w); d_gm_w = nullptr; gm_w_bytes = 0; }
   if (h_gm) { (void)hipHostFree(h_gm); h_gm = nullptr; h_gm_bytes = 0; }
   if (ev_gm_upload) { (void)hipEventDestroy(ev_gm_upload); ev_gm_upload = nullptr; gm_upload_pending = false; }
+  if (gm_stream) { (void)hipStreamSynchronize(gm_stream); (void)hipStreamDestroy(gm_stream); gm_stream = nullptr; }
+  if (ev_packed_ready) { (void)hipEventDestroy(ev_packed_ready); ev_packed_ready = nullptr; }
+  if (ev_gm_done) { (void)hipEventDestroy(ev_gm_done); ev_gm_done = nullptr; gm_done_pending = false; }
   if (ev_codes) { (void)hipEventDestroy(ev_codes); ev_codes = nullptr; }
   if (arena) (void)hipFree(arena);
   if (h_small) (void)hipHostFree(h_small);

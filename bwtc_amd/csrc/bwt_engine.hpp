@@ -227,6 +227,7 @@ struct GmPass {
        *d_tail = nullptr;
   u32 ends[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // the carried state after the block, by the state it starts in
   bool ends_ready = false;
+  void* side = nullptr;                        // the stream the passes run on when it is not the context's (wavelet_models_device)
 };
 
 // A block of the pipeline whose streams came from this device: owns the page-locked bytes.
@@ -317,6 +318,10 @@ struct BwtEngine {
   void* d_gm = nullptr;  u64 gm_bytes = 0;
   void* d_gm_w = nullptr; u64 gm_w_bytes = 0;
   u8* h_gm = nullptr;    u64 h_gm_bytes = 0;
+  hipStream_t gm_stream = nullptr;     // the model passes of the _begin flow: beside the next block's transform
+  hipEvent_t ev_packed_ready = nullptr, ev_gm_done = nullptr;
+  bool gm_done_pending = false;        // the main stream must wait for ev_gm_done before the packed streams' workspace is written again
+  bool models_side_stream = true;      // BWTC_HIP_MODELS_STREAM=0: the passes stay on the context's stream (round 4)
   hipEvent_t ev_gm_upload = nullptr;   // the tables' upload from h_gm has finished (the next block may fill h_gm)
   bool gm_upload_pending = false;
   int reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes);
@@ -497,7 +502,7 @@ int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const 
 // (early_state != null: the state after the block is returned before the long passes are queued -- from
 // that table, else read back with a short wait)
 int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
-                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends = false);
+                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends = false, hipStream_t side = nullptr);
 int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_w, u32* h_tail, u32* early_state);
 
 // WaveletEncoder: writeBlockHeader + encodeData + finishBlock (WaveletCoders.cpp:173-219,

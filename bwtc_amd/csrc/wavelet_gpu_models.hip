@@ -291,9 +291,10 @@ int BwtEngine::reserve_models(u64 device_bytes, u64 host_bytes, u64 w_bytes) {
 // early_state != null -> the state after the block is read back right after the state scan (a wait
 // of some tens of microseconds) and returned, before the long passes are queued.
 int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
-                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends) {
+                           const std::vector<u32>& coded_pos, GmPass* g, bool read_ends, hipStream_t side) {
   BwtEngine::ScanScope scan_scope(e);
-  hipStream_t st = e.stream;
+  hipStream_t st = side ? side : e.stream;             // side: the passes run beside the next block's transform (wavelet_models_device)
+  g->side = side;
   std::vector<gm::Task> tasks;
   std::vector<gm::Chunk> chunks;
   gm::buildTasks(plan, coded_pos.data(), &tasks, &chunks);
@@ -377,7 +378,7 @@ int wavelet_models_prepare(BwtEngine& e, const u32* d_packed, u32 n_coded, const
 
 int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_w, u32* h_tail, u32* early_state) {
   BwtEngine::ScanScope scan_scope(e);
-  hipStream_t st = e.stream;
+  hipStream_t st = g.side ? static_cast<hipStream_t>(g.side) : e.stream;
   if (!g.ready) return -1;
   const u32 nc = g.nc, nt = g.nt, ns = g.ns, nsc = g.nsc, n_coded = g.n_coded;
   const gm::Task* d_tasks = static_cast<const gm::Task*>(g.d_tasks);
@@ -442,10 +443,32 @@ int wavelet_models_run(BwtEngine& e, const GmPass& g, u32 state_in, uint16_t* h_
 
 int wavelet_models_device(BwtEngine& e, const u32* d_packed, u32 n_coded, const bwtc::wavelet::StreamPlan& plan,
                           const std::vector<u32>& coded_pos, u32 state_in, uint16_t* h_w, u32* h_tail) {
+  // One context's stream of blocks (the _begin flow): nothing here waits for the device, so the passes -- 2.9 ms of
+  // kernels per 256 MiB text block that share nothing with the suffix sorter but HBM -- go to a stream of their own and
+  // run beside the NEXT block's transform.  Ordered by events: they start when this block's packed streams are there
+  // (the main stream's position now); the main stream takes the workspace of the packed streams back only when the emit
+  // pass has read them (ev_gm_done, waited for by the next block's stream kernels: wavelet_streams_device).
+  hipStream_t side = nullptr;
+  if (e.models_side_stream) {
+    if (!e.gm_stream) {
+      BWTC_HIP_TRY(hipStreamCreateWithFlags(&e.gm_stream, hipStreamNonBlocking));
+      BWTC_HIP_TRY(hipEventCreateWithFlags(&e.ev_packed_ready, hipEventDisableTiming));
+      BWTC_HIP_TRY(hipEventCreateWithFlags(&e.ev_gm_done, hipEventDisableTiming));
+    }
+    BWTC_HIP_TRY(hipEventRecord(e.ev_packed_ready, e.stream));
+    BWTC_HIP_TRY(hipStreamWaitEvent(e.gm_stream, e.ev_packed_ready, 0));
+    side = e.gm_stream;
+  }
   GmPass g;
-  const int rc = wavelet_models_prepare(e, d_packed, n_coded, plan, coded_pos, &g);
-  if (rc) return rc;
-  return wavelet_models_run(e, g, state_in, h_w, h_tail, nullptr);
+  int rc = wavelet_models_prepare(e, d_packed, n_coded, plan, coded_pos, &g, false, side);
+  if (rc == 0) rc = wavelet_models_run(e, g, state_in, h_w, h_tail, nullptr);
+  if (side) {
+    // (also after an error: whatever was queued there must be through before the workspace changes hands)
+    const hipError_t h = hipEventRecord(e.ev_gm_done, side);
+    e.gm_done_pending = h == hipSuccess;
+    if (h != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(side); }
+  }
+  return rc;
 }
 
 }  // namespace bwtc_hip

@@ -492,6 +492,9 @@ int wavelet_streams_device(BwtEngine& e, const u32* d_run_start, const u8* d_run
   if (nsec == 0 || nsec > 256 || first_run.size() != nsec + 1 || n_runs == 0) return -1;
   BWTC_HIP_TRY(e.codes_wait());                       // the previous block's packed streams have left the device
   BWTC_HIP_TRY(hipSetDevice(e.device));
+  // ... and its model passes (on their own stream, beside this block's transform) have read them: no host wait, the
+  // stream kernels below queue up behind the event
+  if (e.gm_done_pending) { BWTC_HIP_TRY(hipStreamWaitEvent(st, e.ev_gm_done, 0)); e.gm_done_pending = false; }
   const bool dense_ids = !plan.id_group.empty();
   // segmented layout (k_wt_segments): when every section's dense ids fit two digits
   bool segmented = !dense_ids && e.wt_segmented;
