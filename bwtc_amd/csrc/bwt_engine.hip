@@ -2743,6 +2743,7 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
     hard = h_small[kSmallFin + 1];
     std::swap(a, b);
     passes_done = it + 1;
+    if (m < 4096u) break;                                                          // a handful: they join the waiting list (a pass of their own is a launch and a host wait for nothing)
     if (it >= 1 && (u64)m * 5 > (u64)m_was * 3 && (u64)m * 64 > (u64)n) break;     // deep repeats: on to the rounds
     if (it >= 2 && (u64)m * 4 > (u64)m_was * 3) break;                             // a list that hardly shrinks any more: the rounds double, this creeps
   }
