@@ -517,12 +517,13 @@ __global__ __launch_bounds__(256) void k_make_keys_code(const u8* __restrict__ T
   __shared__ u32 s_c0[256];                             // the order-0 row
   __shared__ u32 s_bp[kPos + 8];                        // bit offset of every position's codeword
   __shared__ u32 s_bits[(kPos * kCodeMaxLen) / 32 + 8];
+  __shared__ u32 s_ends[(kPos * kCodeMaxLen) / 32 + 8];   // a one at every codeword's last bit
   __shared__ u64 s_key[kTile];
   __shared__ u32 s_w[kTile];
   __shared__ u32 scr[256 / kWave + 1];
   s_lut[threadIdx.x] = lut[threadIdx.x];
   s_c0[threadIdx.x] = ck.codes[kCodeOrder0 * 256u + threadIdx.x];
-  for (u32 i = threadIdx.x; i < (kPos * kCodeMaxLen) / 32 + 8; i += 256u) s_bits[i] = 0u;
+  for (u32 i = threadIdx.x; i < (kPos * kCodeMaxLen) / 32 + 8; i += 256u) { s_bits[i] = 0u; s_ends[i] = 0u; }
   __syncthreads();
   const u32 J0 = blockIdx.x * kTile;
   if (J0 >= n) return;
@@ -559,6 +560,8 @@ __global__ __launch_bounds__(256) void k_make_keys_code(const u8* __restrict__ T
         atomicOr(&s_bits[word], code >> r);
         atomicOr(&s_bits[word + 1u], code << (32u - r));
       }
+      const u32 last = bp + len - 1u;
+      atomicOr(&s_ends[last >> 5], 0x80000000u >> (last & 31u));
     }
     bp += len;
   }
@@ -594,11 +597,13 @@ __global__ __launch_bounds__(256) void k_make_keys_code(const u8* __restrict__ T
       u64 k_hi, k_lo;                                     // key >> 32, key & 0xFFFFFFFF
       if (need >= 32u) { k_lo = x_lo; k_hi = x_hi | (fc << (need - 32u)); }
       else { const u64 full = (fc << need) | ((x_hi << 32) | x_lo); k_lo = full & 0xFFFFFFFFull; k_hi = full >> 32; }
-      // complete codewords in the key: the first character, and the positions j > t whose codeword ends inside
-      const u32 lim = start + need;
-      u32 lo = t + 1u, hi = min(t + 1u + kCodeLA, span - 1u);   // s_bp[j + 1] <= lim for j < answer
-      while (lo < hi) { const u32 mdl = (lo + hi) >> 1; if (s_bp[mdl + 1u] <= lim) lo = mdl + 1u; else hi = mdl; }
-      const u32 k = 1u + (lo - (t + 1u));
+      // complete codewords in the key: the first character, and the codewords that end inside bits [start, start + need)
+      const u64 ea = ((u64)s_ends[wi] << 32) | (u64)s_ends[wi + 1u];
+      const u64 eb = ((u64)s_ends[wi + 2u] << 32) | (u64)s_ends[wi + 3u];
+      const u64 etop = off ? (ea << off) | (eb >> (64u - off)) : ea;
+      u32 k = 1u;
+      if (need <= 64u) k += need ? (u32)__popcll(etop >> (64u - need)) : 0u;
+      else k += (u32)__popcll(etop) + (u32)__popcll((off ? (eb << off) : eb) >> (128u - need));
       const u32 i = i_base + t;
       u64 key = k_hi;
       key |= (u64)(i ? (u32)s_c[(int)t - 1] : 0u) << ck.chr_shift;

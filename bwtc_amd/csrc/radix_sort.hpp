@@ -29,6 +29,9 @@ constexpr int kRadixBins = 1 << kRadixBits;
 #ifndef BWTC_RADIX_E32
 #define BWTC_RADIX_E32 16
 #endif
+#ifndef BWTC_HIST_COPIES
+#define BWTC_HIST_COPIES 16
+#endif
 constexpr int kRadixTPB = BWTC_RADIX_TPB;         // 8 waves
 constexpr int kRadixWaves = kRadixTPB / kWave;
 
@@ -111,9 +114,12 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
   // on different LDS addresses and banks, so skewed digit distributions (text, DNA, all-equal
   // blocks) do not serialise the ds_add.
   __shared__ u32 hist[kRadixBins * 16];
+  // tiles dealt out as in k_radix_scatter (a contiguous range per XCD; the grid is a whole number of rounds of 8)
+  const u32 tile = (blockIdx.x & 7u) * ((ntiles + 7u) / 8u) + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
   for (u32 i = threadIdx.x; i < kRadixBins * 16; i += kRadixTPB) hist[i] = 0;
   __syncthreads();
-  const u64 tile_base = (u64)blockIdx.x * (kRadixTPB * E);
+  const u64 tile_base = (u64)tile * (kRadixTPB * E);
   const u32 wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const u64 wbase = tile_base + (u64)wave * (kWave * E) + lane;
   const u32 copy = lane & 15u;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ 
     u32 c = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c += hist[threadIdx.x * 16u + r];
-    table[(u64)threadIdx.x * ntiles + blockIdx.x] = c;
+    table[(u64)threadIdx.x * ntiles + tile] = c;
   }
 }
 
@@ -332,28 +338,34 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
   constexpr int HALF = kRadixTPB / 2;
   constexpr int B = 2 * E;                          // bytes of the tile per thread (8, 12, 16 or 32)
   static_assert(B == 8 || B == 12 || B % 16 == 0, "8-byte, 12-byte or whole 16-byte loads");
-  __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * 16];
+  constexpr u32 C = BWTC_HIST_COPIES;                // interleaved copies per bin (copy = thread & (C - 1))
+  __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * C];
   {
     uint4* z = reinterpret_cast<uint4*>(&hist[0][0]);
-    for (u32 i = threadIdx.x; i < 2u * kRadixBins * 16u / 4u; i += kRadixTPB) z[i] = make_uint4(0, 0, 0, 0);
+    for (u32 i = threadIdx.x; i < 2u * kRadixBins * C / 4u; i += kRadixTPB) z[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
   const u32 half = threadIdx.x / HALF, t = threadIdx.x % HALF;
-  const u32 tile = blockIdx.x * 2u + half;
-  if (tile < ntiles) {
+  // tile pairs are dealt out as k_radix_scatter deals its tiles: a contiguous range per XCD (workgroup b runs on XCD
+  // b % 8), so the 4-byte words that neighbouring tiles store into a bin's row meet in ONE L2 and leave as whole lines
+  // (155 -> 115 us for 2^28 items; scripts/dev/hist_probe.cpp) -- and the scatter that reads them runs on the same XCD
+  const u32 npairs = (ntiles + 1u) / 2u, per_xcd = (npairs + 7u) / 8u;
+  const u32 pair = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const u32 tile = pair * 2u + half;
+  if (pair < npairs && tile < ntiles) {
     const u64 base = (u64)tile * (kRadixTPB * E) + (u64)t * B;
-    const u32 copy = t & 15u;
+    const u32 copy = t & (C - 1u);
     u32* h = hist[half];
     if (B == 12 && base + B <= n) {
       const u32* q = reinterpret_cast<const u32*>(plane + base);     // 12 t: a multiple of four
       const u32 w[3] = {q[0], q[1], q[2]};
 #pragma unroll
-      for (int b = 0; b < 12; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+      for (int b = 0; b < 12; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * C + copy], 1u);
     } else if (B == 8 && base + B <= n) {
       const uint2 q = *reinterpret_cast<const uint2*>(plane + base);
       const u32 w[2] = {q.x, q.y};
 #pragma unroll
-      for (int b = 0; b < 8; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+      for (int b = 0; b < 8; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * C + copy], 1u);
     } else if (B % 16 == 0 && base + B <= n) {
       constexpr int Q = B >= 16 ? B / 16 : 1;
       uint4 q[Q];
@@ -363,26 +375,28 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
       for (int i = 0; i < Q; ++i) {
         const u32 w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
 #pragma unroll
-        for (int b = 0; b < 16; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * 16u + copy], 1u);
+        for (int b = 0; b < 16; ++b) atomicAdd(&h[((w[b >> 2] >> (8 * (b & 3))) & 255u) * C + copy], 1u);
       }
     } else {
-      for (int b = 0; b < B; ++b) if (base + b < n) atomicAdd(&h[(u32)plane[base + b] * 16u + copy], 1u);
+      for (int b = 0; b < B; ++b) if (base + b < n) atomicAdd(&h[(u32)plane[base + b] * C + copy], 1u);
     }
   }
   __syncthreads();
-  if (tile < ntiles) {
+  if (pair < npairs && tile < ntiles) {
     SegTile sg = {0, 0, 0};
     if (SEG) sg = seg_of_tile(sa, tile);
     for (u32 bin = t; bin < (u32)kRadixBins; bin += HALF) {
-      const uint4* r4 = reinterpret_cast<const uint4*>(&hist[half][bin * 16u]);
+      const uint4* r4 = reinterpret_cast<const uint4*>(&hist[half][bin * C]);
       u32 c = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const uint4 v = r4[r]; c += v.x + v.y + v.z + v.w; }
+      for (u32 r = 0; r < C / 4u; ++r) { const uint4 v = r4[r]; c += v.x + v.y + v.z + v.w; }
       table[SEG ? seg_table_at(sg, bin, tile) : (u64)bin * ntiles + tile] = c;
     }
   }
 }
 
+// k_radix_hist_plane's grid: two tiles per workgroup, rounded up to whole rounds of the 8 XCDs
+static inline u32 hist_plane_grid(u32 ntiles) { return (((ntiles + 1u) / 2u + 7u) / 8u) * 8u; }
 static inline u64 radix_table_words(u64 max_n) {
   // sized for the smallest tile in use (six items per thread, the long-key sort's), which gives the largest tile count
   const u64 tile = (u64)kRadixTPB * 6;
@@ -452,9 +466,9 @@ static inline void radix_sort_pairs(K* k0, K* k1, V* v0, V* v1, u64 n, int nbits
       const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
       const bool have_plane = plane0 && (!first || (plane0_ready && !skip));   // the previous pass (or the producer) left this pass's digits
       const bool make_plane = plane0 && shift + kRadixBits < nbits;         // and this one leaves the next pass's
-      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles, SegArgs());
-      else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
-      else hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(ntiles), dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
+      if (have_plane) hipLaunchKernelGGL(k_radix_hist_plane<K>, dim3(hist_plane_grid(ntiles)), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n_in, ntiles, SegArgs());
+      else if (skip) hipLaunchKernelGGL((k_radix_hist<K, true>), sgrid, dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
+      else hipLaunchKernelGGL((k_radix_hist<K, false>), sgrid, dim3(kRadixTPB), 0, st, kin, table, n_in, shift, ntiles);
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool timed = probe && probe->begin(st);
 #define BWTC_SCATTER(S, P, KO) hipLaunchKernelGGL((k_radix_scatter<K, S, P, KO, V>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n_in, shift, ntiles, vmode, make_plane ? plane1 : (u8*)nullptr, LongArgs(), SegArgs())
@@ -481,7 +495,7 @@ static inline void radix_sort_keys_segmented(u32* k0, u32* k1, u64 n, int bit_lo
                                              u8* plane0, u8* plane1) {
   constexpr int E = RadixCfg<u32>::E;
   const u32 ntiles = (u32)(n / radix_tile<u32>());
-  const dim3 sgrid(((ntiles + 7u) / 8u) * 8u), hgrid((ntiles + 1u) / 2u), tpb(kRadixTPB);
+  const dim3 sgrid(((ntiles + 7u) / 8u) * 8u), hgrid(hist_plane_grid(ntiles)), tpb(kRadixTPB);
   SegArgs sa; sa.tile_first = tile_first; sa.nseg = nseg;
   hipLaunchKernelGGL((k_radix_hist_plane<u32, E, true>), hgrid, tpb, 0, st, (const u8*)plane0, table, n, ntiles, sa);
   exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
@@ -525,7 +539,7 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
     const u32 ntiles = ceil_div(n, (u64)kRadixTPB * EL);
     const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
     for (int p = 0; p < np; ++p) {
-      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3((ntiles + 1u) / 2u), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles, SegArgs());
+      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3(hist_plane_grid(ntiles)), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles, SegArgs());
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool last = p + 1 == np;
       LongArgs la;
