@@ -1083,6 +1083,53 @@ __device__ __forceinline__ void fin_chars_n(const u8* __restrict__ T, u32 pos, u
   }
 }
 
+// The finisher's comparison loop: how many members of the group at window positions [a, jend) are below the member at
+// position lp, whose key is k (NW big-endian words)?  Four members per step, their LDS reads issued together (one member
+// per step was a chain of LDS latencies); positions past the group's end are read (inside the arrays: they are padded)
+// and not counted.  any_touch (the same for the whole workgroup): some member reaches past the end of T -- "proper
+// prefix sorts first": characters past the end compare as zero bytes, and of two members equal under that rule of which
+// one reaches past the end the shorter -- the larger suffix number -- is the smaller; they are never equal.
+template <int NW>
+__device__ __forceinline__ u32 fin_count_below(const u64* s_ch, const u32* s_S, u32 a, u32 jend, u32 lp, u32 sfx,
+                                               const u64 (&k)[NW], bool any_touch) {
+  u32 below = 0;
+  if (!any_touch) {
+    for (u32 j0 = a; j0 < jend; j0 += 4u) {
+      u64 dd[4][NW];
+#pragma unroll
+      for (u32 u = 0; u < 4u; ++u) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) dd[u][q] = s_ch[(u32)NW * (j0 + u) + (u32)q];
+      }
+#pragma unroll
+      for (u32 u = 0; u < 4u; ++u) {
+        bool lt = false, eq = true;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          lt = lt || (eq && dd[u][q] < k[q]);
+          eq = eq && dd[u][q] == k[q];
+        }
+        below += (j0 + u < jend && lt) ? 1u : 0u;
+      }
+    }
+  } else {
+    const u32 me = s_S[lp];
+    for (u32 j = a; j < jend; ++j) {
+      const u32 sj = s_S[j];
+      bool lt = false, eq = true;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const u64 d = s_ch[(u32)NW * j + (u32)q];
+        lt = lt || (eq && d < k[q]);
+        eq = eq && d == k[q];
+      }
+      if (eq && ((sj | me) >> 31) && j != lp) lt = (sj & 0x7FFFFFFFu) > sfx;
+      below += lt ? 1u : 0u;
+    }
+  }
+  return below;
+}
+
 // hard_count[0]: entries of the hard list, [1]: the smallest depth among them.  Hard entries whose group shares fewer
 // than shal.floor characters go to a list of their own (shal.count[0], [1]: entries, smallest depth): the rounds work
 // at ONE depth for all their groups, the smallest, and a few groups of some exotic but repetitive string (bytes the
@@ -1094,22 +1141,32 @@ struct FinShallow { u32* S; u64* HP; u32* count; u32 floor; };
 // pass only NOTES every member's new rank (its slot when final, else its sub-group's head), by list position, and
 // k_rank_updates writes them afterwards.
 struct FinRank { const u32* rank; u32 at, at2; u32* us; u32* ur; };   // at2 == 0: one look-up
-template <int kFinMaxGroup, int E_ = 4, int NW = 2, bool RANK = false>
-__global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, const u8* __restrict__ T, u32 n,
+// NR (characters only; RANK: 1): the rounds of 8 NW characters a pass makes -- the members that a round leaves tied are
+// compared again, sub-group by sub-group, without leaving the workgroup.  (A template parameter: with the rounds
+// unrolled the kernel needs 30 registers less than with a loop over them, a workgroup more per CU.)
+#ifdef BWTC_FIN_WAVES
+#define BWTC_FIN_BOUNDS __launch_bounds__(kFinTPB, BWTC_FIN_WAVES)
+#else
+#define BWTC_FIN_BOUNDS __launch_bounds__(kFinTPB)
+#endif
+template <int kFinMaxGroup, int E_ = 4, int NW = 2, bool RANK = false, int NR = 1>
+__global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __restrict__ T, u32 n,
                                                     FinList next, FinOut ob, u32* __restrict__ next_count,
                                                     u32* __restrict__ hardS, u64* __restrict__ hardHP, unsigned short* __restrict__ hardC,
                                                     u32* __restrict__ hard_count, FinShallow shal, u32* __restrict__ SA, RrEmit em,
                                                     FinRank rk = FinRank()) {
-  static_assert(!RANK || NW == 2, "rank keys are two words");
+  static_assert(!RANK || (NW == 2 && NR == 1), "rank keys are two words, one round");
+  constexpr u32 nr = NR;
   constexpr int kFinE = E_;                                           // entries per thread: a window of 1024 or 2048
   constexpr int kFinWin = kFinTPB * kFinE;
   static_assert(kFinMaxGroup < kFinWin, "a group must fit the window");
   constexpr int kFinStride = kFinWin - kFinMaxGroup;                  // entries whose groups a workgroup owns
-  constexpr u32 kChars = 8u * NW;                                     // characters compared by this pass
+  constexpr u32 kChars = 8u * NW * NR;                                // characters compared by this pass
   __shared__ __attribute__((aligned(16))) u64 s_ch[(kFinWin + 4) * NW];   // the characters (+ padding for the comparison loop's reads); later the reorder staging
   __shared__ u32 s_S[kFinWin + 4];                                    // suffix | reaches past the end << 31
   __shared__ u32 s_H[kFinWin];
   __shared__ unsigned short s_g[kFinWin + 2];                         // group size by start position; [kFinWin]: the group cut by the window's start
+  __shared__ u32 s_cnt2[NR > 1 ? kFinWin : 1];                        // the sub-group counters of the odd rounds (the even ones': s_H's bytes)
   __shared__ u32 scr[kFinTPB / kWave + 1];
   __shared__ u32 s_base;
   u32* st_S = reinterpret_cast<u32*>(s_ch);                           // staging, by new position
@@ -1151,10 +1208,12 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
   int A[kFinE];                   // group start (window position), or -1: not this workgroup's to settle
   u32 G[kFinE];
   u32 hard_mask = 0;
+  u32* s_cnt = s_H;               // (the heads are in registers by now) members per new sub-group, by its first position
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     const u32 lp = tid + (u32)e * kFinTPB, q = w0 + lp;
     A[e] = -1; G[e] = 0;
+    s_cnt[lp] = 0u;
     if (q < m) {
       const int a = (int)lp - (int)(P[e] - H[e]);
       const u32 g = (P[e] - H[e] < (u32)kFinMaxGroup) ? s_g[a >= 0 ? a : kFinWin] : 0xFFFFu;
@@ -1162,92 +1221,103 @@ __global__ __launch_bounds__(kFinTPB) void k_finish(FinList in, FinRegions rg, c
       else if (a >= 0 && a < kFinStride) { A[e] = a; G[e] = g; }
     }
   }
-  // characters of the members this workgroup settles, each from its own group's depth
-  u64 ch[kFinE][NW];
+  // Rounds.  A round compares 8 NW characters (RANK: the ranks, one round): every member counts the members of its
+  // (sub-)group BELOW it (fin_count_below; broadcast LDS reads: the lanes of a wave walk a few neighbouring groups).
+  // That number names its new sub-group -- equal members count the same -- and its place among its equals is the order
+  // in which they arrive at the sub-group's counter (any order will do: they are a set until something tells them
+  // apart).  The loop carries nothing else: a real text's first pass ran 1560 instructions per entry when it also
+  // counted the equal members before and after.  The next round compares the sub-groups that are left, at their new
+  // places, by the next characters -- loaded while this round counts; they come out of the cache line the first round
+  // paid for: a pass is bound by its random reads of the text, 149 bytes of HBM traffic per entry for the first sixteen
+  // characters.
+  const u32 kRound = 8u * NW;
+  u64 cur[kFinE][NW], nxt[kFinE][NW];
+  u32 a_cur[kFinE], g_cur[kFinE], pos[kFinE];
+  u32 slot0[kFinE];               // the slot of window position 0, were the group to start there (head slot - group start)
+  int touches = 0;
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
+    const u32 lp = tid + (u32)e * kFinTPB;
+    a_cur[e] = A[e] >= 0 ? (u32)A[e] : 0u; g_cur[e] = A[e] >= 0 ? G[e] : 0u; pos[e] = lp;
+    slot0[e] = H[e] - a_cur[e];
 #pragma unroll
-    for (int q = 0; q < NW; ++q) ch[e][q] = 0;
+    for (int q = 0; q < NW; ++q) { cur[e][q] = 0; nxt[e][q] = 0; }
     if (A[e] >= 0) {
       if (RANK) {
         const u64 t1 = (u64)S[e] + rk.at, t2 = (u64)S[e] + rk.at2;
-        ch[e][0] = t1 < (u64)n ? (u64)rk.rank[t1] + 1ull : 0ull;            // (a suffix that ends before the look-up: the smallest key)
-        ch[e][NW - 1] = (rk.at2 && t2 < (u64)n) ? (u64)rk.rank[t2] + 1ull : 0ull;
-      } else fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, ch[e]);
+        cur[e][0] = t1 < (u64)n ? (u64)rk.rank[t1] + 1ull : 0ull;            // (a suffix that ends before the look-up: the smallest key)
+        cur[e][NW - 1] = (rk.at2 && t2 < (u64)n) ? (u64)rk.rank[t2] + 1ull : 0ull;
+      } else fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, cur[e]);
     }
   }
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
     if (A[e] >= 0) {
       const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 touch = (!RANK && (u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 0x80000000u : 0u;
+      const u32 touch = (!RANK && (u64)S[e] + (C[e] >> 8) + kRound > (u64)n) ? 0x80000000u : 0u;        // (in the first round)
 #pragma unroll
-      for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = ch[e][q];
+      for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = cur[e][q];
       s_S[lp] = S[e] | touch;
+      touches |= (!RANK && (u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 1 : 0;                           // (in any round)
     }
   }
-  __syncthreads();
-  // Every member counts the members of its group below it and equal to it (broadcast LDS reads: the lanes of a wave
-  // walk a few neighbouring groups).  "Proper prefix sorts first": characters past the end of T compare as zero bytes,
-  // and of two members equal under that rule of which one reaches past the end the shorter -- the larger suffix number
-  // -- is the smaller; they are never equal.
-  u32 R[kFinE], Q[kFinE];         // members below; equal members before this one | all equal members << 16
+  // (a member that reaches past the end of T: one workgroup in a pass, if any -- everybody else runs the lean loop)
+  const bool any_touch = __syncthreads_or(touches) != 0;
 #pragma unroll
-  for (int e = 0; e < kFinE; ++e) {
-    R[e] = 0; Q[e] = 0;
-    if (A[e] >= 0) {
-      const u32 lp = tid + (u32)e * kFinTPB;
-      const u32 me = s_S[lp];
-      u32 below = 0, eq_before = 0, eq_all = 0;
-      const u32 jend = (u32)A[e] + G[e];
-      // four members per step, their LDS reads issued together (one member per step was a chain of LDS latencies);
-      // positions past the group's end are read (inside the arrays: they are padded) and not counted
-      for (u32 j0 = (u32)A[e]; j0 < jend; j0 += 4u) {
-        u32 sj[4];
-        u64 dd[4][NW];
+  for (u32 r = 0; r < nr; ++r) {
+    u32* cnt = (r & 1u) ? s_cnt2 : s_cnt;              // (the first round's was cleared above)
+    if (r > 0) {
 #pragma unroll
-        for (u32 u = 0; u < 4u; ++u) {
-          sj[u] = s_S[j0 + u];
+      for (int e = 0; e < kFinE; ++e) {
+        cnt[tid + (u32)e * kFinTPB] = 0u;
+        if (g_cur[e] > 1u) {
 #pragma unroll
-          for (int q = 0; q < NW; ++q) dd[u][q] = s_ch[(u32)NW * (j0 + u) + (u32)q];
-        }
-#pragma unroll
-        for (u32 u = 0; u < 4u; ++u) {
-          const u32 j = j0 + u;
-          bool lt = false, eq = true;
-#pragma unroll
-          for (int q = 0; q < NW; ++q) {
-            lt = lt || (eq && dd[u][q] < ch[e][q]);
-            eq = eq && dd[u][q] == ch[e][q];
-          }
-          if (eq && ((sj[u] | me) >> 31) && j != lp) { lt = (sj[u] & 0x7FFFFFFFu) > S[e]; eq = false; }
-          const bool in = j < jend;
-          below += (in && lt) ? 1u : 0u;
-          eq_all += (in && eq) ? 1u : 0u;
-          eq_before += (in && eq && j < lp) ? 1u : 0u;
+          for (int q = 0; q < NW; ++q) s_ch[(u32)NW * pos[e] + (u32)q] = cur[e][q];
+          s_S[pos[e]] = S[e] | (((u64)S[e] + (C[e] >> 8) + (r + 1u) * kRound > (u64)n) ? 0x80000000u : 0u);
         }
       }
-      R[e] = below; Q[e] = eq_before | (eq_all << 16);
-      if (RANK) {                 // the member's new rank, noted by list position (kFinNone: it keeps the one it has)
-        const u32 nr = H[e] + below;                                // (a final member's slot is its sub-group's head)
-        const u32 q = w0 + lp;
-        rk.us[q] = nr != H[e] ? S[e] : kFinNone;
-        rk.ur[q] = nr;
+      __syncthreads();
+    }
+    if (!RANK && r + 1u < nr) {
+#pragma unroll
+      for (int e = 0; e < kFinE; ++e)
+        if (g_cur[e] > 1u) fin_chars_n<NW>(T, S[e] + (C[e] >> 8) + (r + 1u) * kRound, n, nxt[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) {
+      if (g_cur[e] > 1u) {
+        const u32 below = fin_count_below<NW>(s_ch, s_S, a_cur[e], a_cur[e] + g_cur[e], pos[e], S[e], cur[e], any_touch);
+        a_cur[e] += below;
+        if (RANK) {               // the member's new rank, noted by list position (kFinNone: it keeps the one it has)
+          const u32 q = w0 + pos[e];                                 // (a final member's slot is its sub-group's head)
+          rk.us[q] = below ? S[e] : kFinNone;
+          rk.ur[q] = slot0[e] + a_cur[e];
+        }
+        pos[e] = a_cur[e] + atomicAdd(&cnt[a_cur[e]], 1u);           // its place among its equals: as they arrive
+      }
+    }
+    __syncthreads();               // every read of the round's characters is done, every arrival counted
+#pragma unroll
+    for (int e = 0; e < kFinE; ++e) {
+      if (g_cur[e] > 1u) {
+        g_cur[e] = cnt[a_cur[e]];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) cur[e][q] = nxt[e][q];
       }
     }
   }
-  __syncthreads();                 // every read of the characters is done: the bytes become the staging
+  // (the characters' bytes become the staging)
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) st_P[tid + (u32)e * kFinTPB] = kFinNone;
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < kFinE; ++e) {
-    if (A[e] >= 0) {
-      const u32 np = (u32)A[e] + R[e] + (Q[e] & 0xFFFFu);
-      const u32 fin = (Q[e] >> 16) == 1u ? 0x80000000u : 0u;
+    if (g_cur[e]) {                                                            // (a member this workgroup settles)
+      const u32 np = pos[e];
+      const u32 fin = g_cur[e] == 1u ? 0x80000000u : 0u;                       // nobody equals it
       st_S[np] = S[e];
-      st_P[np] = H[e] + R[e] + (Q[e] & 0xFFFFu);
-      st_H[np] = (H[e] + R[e]) | fin;
+      st_P[np] = slot0[e] + np;
+      st_H[np] = (slot0[e] + a_cur[e]) | fin;
       st_C[np] = RANK ? (unsigned short)C[e] : (unsigned short)((C[e] & 0xFFu) | (min(255u, (C[e] >> 8) + kChars) << 8));
     }
   }
@@ -1820,6 +1890,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_FIN_WORDS")) fin_words = std::min(4, std::max(2, std::atoi(std::getenv("BWTC_HIP_FIN_WORDS"))));
+    if (std::getenv("BWTC_HIP_FIN_ROUNDS")) fin_rounds = std::min(3, std::max(1, std::atoi(std::getenv("BWTC_HIP_FIN_ROUNDS"))));
     local_rounds = !(std::getenv("BWTC_HIP_LOCAL_ROUNDS") && std::getenv("BWTC_HIP_LOCAL_ROUNDS")[0] == '0');
     if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
@@ -2687,14 +2758,16 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
   std::memset(&rg, 0, sizeof rg);
   rg.nreg = 1; rg.wfirst[0] = 0; rg.wfirst[1] = ceil_div(m, stride); rg.ebase[0] = 0; rg.ecount[0] = m;   // the list as given is one region
   u32 groups_left = 0;
-  for (int it = 0; it < std::min(fin_max_passes, max_passes) && m > 0; ++it) {
+  const u32 pass_chars = 8u * (u32)fin_words * (fin_words == 2 ? (u32)fin_rounds : 1u);
+  const int depth_passes = (int)((255u - 48u) / pass_chars);      // the depth byte holds 255 (a level's depth is 48 at most)
+  for (int it = 0; it < std::min(std::min(fin_max_passes, std::max(1, depth_passes)), max_passes) && m > 0; ++it) {
     ++stats.rounds;
     stats.active_sum += m;
     stats.finisher_entries += m;
     stats.route |= 2u;
     // a window of entries is read by the workgroups whose windows overlap there (4/3 on average), sixteen characters
     // (three aligned words) per owned entry, a byte and a suffix per finished one, an entry per member that stays
-    stats.alg_bytes += (u64)m * (14 * 4 / 3 + 24 + 5);
+    stats.alg_bytes += (u64)m * (14 * 4 / 3 + (pass_chars + 8) + 5);
     BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, (kFinRegions + 1) * 4, st));
     const u32 grid = rg.wfirst[rg.nreg];
     // the regions of the list this pass leaves: chunk c of 64 workgroups appends to region c mod 16 and leaves at most
@@ -2713,13 +2786,17 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
     }
 #define BWTC_FINISH_W(G, E, NW) hipLaunchKernelGGL((k_finish<G, E, NW>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
                                              b, ob, ncnt, d_parkS + park0, d_parkHP + park0, d_hardC, cnt + 1, shal, d_SA, re)
-#define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); else BWTC_FINISH_W(G, E, 2); } while (0)
+#define BWTC_FINISH_R(G, E, NR) hipLaunchKernelGGL((k_finish<G, E, 2, false, NR>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
+                                             b, ob, ncnt, d_parkS + park0, d_parkHP + park0, d_hardC, cnt + 1, shal, d_SA, re)
+#define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); \
+                               else if (fin_rounds >= 3) BWTC_FINISH_R(G, E, 3); else if (fin_rounds == 2) BWTC_FINISH_R(G, E, 2); else BWTC_FINISH_W(G, E, 2); } while (0)
     if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
     else if (group <= 256) BWTC_FINISH(256, 8);
     else if (group <= 512) BWTC_FINISH(512, 8);
     else BWTC_FINISH(1024, 8);
 #undef BWTC_FINISH
 #undef BWTC_FINISH_W
+#undef BWTC_FINISH_R
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin, cnt, 24, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, (kFinRegions + 1) * 4, hipMemcpyDeviceToHost, st));
     BWTC_HIP_TRY(wait());

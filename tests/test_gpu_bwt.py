@@ -355,7 +355,10 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_SPLIT_INDEX=0,BWTC_HIP_FIN_PASSES=1",
                                     # what the finisher's passes leave of deep repeats: doubled group by group in LDS beside
                                     # the global list (the default), or joined to the global list as in round 4
-                                    "BWTC_HIP_LOCAL_ROUNDS=0", "BWTC_HIP_LOCAL_ROUNDS=0,BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_FIN_WORDS=3"])
+                                    "BWTC_HIP_LOCAL_ROUNDS=0", "BWTC_HIP_LOCAL_ROUNDS=0,BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_FIN_WORDS=3",
+                                    # rounds of sixteen characters a finisher pass makes inside the workgroup (default three)
+                                    "BWTC_HIP_FIN_ROUNDS=1", "BWTC_HIP_FIN_ROUNDS=2", "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_GROUP=512",
+                                    "BWTC_HIP_FIN_ROUNDS=1,BWTC_HIP_FIN_PASSES=1"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
@@ -426,7 +429,8 @@ def test_device_pointers_unaligned_and_aliased(hip_ctx, oracle):
 
 
 @pytest.mark.parametrize("extra", ["", "BWTC_HIP_FIN_PASSES=1", "BWTC_HIP_TEXT_ROUNDS=1", "BWTC_HIP_FIN_PASSES=0,BWTC_HIP_TEXT_ROUNDS=0",
-                                   "BWTC_HIP_KEYS=grams", "BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_CODE_BITS=48"])
+                                   "BWTC_HIP_KEYS=grams", "BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_CODE_BITS=48", "BWTC_HIP_FIN_ROUNDS=1",
+                                   "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_PASSES=1"])
 def test_long_key_route_on_small_structured_blocks(oracle, monkeypatch, extra):
     """The long-key route (long keys, ranking at the long key's depth, finisher, text rounds, late rank completion)
     on blocks small enough for the oracle but of every shape: BWTC_HIP_GRAM_MIN_N lets blocks of a few thousand bytes
