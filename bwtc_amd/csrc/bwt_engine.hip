@@ -1032,7 +1032,11 @@ __global__ __launch_bounds__(kRrTPB) void k_rerank_apply(
 // that are equal under that rule and of which one reaches past the end, the shorter (larger suffix
 // number) is the smaller -- they are never equal (the network's comparison knows).
 // ---------------------------------------------------------------------------------------
-constexpr int kFinTPB = 256;
+#ifndef BWTC_FIN_TPB
+#define BWTC_FIN_TPB 256
+#endif
+constexpr int kFinTPB = BWTC_FIN_TPB;             // threads of a finisher workgroup; a window is 1024 or 2048 entries
+constexpr int kFinE1 = 1024 / kFinTPB, kFinE2 = 2048 / kFinTPB;   // entries per thread
 constexpr u32 kFinNone = 0xFFFFFFFFu;
 
 struct FinList { u32* S; u32* P; u32* H; unsigned short* C; };
@@ -1890,6 +1894,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_LONG_E")) long_items_per_thread = std::atoi(std::getenv("BWTC_HIP_LONG_E")) == 6 ? 6 : 8;
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_FIN_WORDS")) fin_words = std::min(4, std::max(2, std::atoi(std::getenv("BWTC_HIP_FIN_WORDS"))));
+    if (std::getenv("BWTC_HIP_LONG_DIRECT")) long_direct = std::getenv("BWTC_HIP_LONG_DIRECT")[0] != '0';
     if (std::getenv("BWTC_HIP_FIN_ROUNDS")) fin_rounds = std::min(3, std::max(1, std::atoi(std::getenv("BWTC_HIP_FIN_ROUNDS"))));
     local_rounds = !(std::getenv("BWTC_HIP_LOCAL_ROUNDS") && std::getenv("BWTC_HIP_LOCAL_ROUNDS")[0] == '0');
     if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
@@ -2513,13 +2518,13 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
       u64* ks = nullptr; unsigned short* vs16 = nullptr; u32* ws = nullptr;
       u32* vs32 = nullptr;
       if (!split_now)
-        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1, 0);
+        radix_sort_long<u32, 6>(ka, kb, d_V0, d_V1, d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs32, &ws, &probe, d_P0, d_P1, 0, false, long_direct);
       else if (long_items_per_thread == 6)
         radix_sort_long<unsigned short, 6>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0, false, long_direct);
       else
         radix_sort_long<unsigned short, 8>(ka, kb, reinterpret_cast<unsigned short*>(d_V0), reinterpret_cast<unsigned short*>(d_V1),
-                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0);
+                                           d_W0, d_W1, n, key_bits, w_bits, d_table, d_partial, stream, &ks, &vs16, &ws, &probe, d_P0, d_P1, 0, false, long_direct);
       BWTC_HIP_TRY(hipEventRecord(ev_sort[n_sort_events++], st));
       u32* vs = split_now ? reinterpret_cast<u32*>(vs16) : vs32;
       rb.rec_keys = ks; rb.rec_free = ks == ka ? kb : ka;
@@ -2790,10 +2795,10 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
                                              b, ob, ncnt, d_parkS + park0, d_parkHP + park0, d_hardC, cnt + 1, shal, d_SA, re)
 #define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); \
                                else if (fin_rounds >= 3) BWTC_FINISH_R(G, E, 3); else if (fin_rounds == 2) BWTC_FINISH_R(G, E, 2); else BWTC_FINISH_W(G, E, 2); } while (0)
-    if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, 4); else BWTC_FINISH(512, 4); }
-    else if (group <= 256) BWTC_FINISH(256, 8);
-    else if (group <= 512) BWTC_FINISH(512, 8);
-    else BWTC_FINISH(1024, 8);
+    if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, kFinE1); else BWTC_FINISH(512, kFinE1); }
+    else if (group <= 256) BWTC_FINISH(256, kFinE2);
+    else if (group <= 512) BWTC_FINISH(512, kFinE2);
+    else BWTC_FINISH(1024, kFinE2);
 #undef BWTC_FINISH
 #undef BWTC_FINISH_W
 #undef BWTC_FINISH_R
@@ -2933,10 +2938,10 @@ int BwtEngine::local_pass(u32 n, u64 h_global, RrEmit& re) {
   FinRank rk{d_rank, (u32)at, (u32)at2, d_US, d_UR};
 #define BWTC_LOCAL(G, E) hipLaunchKernelGGL((k_finish<G, E, 2, true>), dim3(grid), dim3(kFinTPB), 0, st, local_list(local_home), local_rg, (const u8*)d_T, n, \
                                             local_list(1 - local_home), ob, ncnt, d_parkS, d_parkHP, d_LC1 /* never written: no group is too large */, cnt + 1, none, d_SA, re, rk)
-  if (window <= 1024) { if (group <= 256) BWTC_LOCAL(256, 4); else BWTC_LOCAL(512, 4); }
-  else if (group <= 256) BWTC_LOCAL(256, 8);
-  else if (group <= 512) BWTC_LOCAL(512, 8);
-  else BWTC_LOCAL(1024, 8);
+  if (window <= 1024) { if (group <= 256) BWTC_LOCAL(256, kFinE1); else BWTC_LOCAL(512, kFinE1); }
+  else if (group <= 256) BWTC_LOCAL(256, kFinE2);
+  else if (group <= 512) BWTC_LOCAL(512, kFinE2);
+  else BWTC_LOCAL(1024, kFinE2);
 #undef BWTC_LOCAL
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFin + 1, cnt + 1, 4, hipMemcpyDeviceToHost, st));
   BWTC_HIP_TRY(hipMemcpyAsync(h_small + kSmallFinNext, ncnt, kFinRegions * 4, hipMemcpyDeviceToHost, st));

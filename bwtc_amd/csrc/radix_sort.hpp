@@ -105,11 +105,11 @@ __device__ __forceinline__ u64 seg_table_at(const SegTile& st, u32 bin, u32 tile
 
 // skip: items whose key is all ones do not exist (first pass of a sort whose input was written
 // with holes, see k_gather_dense): they are neither counted nor moved, so the pass compacts.
-template <typename K, bool SKIP>
+template <typename K, bool SKIP, int E_ = RadixCfg<K>::E>
 __global__ __launch_bounds__(kRadixTPB) void k_radix_hist(const K* __restrict__ keys,
                                                           u32* __restrict__ table, u64 n,
                                                           int shift, u32 ntiles) {
-  constexpr int E = RadixCfg<K>::E;
+  constexpr int E = E_;
   // 16 interleaved copies per bin (copy = lane & 15): equal digits of neighbouring lanes land
   // on different LDS addresses and banks, so skewed digit distributions (text, DNA, all-equal
   // blocks) do not serialise the ds_add.
@@ -395,6 +395,58 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_hist_plane(const u8* __rest
   }
 }
 
+// Tile histogram of digit (w >> shift) & 255 of 32-bit words (the long-key sort's second word): k_radix_hist_plane's
+// scheme -- two tiles per workgroup, sixteen interleaved copies per bin, tile pairs dealt out per XCD -- with 16-byte loads
+// of four words.  Same table as k_radix_hist<u32> over tiles of kRadixTPB * E_ words.
+template <int E_>
+__global__ __launch_bounds__(kRadixTPB) void k_radix_hist_words(const u32* __restrict__ words, u32* __restrict__ table, u64 n,
+                                                                int shift, u32 ntiles) {
+  constexpr int HALF = kRadixTPB / 2;
+  constexpr int TILE = kRadixTPB * E_;                 // words of a tile
+  constexpr int Q = TILE / (HALF * 4);                 // 16-byte loads per thread
+  static_assert(TILE % (HALF * 4) == 0, "whole 16-byte loads");
+  constexpr u32 C = BWTC_HIST_COPIES;
+  __shared__ __attribute__((aligned(16))) u32 hist[2][kRadixBins * C];
+  {
+    uint4* z = reinterpret_cast<uint4*>(&hist[0][0]);
+    for (u32 i = threadIdx.x; i < 2u * kRadixBins * C / 4u; i += kRadixTPB) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const u32 half = threadIdx.x / HALF, t = threadIdx.x % HALF;
+  const u32 npairs = (ntiles + 1u) / 2u, per_xcd = (npairs + 7u) / 8u;
+  const u32 pair = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const u32 tile = pair * 2u + half;
+  if (pair < npairs && tile < ntiles) {
+    const u64 base = (u64)tile * TILE;
+    const u32 copy = t & (C - 1u);
+    u32* h = hist[half];
+    if (base + TILE <= n) {
+      const uint4* src = reinterpret_cast<const uint4*>(words + base);     // tiles start at multiples of 16 bytes
+      uint4 q[Q];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) q[i] = src[t + (u32)i * HALF];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const u32 w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) atomicAdd(&h[((w[b] >> shift) & 255u) * C + copy], 1u);
+      }
+    } else {
+      for (u64 i = base + t; i < n; i += HALF) atomicAdd(&h[((words[i] >> shift) & 255u) * C + copy], 1u);
+    }
+  }
+  __syncthreads();
+  if (pair < npairs && tile < ntiles) {
+    for (u32 bin = t; bin < (u32)kRadixBins; bin += HALF) {
+      const uint4* r4 = reinterpret_cast<const uint4*>(&hist[half][bin * C]);
+      u32 c = 0;
+#pragma unroll
+      for (u32 r = 0; r < C / 4u; ++r) { const uint4 v = r4[r]; c += v.x + v.y + v.z + v.w; }
+      table[(u64)bin * ntiles + tile] = c;
+    }
+  }
+}
+
 // k_radix_hist_plane's grid: two tiles per workgroup, rounded up to whole rounds of the 8 XCDs
 static inline u32 hist_plane_grid(u32 ntiles) { return (((ntiles + 1u) / 2u + 7u) / 8u) * 8u; }
 static inline u64 radix_table_words(u64 max_n) {
@@ -518,7 +570,11 @@ template <typename V, int EL = 8>
 static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32* w1, u64 n, int kbits, int wbits,
                                    u32* table, u32* partial, hipStream_t st, u64** k_sorted, V** v_sorted,
                                    u32** w_sorted, ScatterProbe* probe, u8* plane0, u8* plane1, int wlo = 0,
-                                   bool values_given = false) {
+                                   bool values_given = false, bool direct_w = true) {
+  // direct_w: the passes over w's digits (but the first, whose plane the producer made) take their histograms from the w
+  // words themselves and the pass before them leaves no plane.  A plane costs its scattered byte stores (runs of 16 bytes:
+  // 0.33 ms of a 1.74 ms pass over 2^28 items) and the histogram's read of it (0.13 ms); reading 4 bytes per item costs
+  // 0.2 ms.  (A key digit's 8 bytes per item cost what the plane does: those passes keep theirs.)
   // wlo: w's lowest bits that do NOT take part in the order (the sorted bits are [wlo, wlo + wbits))
   u64 *kin = k0, *kout = k1;
   V *vin = v0, *vout = v1;
@@ -539,21 +595,24 @@ static inline void radix_sort_long(u64* k0, u64* k1, V* v0, V* v1, u32* w0, u32*
     const u32 ntiles = ceil_div(n, (u64)kRadixTPB * EL);
     const dim3 sgrid(((ntiles + 7u) / 8u) * 8u);
     for (int p = 0; p < np; ++p) {
-      hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3(hist_plane_grid(ntiles)), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles, SegArgs());
+      const bool from_words = direct_w && p > 0 && ps[p].from_w == 1 && ps[p].dmask == (1u << kRadixBits) - 1u;
+      if (from_words) hipLaunchKernelGGL((k_radix_hist_words<EL>), dim3(hist_plane_grid(ntiles)), dim3(kRadixTPB), 0, st, (const u32*)win, table, n, ps[p].shift, ntiles);
+      else hipLaunchKernelGGL((k_radix_hist_plane<u64, EL>), dim3(hist_plane_grid(ntiles)), dim3(kRadixTPB), 0, st, (const u8*)plane0, table, n, ntiles, SegArgs());
       exclusive_scan_u32(table, (u64)ntiles * kRadixBins, partial, st);
       const bool last = p + 1 == np;
+      const bool no_plane = last || (direct_w && ps[p + 1].from_w == 1 && ps[p + 1].dmask == (1u << kRadixBits) - 1u);   // the next pass reads none
       LongArgs la;
       la.win = win; la.wout = wout; la.dmask = ps[p].dmask; la.bridge = ps[p].bridge;
       la.nshift = last ? 0 : ps[p + 1].shift; la.nfrom_w = last ? 0 : ps[p + 1].from_w; la.ndmask = last ? 0u : ps[p + 1].dmask;
       la.nbridge = last ? 0 : ps[p + 1].bridge;
       const int vmode = (p == 0 && !values_given) ? 3 : 0;     // values_given: v0 holds the items' values (else the first pass makes them up)
       const bool timed = probe && probe->begin(st);
-#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, last ? (u8*)nullptr : plane1, la, SegArgs())
-      if (ps[p].from_w == 2) { if (last) BWTC_SCATTER_L(false, 3); else BWTC_SCATTER_L(true, 3); }
-      else if (ps[p].from_w) { if (last) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
-      else { if (last) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
+#define BWTC_SCATTER_L(P, L) hipLaunchKernelGGL((k_radix_scatter<u64, false, P, false, V, L, EL>), sgrid, dim3(kRadixTPB), 0, st, kin, vin, kout, vout, table, n, ps[p].shift, ntiles, vmode, no_plane ? (u8*)nullptr : plane1, la, SegArgs())
+      if (ps[p].from_w == 2) { if (no_plane) BWTC_SCATTER_L(false, 3); else BWTC_SCATTER_L(true, 3); }
+      else if (ps[p].from_w) { if (no_plane) BWTC_SCATTER_L(false, 2); else BWTC_SCATTER_L(true, 2); }
+      else { if (no_plane) BWTC_SCATTER_L(false, 1); else BWTC_SCATTER_L(true, 1); }
 #undef BWTC_SCATTER_L
-      if (timed) probe->end(st, 2 * n * (sizeof(u64) + sizeof(V) + sizeof(u32)) + (last ? 0 : n));
+      if (timed) probe->end(st, 2 * n * (sizeof(u64) + sizeof(V) + sizeof(u32)) + (no_plane ? 0 : n));
       { u8* tp = plane0; plane0 = plane1; plane1 = tp; }
       { u64* t = kin; kin = kout; kout = t; }
       { V* t = vin; vin = vout; vout = t; }

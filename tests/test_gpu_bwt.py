@@ -358,7 +358,9 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_LOCAL_ROUNDS=0", "BWTC_HIP_LOCAL_ROUNDS=0,BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_FIN_WORDS=3",
                                     # rounds of sixteen characters a finisher pass makes inside the workgroup (default three)
                                     "BWTC_HIP_FIN_ROUNDS=1", "BWTC_HIP_FIN_ROUNDS=2", "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_GROUP=512",
-                                    "BWTC_HIP_FIN_ROUNDS=1,BWTC_HIP_FIN_PASSES=1"])
+                                    "BWTC_HIP_FIN_ROUNDS=1,BWTC_HIP_FIN_PASSES=1",
+                                    # the long-key sort's second-word passes with digit planes, as the key word's passes
+                                    "BWTC_HIP_LONG_DIRECT=0"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
