@@ -530,13 +530,15 @@ def main():
         if args.size_mib == 256 and pmcs:
             # all scatter launches of the transform (the same mix the probe averages over)
             tot_b, tot_n = 0.0, 0
-            for name, v in json.load(open(pmcs[-1]))["kernels"].items():
+            pmc_kernels = json.load(open(pmcs[-1]))["kernels"]
+            has_long = any("k_radix_scatter<unsigned long" in k and "unsigned short, " in k for k in pmc_kernels)
+            for name, v in pmc_kernels.items():
                 # the launches the probe times: the suffix sorter's full-size passes (round 4: the long-key sort's,
                 # whose items carry a 16-bit value and a second key word; not the 'B' coder's keys-only step sort,
                 # not the few-thousand-item passes of the text rounds)
                 is_long = "k_radix_scatter<unsigned long" in name and any("unsigned short, %d," % m in name for m in (1, 2, 3))
                 is_old = "k_radix_scatter<" in name and "unsigned short" not in name and ", true, unsigned int, 0, 16>" not in name
-                if (is_long or (is_old and v["hbm_bytes_per_launch_avg"] > 1e8 and "r04" not in os.path.basename(pmcs[-1]))):
+                if (is_long or (is_old and not has_long and v["hbm_bytes_per_launch_avg"] > 1e8 and "r04" not in os.path.basename(pmcs[-1]))):
                     tot_b += v["hbm_bytes_per_launch_avg"] * v["launches"]
                     tot_n += v["launches"]
             if tot_n:
