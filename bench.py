@@ -527,7 +527,7 @@ def main():
         # by scripts/pmc_summary.py).  Only quoted for the workload it was measured on.
         traffic, traffic_src = None, None
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_text256.json")))
-        if args.size_mib == 256 and pmcs:
+        if args.size_mib == 256 and args.workload == "c3" and pmcs:
             # all scatter launches of the transform (the same mix the probe averages over)
             tot_b, tot_n = 0.0, 0
             pmc_kernels = json.load(open(pmcs[-1]))["kernels"]
