@@ -1105,15 +1105,14 @@ __device__ __forceinline__ u32 fin_count_below(const u64* s_ch, const u32* s_S, 
 #pragma unroll
         for (int q = 0; q < NW; ++q) dd[u][q] = s_ch[(u32)NW * (j0 + u) + (u32)q];
       }
+      // (no short cuts: with `||` and `&&` the compiler made the second word's read and comparison a branch per
+      // member -- four dependent LDS round trips a step)
 #pragma unroll
       for (u32 u = 0; u < 4u; ++u) {
-        bool lt = false, eq = true;
+        u32 lt = (u32)(dd[u][NW - 1] < k[NW - 1]);
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-          lt = lt || (eq && dd[u][q] < k[q]);
-          eq = eq && dd[u][q] == k[q];
-        }
-        below += (j0 + u < jend && lt) ? 1u : 0u;
+        for (int q = NW - 2; q >= 0; --q) lt = (u32)(dd[u][q] < k[q]) | ((u32)(dd[u][q] == k[q]) & lt);
+        below += lt & (u32)(j0 + u < jend);
       }
     }
   } else {
@@ -1231,11 +1230,11 @@ __global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __
   // in which they arrive at the sub-group's counter (any order will do: they are a set until something tells them
   // apart).  The loop carries nothing else: a real text's first pass ran 1560 instructions per entry when it also
   // counted the equal members before and after.  The next round compares the sub-groups that are left, at their new
-  // places, by the next characters -- loaded while this round counts; they come out of the cache line the first round
-  // paid for: a pass is bound by its random reads of the text, 149 bytes of HBM traffic per entry for the first sixteen
+  // places, by the next characters -- read with the first round's: they come out of the cache line the first round paid
+  // for, and a pass is bound by its random reads of the text, 149 bytes of HBM traffic per entry for the first sixteen
   // characters.
   const u32 kRound = 8u * NW;
-  u64 cur[kFinE][NW], nxt[kFinE][NW];
+  u64 all[kFinE][NW * NR];        // every round's characters, read in one go (RANK: the keys)
   u32 a_cur[kFinE], g_cur[kFinE], pos[kFinE];
   u32 slot0[kFinE];               // the slot of window position 0, were the group to start there (head slot - group start)
   int touches = 0;
@@ -1245,13 +1244,18 @@ __global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __
     a_cur[e] = A[e] >= 0 ? (u32)A[e] : 0u; g_cur[e] = A[e] >= 0 ? G[e] : 0u; pos[e] = lp;
     slot0[e] = H[e] - a_cur[e];
 #pragma unroll
-    for (int q = 0; q < NW; ++q) { cur[e][q] = 0; nxt[e][q] = 0; }
+    for (int q = 0; q < NW * NR; ++q) all[e][q] = 0;
     if (A[e] >= 0) {
       if (RANK) {
         const u64 t1 = (u64)S[e] + rk.at, t2 = (u64)S[e] + rk.at2;
-        cur[e][0] = t1 < (u64)n ? (u64)rk.rank[t1] + 1ull : 0ull;            // (a suffix that ends before the look-up: the smallest key)
-        cur[e][NW - 1] = (rk.at2 && t2 < (u64)n) ? (u64)rk.rank[t2] + 1ull : 0ull;
-      } else fin_chars_n<NW>(T, S[e] + (C[e] >> 8), n, cur[e]);
+        all[e][0] = t1 < (u64)n ? (u64)rk.rank[t1] + 1ull : 0ull;            // (a suffix that ends before the look-up: the smallest key)
+        all[e][NW - 1] = (rk.at2 && t2 < (u64)n) ? (u64)rk.rank[t2] + 1ull : 0ull;
+      } else {
+        // every round's characters in one go: the later rounds' come out of the line(s) the first round's are in.  (Loaded
+        // a round later, while the round before counts, the line has left L2 again: 300 bytes of traffic per entry instead
+        // of 150, and 1.2 ms more per pass over 233 M entries.)
+        fin_chars_n<NW * NR>(T, S[e] + (C[e] >> 8), n, all[e]);
+      }
     }
   }
 #pragma unroll
@@ -1260,7 +1264,7 @@ __global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __
       const u32 lp = tid + (u32)e * kFinTPB;
       const u32 touch = (!RANK && (u64)S[e] + (C[e] >> 8) + kRound > (u64)n) ? 0x80000000u : 0u;        // (in the first round)
 #pragma unroll
-      for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = cur[e][q];
+      for (int q = 0; q < NW; ++q) s_ch[(u32)NW * lp + (u32)q] = all[e][q];
       s_S[lp] = S[e] | touch;
       touches |= (!RANK && (u64)S[e] + (C[e] >> 8) + kChars > (u64)n) ? 1 : 0;                           // (in any round)
     }
@@ -1276,21 +1280,19 @@ __global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __
         cnt[tid + (u32)e * kFinTPB] = 0u;
         if (g_cur[e] > 1u) {
 #pragma unroll
-          for (int q = 0; q < NW; ++q) s_ch[(u32)NW * pos[e] + (u32)q] = cur[e][q];
+          for (int q = 0; q < NW; ++q) s_ch[(u32)NW * pos[e] + (u32)q] = all[e][r * NW + q];
           s_S[pos[e]] = S[e] | (((u64)S[e] + (C[e] >> 8) + (r + 1u) * kRound > (u64)n) ? 0x80000000u : 0u);
         }
       }
       __syncthreads();
     }
-    if (!RANK && r + 1u < nr) {
-#pragma unroll
-      for (int e = 0; e < kFinE; ++e)
-        if (g_cur[e] > 1u) fin_chars_n<NW>(T, S[e] + (C[e] >> 8) + (r + 1u) * kRound, n, nxt[e]);
-    }
 #pragma unroll
     for (int e = 0; e < kFinE; ++e) {
       if (g_cur[e] > 1u) {
-        const u32 below = fin_count_below<NW>(s_ch, s_S, a_cur[e], a_cur[e] + g_cur[e], pos[e], S[e], cur[e], any_touch);
+        u64 key[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) key[q] = all[e][r * NW + q];
+        const u32 below = fin_count_below<NW>(s_ch, s_S, a_cur[e], a_cur[e] + g_cur[e], pos[e], S[e], key, any_touch);
         a_cur[e] += below;
         if (RANK) {               // the member's new rank, noted by list position (kFinNone: it keeps the one it has)
           const u32 q = w0 + pos[e];                                 // (a final member's slot is its sub-group's head)
@@ -1303,11 +1305,7 @@ __global__ BWTC_FIN_BOUNDS void k_finish(FinList in, FinRegions rg, const u8* __
     __syncthreads();               // every read of the round's characters is done, every arrival counted
 #pragma unroll
     for (int e = 0; e < kFinE; ++e) {
-      if (g_cur[e] > 1u) {
-        g_cur[e] = cnt[a_cur[e]];
-#pragma unroll
-        for (int q = 0; q < NW; ++q) cur[e][q] = nxt[e][q];
-      }
+      if (g_cur[e] > 1u) g_cur[e] = cnt[a_cur[e]];
     }
   }
   // (the characters' bytes become the staging)
@@ -1895,7 +1893,7 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_FIN_PASSES")) fin_max_passes = std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_PASSES")));
     if (std::getenv("BWTC_HIP_FIN_WORDS")) fin_words = std::min(4, std::max(2, std::atoi(std::getenv("BWTC_HIP_FIN_WORDS"))));
     if (std::getenv("BWTC_HIP_LONG_DIRECT")) long_direct = std::getenv("BWTC_HIP_LONG_DIRECT")[0] != '0';
-    if (std::getenv("BWTC_HIP_FIN_ROUNDS")) fin_rounds = std::min(3, std::max(1, std::atoi(std::getenv("BWTC_HIP_FIN_ROUNDS"))));
+    if (std::getenv("BWTC_HIP_FIN_ROUNDS")) fin_rounds = std::min(4, std::max(1, std::atoi(std::getenv("BWTC_HIP_FIN_ROUNDS"))));
     local_rounds = !(std::getenv("BWTC_HIP_LOCAL_ROUNDS") && std::getenv("BWTC_HIP_LOCAL_ROUNDS")[0] == '0');
     if (std::getenv("BWTC_HIP_FIN_FLOOR")) fin_floor = (u32)std::max(0, std::atoi(std::getenv("BWTC_HIP_FIN_FLOOR")));
     if (std::getenv("BWTC_HIP_TEXT_ROUNDS")) { text_rounds = std::max(0, std::atoi(std::getenv("BWTC_HIP_TEXT_ROUNDS"))); text_rounds_fixed = true; }
@@ -2794,7 +2792,8 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
 #define BWTC_FINISH_R(G, E, NR) hipLaunchKernelGGL((k_finish<G, E, 2, false, NR>), dim3(grid), dim3(kFinTPB), 0, st, a, rg, (const u8*)d_T, n, \
                                              b, ob, ncnt, d_parkS + park0, d_parkHP + park0, d_hardC, cnt + 1, shal, d_SA, re)
 #define BWTC_FINISH(G, E) do { if (fin_words >= 4) BWTC_FINISH_W(G, E, 4); else if (fin_words == 3) BWTC_FINISH_W(G, E, 3); \
-                               else if (fin_rounds >= 3) BWTC_FINISH_R(G, E, 3); else if (fin_rounds == 2) BWTC_FINISH_R(G, E, 2); else BWTC_FINISH_W(G, E, 2); } while (0)
+                               else if (fin_rounds >= 4) BWTC_FINISH_R(G, E, 4); else if (fin_rounds == 3) BWTC_FINISH_R(G, E, 3); \
+                               else if (fin_rounds == 2) BWTC_FINISH_R(G, E, 2); else BWTC_FINISH_W(G, E, 2); } while (0)
     if (window <= 1024) { if (group <= 256) BWTC_FINISH(256, kFinE1); else BWTC_FINISH(512, kFinE1); }
     else if (group <= 256) BWTC_FINISH(256, kFinE2);
     else if (group <= 512) BWTC_FINISH(512, kFinE2);

@@ -436,7 +436,7 @@ struct BwtEngine {
   int fin_max_group = 256;   // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
   int fin_words = 2;         // BWTC_HIP_FIN_WORDS=2|3|4: 8-character words a finisher pass compares
   bool long_direct = true;   // BWTC_HIP_LONG_DIRECT=0: every pass of the long-key sort takes its histogram from a digit plane (else: the second word's passes read the words)
-  int fin_rounds = 3;        // BWTC_HIP_FIN_ROUNDS=1|2|3 (with two words): rounds of fin_words words a finisher pass makes (the members a round leaves tied are compared again inside the workgroup)
+  int fin_rounds = 3;        // BWTC_HIP_FIN_ROUNDS=1..4 (with two words): rounds of fin_words words a finisher pass makes (the members a round leaves tied are compared again inside the workgroup)
   int fin_max_passes = 8;    // BWTC_HIP_FIN_PASSES: finisher passes at most before what is still tied takes the doubling rounds
   int text_rounds = 6;       // BWTC_HIP_TEXT_ROUNDS: rounds that compare the text itself before rank[] is completed for doubling
   bool text_rounds_fixed = false;

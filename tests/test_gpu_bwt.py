@@ -357,7 +357,7 @@ _SWITCH_INPUTS = []
                                     # the global list (the default), or joined to the global list as in round 4
                                     "BWTC_HIP_LOCAL_ROUNDS=0", "BWTC_HIP_LOCAL_ROUNDS=0,BWTC_HIP_FIN_FLOOR=48", "BWTC_HIP_FIN_GROUP=512,BWTC_HIP_FIN_WORDS=3",
                                     # rounds of sixteen characters a finisher pass makes inside the workgroup (default three)
-                                    "BWTC_HIP_FIN_ROUNDS=1", "BWTC_HIP_FIN_ROUNDS=2", "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_GROUP=512",
+                                    "BWTC_HIP_FIN_ROUNDS=1", "BWTC_HIP_FIN_ROUNDS=2", "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_GROUP=512", "BWTC_HIP_FIN_ROUNDS=4",
                                     "BWTC_HIP_FIN_ROUNDS=1,BWTC_HIP_FIN_PASSES=1",
                                     # the long-key sort's second-word passes with digit planes, as the key word's passes
                                     "BWTC_HIP_LONG_DIRECT=0"])
