@@ -1879,6 +1879,8 @@ int BwtEngine::init(int dev, u32 max_block_size) {
     if (std::getenv("BWTC_HIP_LONG_G2")) long_grams_override = std::atoi(std::getenv("BWTC_HIP_LONG_G2"));
     if (std::getenv("BWTC_HIP_FIN_GROUP")) fin_max_group = std::atoi(std::getenv("BWTC_HIP_FIN_GROUP"));
     if (std::getenv("BWTC_HIP_FIN_WINDOW")) fin_window = std::atoi(std::getenv("BWTC_HIP_FIN_WINDOW"));
+    fin_shape_fixed = std::getenv("BWTC_HIP_FIN_GROUP") || std::getenv("BWTC_HIP_FIN_WINDOW");
+    fin_wide_short = !(std::getenv("BWTC_HIP_FIN_WIDE") && std::getenv("BWTC_HIP_FIN_WIDE")[0] == '0');
     fin_window = fin_window >= 2048 ? 2048 : 1024;
     fin_max_group = fin_max_group >= 1024 ? 1024 : fin_max_group >= 512 ? 512 : 256;
     if (fin_max_group >= fin_window) fin_max_group = fin_window / 2;
@@ -2677,6 +2679,15 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // Groups of hundreds of members on average (a period, one text many times over) are not the finisher's: its loop
     // costs a group's size per member.  The list then goes to the rounds as it is (shallow groups apart).
     const bool giant = res.groups > 0 && (u64)res.m > (u64)res.groups * 64;
+    // The shape of the passes.  The comparison loop costs a group's size per member, which is why groups above 256 members
+    // are not the finisher's on a real text (most of the block is on its list).  A SHORT list -- the long keys told
+    // nearly everything apart: 2.6 % of the generator's text is left -- takes windows of 2048 entries and groups of up to
+    // 1024 members instead: the few large groups (tokens repeated: 19 K entries of 7 M) are settled with the others and
+    // no hard list is left for the text rounds, whose five rounds of tiny launches cost more than the whole pass
+    // (256 MiB: 21.9 -> 21.3 ms).  Bounded: the wide shape costs at most 0.45 ns per entry more (measured on a real
+    // text, where every group is large), n / 24 entries at most.
+    fin_window_blk = fin_window; fin_group_blk = fin_max_group;
+    if (!fin_shape_fixed && fin_wide_short && !giant && (u64)res.m * 24 <= (u64)n) { fin_window_blk = 2048; fin_group_blk = 1024; }
     rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds, giant ? 0 : fin_max_passes);
     if (rc) return rc;
     const u32 shallow = h_small[kSmallFin + 4];
@@ -2755,7 +2766,7 @@ int BwtEngine::finisher_passes(u32 n, u32 m, FinList a, FinList b, RrEmit& re, F
   u32 hard = 0;
   passes_done = 0;
   const u32 park0 = parked;            // the groups too large for a window join the waiting list from here
-  const int window = fin_window, group = fin_max_group;
+  const int window = fin_window_blk, group = fin_group_blk;
   const u32 stride = (u32)(window - group);
   FinRegions rg;
   std::memset(&rg, 0, sizeof rg);
@@ -2916,7 +2927,7 @@ int BwtEngine::local_pass(u32 n, u64 h_global, RrEmit& re) {
   if (at2 + delta > 0xFFFFFFF0ull) return -3;
   u32* cnt = d_small + kSmallFin;
   u32* ncnt = d_small + kSmallFinNext;
-  const int window = fin_window, group = fin_max_group;   // the local list's groups are as large as the finisher's passes left them
+  const int window = fin_window_blk, group = fin_group_blk;   // the local list's groups are as large as the finisher's passes left them
   const u32 stride = (u32)(window - group);
   BWTC_HIP_TRY(hipMemsetAsync(ncnt, 0, kFinRegions * 4, st));
   BWTC_HIP_TRY(hipMemsetAsync(cnt + 1, 0, 4, st));

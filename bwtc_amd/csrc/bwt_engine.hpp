@@ -435,6 +435,11 @@ struct BwtEngine {
   int fin_window = 1024;     // BWTC_HIP_FIN_WINDOW=2048: entries a finisher workgroup sorts
   int fin_max_group = 256;   // BWTC_HIP_FIN_GROUP=256|512|1024: the largest group the finisher settles (larger ones take the text rounds)
   int fin_words = 2;         // BWTC_HIP_FIN_WORDS=2|3|4: 8-character words a finisher pass compares
+  bool fin_shape_fixed = false;  // either of the two was given: every block takes that shape
+  bool fin_wide_short = true;    // BWTC_HIP_FIN_WIDE=0: a short list (the long keys left at most n / 24 suffixes tied) keeps the default shape;
+                                 // else it takes windows of 2048 entries and groups of up to 1024 members, and no hard list is left for the rounds
+  int fin_window_blk = 1024;     // this block's shape (finisher_passes and local_pass must agree: the local list's groups are as large as the passes left them)
+  int fin_group_blk = 256;
   bool long_direct = true;   // BWTC_HIP_LONG_DIRECT=0: every pass of the long-key sort takes its histogram from a digit plane (else: the second word's passes read the words)
   int fin_rounds = 3;        // BWTC_HIP_FIN_ROUNDS=1..4 (with two words): rounds of fin_words words a finisher pass makes (the members a round leaves tied are compared again inside the workgroup)
   int fin_max_passes = 8;    // BWTC_HIP_FIN_PASSES: finisher passes at most before what is still tied takes the doubling rounds

@@ -39,7 +39,7 @@ def packed(v):
 
 
 FUZZ6_KEYS = ("BWTC_HIP_FIN_PASSES", "BWTC_HIP_TEXT_ROUNDS", "BWTC_HIP_LONG_G2", "BWTC_HIP_FINISHER", "BWTC_HIP_FIN_GROUP", "BWTC_HIP_KEYS",
-              "BWTC_HIP_CODE_BITS", "BWTC_HIP_FIN_FLOOR", "BWTC_HIP_LOCAL_ROUNDS", "BWTC_HIP_FIN_WINDOW", "BWTC_HIP_FIN_WORDS", "BWTC_HIP_FIN_ROUNDS")
+              "BWTC_HIP_CODE_BITS", "BWTC_HIP_FIN_FLOOR", "BWTC_HIP_LOCAL_ROUNDS", "BWTC_HIP_FIN_WINDOW", "BWTC_HIP_FIN_WORDS", "BWTC_HIP_FIN_ROUNDS", "BWTC_HIP_FIN_WIDE")
 
 
 def main():
@@ -176,7 +176,8 @@ def main():
                 {"BWTC_HIP_KEYS": "grams"}, {"BWTC_HIP_CODE_BITS": "48", "BWTC_HIP_FIN_GROUP": "512"}, {"BWTC_HIP_FIN_FLOOR": "48", "BWTC_HIP_FIN_PASSES": "1"},
                 {"BWTC_HIP_LOCAL_ROUNDS": "0"}, {"BWTC_HIP_FIN_WINDOW": "2048", "BWTC_HIP_FIN_GROUP": "1024", "BWTC_HIP_FIN_WORDS": "3"},
                 {"BWTC_HIP_FIN_FLOOR": "0"}, {"BWTC_HIP_CODE_BITS": "64", "BWTC_HIP_TEXT_ROUNDS": "0"},
-                {"BWTC_HIP_FIN_ROUNDS": "1"}, {"BWTC_HIP_FIN_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "1"}]
+                {"BWTC_HIP_FIN_ROUNDS": "1"}, {"BWTC_HIP_FIN_ROUNDS": "2", "BWTC_HIP_FIN_PASSES": "1"},
+                {"BWTC_HIP_FIN_WIDE": "0"}, {"BWTC_HIP_FIN_WIDE": "0", "BWTC_HIP_FIN_PASSES": "1"}]
     while "6" in phases and time.time() - t0 < budget:
         var = variants[n6 % len(variants)]
         os.environ["BWTC_HIP_GRAM_MIN_N"] = "64"

@@ -360,7 +360,10 @@ _SWITCH_INPUTS = []
                                     "BWTC_HIP_FIN_ROUNDS=1", "BWTC_HIP_FIN_ROUNDS=2", "BWTC_HIP_FIN_ROUNDS=2,BWTC_HIP_FIN_GROUP=512", "BWTC_HIP_FIN_ROUNDS=4",
                                     "BWTC_HIP_FIN_ROUNDS=1,BWTC_HIP_FIN_PASSES=1",
                                     # the long-key sort's second-word passes with digit planes, as the key word's passes
-                                    "BWTC_HIP_LONG_DIRECT=0"])
+                                    "BWTC_HIP_LONG_DIRECT=0",
+                                    # a short list keeps the finisher's default shape (default: windows of 2048 entries and
+                                    # groups of up to 1024 members when the long keys left at most n / 24 suffixes tied)
+                                    "BWTC_HIP_FIN_WIDE=0", "BWTC_HIP_FIN_WIDE=0,BWTC_HIP_FIN_ROUNDS=2"])
 def test_sorter_feature_switches_agree(oracle, monkeypatch, switch):
     """Every switch that turns a feature of the suffix sorter off (or another way) changes speed
     only: a 6 MiB text block and a block with zero bytes against the reference's sorter."""
