@@ -2687,8 +2687,13 @@ int BwtEngine::suffix_sort(u32 n, const u32* hist, bool lone_sentinel, const Emi
     // (256 MiB: 21.9 -> 21.3 ms).  Bounded: the wide shape costs at most 0.45 ns per entry more (measured on a real
     // text, where every group is large), n / 24 entries at most.
     fin_window_blk = fin_window; fin_group_blk = fin_max_group;
-    if (!fin_shape_fixed && fin_wide_short && !giant && (u64)res.m * 24 <= (u64)n) { fin_window_blk = 2048; fin_group_blk = 1024; }
-    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds, giant ? 0 : fin_max_passes);
+    // One pass only in that shape: what three rounds of sixteen characters leave tied in a short list is deep repeats
+    // (copies of a long piece), the rounds' business -- further passes over groups of hundreds of members cost their size
+    // per member and settle nothing (300 copies of a 10 KB piece in the generator's text: 32.6 ms with three passes, 30.0
+    // in the narrow shape, where such groups are hard at once).
+    bool wide = false;
+    if (!fin_shape_fixed && fin_wide_short && !giant && (u64)res.m * 24 <= (u64)n) { fin_window_blk = 2048; fin_group_blk = 1024; wide = true; }
+    rc = finisher_passes(n, res.m, la, lb, re, shal, &fo, local_rounds, giant ? 0 : wide ? std::min(1, fin_max_passes) : fin_max_passes);
     if (rc) return rc;
     const u32 shallow = h_small[kSmallFin + 4];
     const u64 h_sh = h_small[kSmallFin + 5];

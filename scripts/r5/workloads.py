@@ -60,6 +60,17 @@ def gen(kind, n):
             d = np.tile(d, n // d.size + 1)[:n]
             what += " (repeated to size)"
         return d.copy(), what
+    if kind.startswith("c3copies"):
+        # the generator's text with COPIES copies (default 300) of one 10 KB piece of it at random places: a short finisher
+        # list (a few per cent of the block) whose groups are large AND deep -- the wide shape's worst case
+        copies = int(kind[8:] or 300)
+        d, _ = r4.gen("c3", n)
+        d = d.copy()
+        rng = np.random.default_rng(11)
+        piece = d[12345:12345 + 10000].copy()
+        for at in rng.integers(0, n - 10000, copies):
+            d[at:at + 10000] = piece
+        return d, "C3 generator with %d copies of a 10 KB piece at random places" % copies
     return r4.gen(kind, n)
 
 
