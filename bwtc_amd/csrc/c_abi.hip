@@ -762,6 +762,7 @@ int bwtc_hip_test_sort_u64(bwtc_hip_ctx* ctx, uint64_t* keys, uint32_t* vals, ui
 int bwtc_hip_test_gpu_lanes(bwtc_hip_ctx* ctx, const uint16_t* w, uint64_t n, const uint64_t* bounds, uint32_t k, int mode,
                             uint8_t* out, uint64_t out_cap, uint64_t* offsets) {
   if (!ctx || !w || !bounds || !out || !offsets || k == 0 || bounds[k] > n) return -1;
+  for (uint32_t j = 0; j < k; ++j) if (bounds[j] > bounds[j + 1]) return -1;       // chains are [bounds[j], bounds[j + 1])
   BWTC_HIP_TRY(hipSetDevice(ctx->eng.device));
   std::vector<std::vector<uint8_t> > outs(k);
   struct Src : bwtc::wavelet::ChainSource {
